@@ -1,0 +1,281 @@
+"""ctypes view of the C ABI (include/ergodic_amd.h) of the gfx950 engine.
+
+This is plumbing for tests and bench.py: it loads ergodic_exploration_amd/lib/libergodic_amd.so
+and fails loudly when the library is missing.  There is no CPU fallback: every compute
+entry point runs HIP kernels on the device.
+"""
+import ctypes as C
+import os
+import re
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "lib", "libergodic_amd.so")
+HEADER_PATH = os.path.join(ROOT, "include", "ergodic_amd.h")
+
+MODEL_OMNI, MODEL_SIMPLE_CART = 0, 1
+PREC_F64, PREC_F32 = 0, 1
+OK, ERR_INVALID_ARGUMENT, ERR_INVALID_TWIST, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_TARGET = range(6)
+
+
+class EngineError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("eea status %d: %s" % (status, msg))
+        self.status = status
+
+
+class Config(C.Structure):
+    _fields_ = [("model", C.c_int), ("precision", C.c_int), ("device", C.c_int),
+                ("dt", C.c_double), ("horizon", C.c_double), ("resolution", C.c_double),
+                ("expl_weight", C.c_double), ("num_basis", C.c_uint),
+                ("Rinv", C.c_double * 9), ("umin", C.c_double * 3), ("umax", C.c_double * 3)]
+
+
+class BatchIO(C.Structure):
+    _fields_ = [("d_pose", C.c_void_p), ("d_ut", C.c_void_p), ("d_mem_cols", C.c_void_p),
+                ("d_n_mem", C.c_void_p), ("mem_stride", C.c_uint), ("d_u0", C.c_void_p),
+                ("d_traj", C.c_void_p), ("d_ck", C.c_void_p), ("d_edx", C.c_void_p),
+                ("d_bdx", C.c_void_p), ("d_rhot", C.c_void_p), ("d_status", C.c_void_p)]
+
+
+class CollisionCfg(C.Structure):
+    _fields_ = [("xmin", C.c_double), ("ymin", C.c_double), ("resolution", C.c_double),
+                ("xsize", C.c_uint), ("ysize", C.c_uint), ("boundary_radius", C.c_double),
+                ("search_radius", C.c_double), ("obstacle_threshold", C.c_double),
+                ("occupied_threshold", C.c_double)]
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 build of the library (csrc/Makefile)."""
+    args = ["make", "-s", "-j4", "-C", os.path.join(_HERE, "csrc")]
+    if force:
+        subprocess.check_call(args + ["clean"])
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+def declared_symbols():
+    """Entry points declared in include/ergodic_amd.h."""
+    with open(HEADER_PATH) as f:
+        text = f.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(eea_[a-z0-9_]+)\s*\(", text)))
+
+
+_lib = None
+
+
+def lib():
+    """Loads the shared library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError("libergodic_amd.so is missing: run __graft_entry__.build() "
+                               "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.eea_last_error.restype = C.c_char_p
+        L.eea_steps.restype = C.c_uint
+        L.eea_num_modes.restype = C.c_uint
+        L.eea_real_size.restype = C.c_size_t
+        L.eea_time_step.restype = C.c_double
+        L.eea_abi_version.restype = C.c_uint
+        for name in ("eea_steps", "eea_num_modes", "eea_real_size", "eea_time_step", "eea_destroy"):
+            getattr(L, name).argtypes = [C.c_void_p]
+        L.eea_destroy.restype = None
+        L.eea_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+        L.eea_set_target_gaussians.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p]
+        L.eea_set_target_grid.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_int,
+                                          C.c_double, C.c_double, C.c_void_p]
+        L.eea_config_domain.argtypes = [C.c_void_p] + [C.c_double] * 4 + [C.POINTER(C.c_int), C.c_void_p]
+        L.eea_get_phik.argtypes = [C.c_void_p, C.c_void_p]
+        L.eea_get_lamdak.argtypes = [C.c_void_p, C.c_void_p]
+        L.eea_target_grid_size.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+        L.eea_get_target_grid.argtypes = [C.c_void_p, C.c_void_p]
+        L.eea_control_batch.argtypes = [C.c_void_p, C.c_uint, C.POINTER(BatchIO), C.c_void_p]
+        L.eea_rollout_batch.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]
+        L.eea_control.argtypes = [C.c_void_p] + [C.c_double] * 4 + [C.c_void_p, C.c_void_p, C.c_uint,
+                                                                     C.c_void_p]
+        L.eea_opt_traj.argtypes = [C.c_void_p, C.c_void_p]
+        L.eea_get_ut.argtypes = [C.c_void_p, C.c_void_p]
+        L.eea_set_ut.argtypes = [C.c_void_p, C.c_void_p]
+        L.eea_basis_traj_coeff.argtypes = [C.c_int, C.c_double, C.c_double, C.c_uint, C.c_void_p,
+                                           C.c_uint, C.c_uint, C.c_void_p]
+        L.eea_basis_spatial_coeff.argtypes = [C.c_int, C.c_double, C.c_double, C.c_uint, C.c_void_p,
+                                              C.c_void_p, C.c_uint, C.c_void_p]
+        L.eea_collision_check_batch.argtypes = [C.c_int, C.POINTER(CollisionCfg), C.c_void_p,
+                                                C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p]
+        L.eea_validate_control_batch.argtypes = [C.c_int, C.POINTER(CollisionCfg), C.c_void_p,
+                                                 C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                                 C.c_uint, C.c_void_p, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def check(status):
+    if status != OK:
+        raise EngineError(status, lib().eea_last_error().decode())
+
+
+def make_config(model, dt, horizon, resolution, expl_weight, num_basis, Rinv, umin, umax,
+                precision=PREC_F64, device=0):
+    cfg = Config()
+    cfg.model, cfg.precision, cfg.device = model, precision, device
+    cfg.dt, cfg.horizon, cfg.resolution, cfg.expl_weight = dt, horizon, resolution, expl_weight
+    cfg.num_basis = num_basis
+    for c in range(3):
+        for r in range(3):
+            cfg.Rinv[r + 3 * c] = float(Rinv[r][c])
+    for i in range(3):
+        cfg.umin[i] = float(umin[i])
+        cfg.umax[i] = float(umax[i])
+    return cfg
+
+
+def _ptr(t):
+    """Raw device/host pointer of a torch tensor, numpy array or None."""
+    if t is None:
+        return None
+    if hasattr(t, "data_ptr"):
+        return C.c_void_p(t.data_ptr())
+    return C.c_void_p(t.ctypes.data)
+
+
+class Engine:
+    """One `ErgodicControl` engine (handle of the C ABI)."""
+
+    def __init__(self, cfg):
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        check(lib().eea_create(C.byref(cfg), C.byref(self.h)))
+        self.T = int(lib().eea_steps(self.h))
+        self.K2 = int(lib().eea_num_modes(self.h))
+        self.real_size = int(lib().eea_real_size(self.h))
+
+    def close(self):
+        if self.h:
+            lib().eea_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_target_gaussians(self, mu, sigma):
+        import numpy as np
+        mu = np.ascontiguousarray(mu, dtype=np.float64).reshape(-1)
+        sigma = np.ascontiguousarray(sigma, dtype=np.float64).reshape(-1)
+        check(lib().eea_set_target_gaussians(self.h, mu.size // 2, _ptr(mu), _ptr(sigma)))
+
+    def set_target_grid(self, nx, ny, phi_vals, lx, ly, stream=None):
+        on_device = 1 if (hasattr(phi_vals, "is_cuda") and phi_vals.is_cuda) else 0
+        check(lib().eea_set_target_grid(self.h, nx, ny, _ptr(phi_vals), on_device, lx, ly,
+                                        C.c_void_p(stream or 0)))
+
+    def config_domain(self, bounds, stream=None):
+        rebuilt = C.c_int(0)
+        check(lib().eea_config_domain(self.h, *[float(b) for b in bounds], C.byref(rebuilt),
+                                      C.c_void_p(stream or 0)))
+        return bool(rebuilt.value)
+
+    def phik(self):
+        import numpy as np
+        out = np.empty(self.K2)
+        check(lib().eea_get_phik(self.h, _ptr(out)))
+        return out
+
+    def lamdak(self):
+        import numpy as np
+        out = np.empty(self.K2)
+        check(lib().eea_get_lamdak(self.h, _ptr(out)))
+        return out
+
+    def target_grid(self):
+        import numpy as np
+        nx, ny = C.c_uint(), C.c_uint()
+        check(lib().eea_target_grid_size(self.h, C.byref(nx), C.byref(ny)))
+        out = np.empty(nx.value * ny.value)
+        check(lib().eea_get_target_grid(self.h, _ptr(out)))
+        return out, nx.value, ny.value
+
+    def control_batch(self, B, pose, ut, u0, mem_cols=None, n_mem=None, mem_stride=0, traj=None,
+                      ck=None, edx=None, bdx=None, rhot=None, status=None, stream=None):
+        io = BatchIO()
+        io.d_pose, io.d_ut, io.d_u0 = _ptr(pose), _ptr(ut), _ptr(u0)
+        io.d_mem_cols, io.d_n_mem, io.mem_stride = _ptr(mem_cols), _ptr(n_mem), mem_stride
+        io.d_traj, io.d_ck, io.d_edx, io.d_bdx = _ptr(traj), _ptr(ck), _ptr(edx), _ptr(bdx)
+        io.d_rhot, io.d_status = _ptr(rhot), _ptr(status)
+        check(lib().eea_control_batch(self.h, B, C.byref(io), C.c_void_p(stream or 0)))
+
+    def rollout_batch(self, B, pose, ut, traj, status=None, stream=None):
+        check(lib().eea_rollout_batch(self.h, B, _ptr(pose), _ptr(ut), _ptr(traj), _ptr(status),
+                                      C.c_void_p(stream or 0)))
+
+    def control(self, bounds, x, mem_cols=None):
+        """Single agent, host buffers: mirrors ErgodicControl::control(grid, x)."""
+        import numpy as np
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        u = np.empty(3)
+        n_mem, mem = 0, None
+        if mem_cols is not None and np.asarray(mem_cols).size:
+            mem = np.ascontiguousarray(np.asarray(mem_cols, dtype=np.float64).T)  # (n_mem, 3)
+            n_mem = mem.shape[0]
+        check(lib().eea_control(self.h, *[float(b) for b in bounds], _ptr(x), _ptr(mem), n_mem,
+                                _ptr(u)))
+        return u
+
+    def opt_traj(self):
+        import numpy as np
+        out = np.empty((self.T, 3))
+        check(lib().eea_opt_traj(self.h, _ptr(out)))
+        return out.T.copy()
+
+    def get_ut(self):
+        import numpy as np
+        out = np.empty((self.T, 3))
+        check(lib().eea_get_ut(self.h, _ptr(out)))
+        return out.T.copy()
+
+    def set_ut(self, ut):
+        import numpy as np
+        a = np.ascontiguousarray(np.asarray(ut, dtype=np.float64).T)
+        check(lib().eea_set_ut(self.h, _ptr(a)))
+
+
+def basis_traj_coeff(lx, ly, K, xt, device=0):
+    import numpy as np
+    xt = np.asarray(xt, dtype=np.float64)
+    rows, n = xt.shape
+    a = np.ascontiguousarray(xt.T)
+    out = np.empty(K * K)
+    check(lib().eea_basis_traj_coeff(device, lx, ly, K, _ptr(a), rows, n, _ptr(out)))
+    return out
+
+
+def basis_spatial_coeff(lx, ly, K, phi_vals, grid, device=0):
+    import numpy as np
+    pv = np.ascontiguousarray(phi_vals, dtype=np.float64)
+    g = np.ascontiguousarray(np.asarray(grid, dtype=np.float64).T)
+    out = np.empty(K * K)
+    check(lib().eea_basis_spatial_coeff(device, lx, ly, K, _ptr(pv), _ptr(g), pv.size, _ptr(out)))
+    return out
+
+
+def make_collision_cfg(xmin, ymin, resolution, xsize, ysize, boundary_radius, search_radius,
+                       obstacle_threshold, occupied_threshold):
+    return CollisionCfg(xmin, ymin, resolution, xsize, ysize, boundary_radius, search_radius,
+                        obstacle_threshold, occupied_threshold)
+
+
+def collision_check_batch(cfg, grid, pose, hit, device=0, stream=None):
+    check(lib().eea_collision_check_batch(device, C.byref(cfg), _ptr(grid), _ptr(pose),
+                                          pose.shape[0], _ptr(hit), C.c_void_p(stream or 0)))
+
+
+def validate_control_batch(cfg, grid, x0, u, dt, horizon, valid, device=0, stream=None):
+    check(lib().eea_validate_control_batch(device, C.byref(cfg), _ptr(grid), _ptr(x0), _ptr(u), dt,
+                                           horizon, x0.shape[0], _ptr(valid),
+                                           C.c_void_p(stream or 0)))

@@ -1,0 +1,156 @@
+// Batched collision lookups for gfx950: Collision::collisionCheck (reference
+// collision.cpp:126-243) on a GridMap (grid.cpp:96-184) and validate_control
+// (numerics.hpp:273-330).  Integer work, one pose per lane; results are bit-exact with the
+// reference's x86-64 build, including the wrap of negative world coordinates in world2Grid.
+#include "common.hpp"
+
+namespace eea
+{
+namespace
+{
+// static_cast<unsigned>(double) as x86-64 gcc compiles it (cvttsd2si r64, low 32 bits):
+// negative and > 2^32 values wrap mod 2^32, out-of-range / NaN give 0.  The GPU's own
+// double->u32 conversion saturates, so it is not used.
+__device__ __forceinline__ unsigned cast_u32_x86(double v)
+{
+  if (!(v > -9.2233720368547758e18 && v < 9.2233720368547758e18)) return 0u;
+  return static_cast<unsigned>(static_cast<unsigned long long>(static_cast<long long>(v)));
+}
+
+struct RingState
+{
+  int cx, cy, sqrd_obs;
+};
+
+// collision.cpp:216-243 (+ grid.cpp:96-100, 109-117, 177-184)
+__device__ __forceinline__ bool check_cell(const CollisionParams& c, const int8_t* __restrict__ grid,
+                                           RingState& st, unsigned cj, unsigned ci)
+{
+  if ((ci <= c.ysize - 1u) && (cj <= c.xsize - 1u)) {
+    const double cell = static_cast<double>(grid[ci * c.xsize + cj]) / 100.0;
+    if (!(cell < c.occupied_threshold)) {
+      const unsigned ddx = static_cast<unsigned>(st.cx) - cj, ddy = static_cast<unsigned>(st.cy) - ci;
+      const int sq = static_cast<int>(ddx * ddx + ddy * ddy);
+      if (sq < st.sqrd_obs || st.sqrd_obs == -1) st.sqrd_obs = sq;
+      if (sq <= c.r_col * c.r_col) return true;
+    }
+  }
+  return false;
+}
+
+// collision.cpp:166-214
+__device__ __forceinline__ bool bresenham_circle(const CollisionParams& c,
+                                                 const int8_t* __restrict__ grid, RingState& st, int r)
+{
+  int x = -r, y = 0, err = 2 - 2 * r;
+  while (x < 0) {
+    if (check_cell(c, grid, st, static_cast<unsigned>(st.cx - x), static_cast<unsigned>(st.cy + y))) return true;
+    if (check_cell(c, grid, st, static_cast<unsigned>(st.cx - y), static_cast<unsigned>(st.cy - x))) return true;
+    if (check_cell(c, grid, st, static_cast<unsigned>(st.cx + x), static_cast<unsigned>(st.cy - y))) return true;
+    if (check_cell(c, grid, st, static_cast<unsigned>(st.cx + y), static_cast<unsigned>(st.cy + x))) return true;
+    r = err;
+    if (r <= y) {
+      y++;
+      err += 2 * y + 1;
+    }
+    if (r > x || err > y) {
+      x++;
+      err += 2 * x + 1;
+    }
+  }
+  return false;
+}
+
+// collision.cpp:126-164 with grid.cpp:143-159
+__device__ __forceinline__ bool collision_check(const CollisionParams& c,
+                                                const int8_t* __restrict__ grid, double px, double py)
+{
+  unsigned j = cast_u32_x86(floor((px - c.xmin) / c.resolution));
+  unsigned i = cast_u32_x86(floor((py - c.ymin) / c.resolution));
+  if (j == c.xsize) j--;
+  if (i == c.ysize) i--;
+  RingState st;
+  st.cx = static_cast<int>(j);
+  st.cy = static_cast<int>(i);
+  st.sqrd_obs = -1;
+  for (int r = c.r_bnd; r <= c.r_max; ++r) {
+    if (bresenham_circle(c, grid, st, r)) return true;
+  }
+  return false;
+}
+
+__global__ __launch_bounds__(kBlock) void collision_check_kernel(const CollisionParams c,
+                                                                 const int8_t* __restrict__ grid,
+                                                                 const double* __restrict__ pose,
+                                                                 unsigned P, int* __restrict__ hit)
+{
+  const unsigned q = blockIdx.x * kBlock + threadIdx.x;
+  if (q >= P) return;
+  hit[q] = collision_check(c, grid, pose[3 * static_cast<size_t>(q)], pose[3 * static_cast<size_t>(q) + 1]) ? 1 : 0;
+}
+
+__device__ __forceinline__ double wrap_pi_d(double rad) { return wrap_pi<double>(rad); }
+
+// numerics.hpp:273-330
+__global__ __launch_bounds__(kBlock) void validate_control_kernel(const CollisionParams c,
+                                                                  const int8_t* __restrict__ grid,
+                                                                  const double* __restrict__ x0,
+                                                                  const double* __restrict__ u,
+                                                                  double dt, unsigned steps, unsigned P,
+                                                                  int* __restrict__ valid)
+{
+  const unsigned q = blockIdx.x * kBlock + threadIdx.x;
+  if (q >= P) return;
+  double x = x0[3 * static_cast<size_t>(q)], y = x0[3 * static_cast<size_t>(q) + 1],
+         th = x0[3 * static_cast<size_t>(q) + 2];
+  const double u0 = u[3 * static_cast<size_t>(q)], u1 = u[3 * static_cast<size_t>(q) + 1],
+               u2 = u[3 * static_cast<size_t>(q) + 2];
+  // body-frame displacement of one step is the same every step (constant twist)
+  double d0, d1, d2;
+  if (fabs(u2 - 0.0) < 1.0e-12) {
+    d0 = u0 * dt;
+    d1 = u1 * dt;
+    d2 = 0.0;
+  } else {
+    const double vb0 = u0 * dt, vb1 = u1 * dt, vb2 = u2 * dt;
+    double s, cc;
+    sincos(vb2, &s, &cc);
+    d0 = (vb0 * s + vb1 * (cc - 1.0)) / vb2;
+    d1 = (vb1 * s + vb0 * (1.0 - cc)) / vb2;
+    d2 = vb2;
+  }
+  int ok = 1;
+  for (unsigned i = 0; i < steps; ++i) {
+    double s, cc;
+    sincos(th, &s, &cc);
+    x = x + (cc * d0 + (-s) * d1);
+    y = y + (s * d0 + cc * d1);
+    th = wrap_pi_d(th + d2);
+    if (collision_check(c, grid, x, y)) {
+      ok = 0;
+      break;
+    }
+  }
+  valid[q] = ok;
+}
+}  // namespace
+
+hipError_t launch_collision_check(const CollisionParams& c, const int8_t* d_grid,
+                                  const double* d_pose, unsigned P, int* d_hit, hipStream_t s)
+{
+  if (P == 0) return hipSuccess;
+  hipLaunchKernelGGL(collision_check_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, c,
+                     d_grid, d_pose, P, d_hit);
+  return hipGetLastError();
+}
+
+hipError_t launch_validate_control(const CollisionParams& c, const int8_t* d_grid,
+                                   const double* d_x0, const double* d_u, double dt, unsigned steps,
+                                   unsigned P, int* d_valid, hipStream_t s)
+{
+  if (P == 0) return hipSuccess;
+  hipLaunchKernelGGL(validate_control_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, c,
+                     d_grid, d_x0, d_u, dt, steps, P, d_valid);
+  return hipGetLastError();
+}
+}  // namespace eea

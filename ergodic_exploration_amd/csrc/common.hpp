@@ -1,0 +1,183 @@
+// Shared declarations of the gfx950 kernels behind include/ergodic_amd.h.
+// Host launchers are declared here and defined next to their kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+namespace eea
+{
+constexpr int kBlock = 256;    // threads per workgroup: 4 wavefronts of 64 lanes
+constexpr int kWave = 64;
+constexpr int kMaxBasis = 32;  // K <= 32 (K^2 <= 1024 modes)
+
+// numerics.hpp:59 of the reference
+constexpr double kPi = 3.14159265358979323846;
+
+enum : int { kModelOmni = 0, kModelSimpleCart = 1 };
+
+// Everything one control launch needs; passed by value (kernarg).
+template <typename R>
+struct ControlParams
+{
+  int T;              // steps_ (ergodic_control.hpp:199)
+  int K;              // num_basis
+  int chunk;          // points staged per contraction pass (multiple of 64)
+  unsigned mem_stride;
+  R dt, lx, ly, map_x, map_y, expl_weight;
+  R pi_lx, pi_ly;     // PI / lx, PI / ly (basis.cpp:85)
+  R Rinv[9];          // column-major
+  R umin[3], umax[3];
+  const R* phik;      // [K^2]
+  const R* lamdak;    // [K^2]
+  // per-agent buffers (see eea_batch_io)
+  const R* pose;
+  R* ut;
+  const R* mem_cols;
+  const int* n_mem;
+  R* u0;
+  R* traj;
+  R* ck;
+  R* edx;
+  R* bdx;
+  R* rhot;
+  int* status;
+};
+
+template <typename R>
+size_t control_lds_bytes(int T, int K, int n_mem_max, int chunk);
+
+// Launches the fused control kernel for B agents.  rollout_only: stop after the forward
+// pass (optTraj), using ut as is (no shift).  Returns hipSuccess or the launch error.
+template <typename R>
+hipError_t launch_control(const ControlParams<R>& p, unsigned B, int model, int n_mem_max,
+                          bool rollout_only, hipStream_t stream);
+
+// ---- phi_k path ----------------------------------------------------------------------
+// cos tables: out[k * n + i] = cos((k * pi_over_l) * coord[i]), k < K
+template <typename R>
+hipError_t launch_cos_tables(const R* d_coord, int n, int K, R pi_over_l, R* d_out, hipStream_t s);
+// transposed layout: out[i * K + k]
+template <typename R>
+hipError_t launch_cos_tables_t(const R* d_coord, int n, int K, R pi_over_l, R* d_out, hipStream_t s);
+
+// Target::fill without the normalisation: phi[iy*nx+ix] = sum_g exp(-0.5 d^T Sigma^-1 d).
+// d_gauss: [n_gauss][4] = mean in the Fourier frame (mu - map_pos) and diag(cov_inv).
+// Block partial sums of phi go to d_partials[*n_partials] (>= ceil(nx*ny/256) reals).
+template <typename R>
+hipError_t launch_target_fill(const R* d_xs, const R* d_ys, int nx, int ny, const R* d_gauss,
+                              int n_gauss, R* d_phi, R* d_partials, int* n_partials, hipStream_t s);
+
+// deterministic sum of n values -> d_out[0]
+template <typename R>
+hipError_t launch_reduce_sum(const R* d_in, int n, R* d_out, hipStream_t s);
+
+// phi_vals *= 1 / d_sum[0]   (Target::fill's normalisation, target.cpp:87)
+template <typename R>
+hipError_t launch_scale_by_inv(R* d_phi, size_t n, const R* d_sum, hipStream_t s);
+
+// spatialCoeff on a regular grid (separable form): two passes, atomics-free.
+// d_cx: [K][nx], d_cy: [ny][K] (note the transposed layout of the y table),
+// d_work: >= spatial_work_elems(nx, ny, K) reals, d_phik: [K^2] (col = k2*K + k1)
+size_t spatial_work_elems(int nx, int ny, int K);
+template <typename R>
+hipError_t launch_spatial_coeff(const R* d_phi, int nx, int ny, int K, const R* d_cx, const R* d_cy,
+                                R* d_work, R* d_phik, hipStream_t s);
+
+// Weighted basis sum over an arbitrary point list (Basis::trajCoeff / spatialCoeff):
+// out[m] = scale * sum_p w_p f_m(x_p, y_p); d_w may be null (w = 1).
+// d_work: >= point_work_elems(P, K) reals.
+size_t point_work_elems(unsigned P, int K);
+template <typename R>
+hipError_t launch_point_coeff(const R* d_x, const R* d_y, const R* d_w, unsigned P, int K, R pi_lx,
+                              R pi_ly, R scale, R* d_work, R* d_out, hipStream_t s);
+
+// ---- collision path (integer, bit-exact) ------------------------------------------------
+struct CollisionParams
+{
+  double xmin, ymin, resolution;
+  unsigned xsize, ysize;
+  int r_bnd, r_col, r_max;
+  double occupied_threshold;
+};
+hipError_t launch_collision_check(const CollisionParams& c, const int8_t* d_grid,
+                                  const double* d_pose, unsigned P, int* d_hit, hipStream_t s);
+hipError_t launch_validate_control(const CollisionParams& c, const int8_t* d_grid,
+                                   const double* d_x0, const double* d_u, double dt, unsigned steps,
+                                   unsigned P, int* d_valid, hipStream_t s);
+
+// ======================================================================================
+// device helpers
+// ======================================================================================
+#if defined(__HIPCC__)
+
+template <typename R>
+__device__ __forceinline__ void sincos_r(R a, R* s, R* c);
+template <>
+__device__ __forceinline__ void sincos_r<double>(double a, double* s, double* c)
+{
+  sincos(a, s, c);
+}
+template <>
+__device__ __forceinline__ void sincos_r<float>(float a, float* s, float* c)
+{
+  sincosf(a, s, c);
+}
+
+// numerics.hpp:78-90 of the reference: wrap to [-pi, pi)
+template <typename R>
+__device__ __forceinline__ R wrap_pi(R rad)
+{
+  const R pi = static_cast<R>(kPi);
+  const R q = floor((rad + pi) / (R(2) * pi));
+  rad = (rad + pi) - q * R(2) * pi;
+  if (rad < R(0)) rad += R(2) * pi;
+  return rad - pi;
+}
+
+// std::clamp semantics (NaN passes through), ergodic_control.hpp:447-449
+template <typename R>
+__device__ __forceinline__ R clamp_std(R v, R lo, R hi)
+{
+  return (v < lo) ? lo : ((hi < v) ? hi : v);
+}
+
+template <typename R>
+__device__ __forceinline__ R wave_inclusive_scan(R v)
+{
+  const int lane = threadIdx.x & (kWave - 1);
+#pragma unroll
+  for (int o = 1; o < kWave; o <<= 1) {
+    const R t = __shfl_up(v, o, kWave);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+// Inclusive scan over the workgroup (kBlock threads).  s_w: kBlock/kWave + 1 reals of LDS
+// scratch.  Returns the inclusive prefix; *total receives the workgroup sum.
+// Contains two __syncthreads().
+template <typename R>
+__device__ __forceinline__ R block_inclusive_scan(R v, R* s_w, R* total)
+{
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = threadIdx.x / kWave;
+  const R s = wave_inclusive_scan(v);
+  if (lane == kWave - 1) s_w[wave] = s;
+  __syncthreads();
+  R off = R(0), tot = R(0);
+#pragma unroll
+  for (int w = 0; w < kBlock / kWave; ++w) {
+    const R ws = s_w[w];
+    if (w < wave) off += ws;
+    tot += ws;
+  }
+  __syncthreads();
+  *total = tot;
+  return s + off;
+}
+
+#endif  // __HIPCC__
+}  // namespace eea

@@ -1,0 +1,733 @@
+// C ABI (include/ergodic_amd.h) of the MI355X ergodic receding-horizon engine: argument
+// checking, device-memory ownership and kernel dispatch.  All arithmetic of the hot path
+// runs in the HIP kernels (control_kernel.hip, phik_kernel.hip, collision_kernel.hip); the
+// host code here only prepares their inputs the way the reference's host code does
+// (steps_ truncation, grid coordinates by accumulation, covariance inverse).
+#include "../../include/ergodic_amd.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.hpp"
+
+namespace
+{
+thread_local std::string g_err;
+
+eea_status fail(eea_status st, const std::string& msg)
+{
+  g_err = msg;
+  return st;
+}
+
+#define EEA_HIP(expr)                                                                         \
+  do {                                                                                        \
+    const hipError_t err__ = (expr);                                                          \
+    if (err__ != hipSuccess) {                                                                \
+      return fail(EEA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(err__));         \
+    }                                                                                         \
+  } while (0)
+
+// grid.hpp:61-64 of the reference (x86-64 cast semantics do not matter here: non-negative)
+unsigned axis_length(double lower, double upper, double resolution)
+{
+  return static_cast<unsigned>(std::round((upper - lower) / resolution));
+}
+
+struct DevBuf
+{
+  void* p = nullptr;
+  size_t cap = 0;
+  hipError_t reserve(size_t bytes)
+  {
+    if (bytes <= cap) return hipSuccess;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    const hipError_t e = hipMalloc(&p, bytes);
+    if (e == hipSuccess) cap = bytes;
+    return e;
+  }
+  void release()
+  {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+// host mailbox of the single-agent path, device-visible (zero-copy over PCIe)
+struct Mailbox
+{
+  double pose[3];  // viewed as R[3]
+  double u0[3];    // viewed as R[3]
+  int status;
+  int pad;
+};
+}  // namespace
+
+struct eea_engine
+{
+  eea_config cfg;
+  int T = 0, K = 0, K2 = 0;
+  bool f32 = false;
+  size_t rs = 8;  // sizeof(real)
+  int chunk = 128;
+
+  // Basis state (basis_.lx_, ly_ start at 0: ergodic_control.hpp:208)
+  double lx = 0.0, ly = 0.0, map_x = 0.0, map_y = 0.0;
+  bool have_phik = false;
+  std::vector<double> mu, sigma;  // target Gaussians, map frame
+  bool have_gauss = false;
+
+  DevBuf d_phik, d_lamdak;
+  // phi grid of the last rebuild
+  unsigned nx = 0, ny = 0;
+  DevBuf d_phi, d_xs, d_ys, d_cx, d_cy, d_work, d_gauss, d_sum;
+
+  // single-agent path
+  hipStream_t stream1 = nullptr;
+  Mailbox* h_mail = nullptr;
+  void* d_mail = nullptr;
+  DevBuf d_ut1, d_traj1, d_mem1;
+  void* h_stage = nullptr;  // pinned staging for mem_cols / ut transfers
+  size_t h_stage_cap = 0;
+  double last_pose[3] = { 0, 0, 0 };
+};
+
+namespace
+{
+template <typename R>
+void to_real(const double* in, R* out, size_t n)
+{
+  for (size_t i = 0; i < n; ++i) out[i] = static_cast<R>(in[i]);
+}
+
+eea_status use_device(const eea_engine* e)
+{
+  EEA_HIP(hipSetDevice(e->cfg.device));
+  return EEA_OK;
+}
+
+eea_status stage_reserve(eea_engine* e, size_t bytes)
+{
+  if (bytes <= e->h_stage_cap) return EEA_OK;
+  if (e->h_stage) (void)hipHostFree(e->h_stage);
+  e->h_stage = nullptr;
+  e->h_stage_cap = 0;
+  EEA_HIP(hipHostMalloc(&e->h_stage, bytes, hipHostMallocDefault));
+  e->h_stage_cap = bytes;
+  return EEA_OK;
+}
+
+template <typename R>
+eea_status upload_lamdak(eea_engine* e)
+{
+  // basis.cpp:69-75: lamdak = 1 / (1 + sqrt(k1^2 + k2^2))^1.5, col = k2*K + k1
+  std::vector<R> lam(e->K2);
+  for (int k2 = 0; k2 < e->K; ++k2) {
+    for (int k1 = 0; k1 < e->K; ++k1) {
+      const double ss = static_cast<double>(k1 * k1 + k2 * k2);
+      lam[k2 * e->K + k1] = static_cast<R>(1.0 / std::pow(1.0 + std::sqrt(ss), 1.5));
+    }
+  }
+  EEA_HIP(e->d_lamdak.reserve(sizeof(R) * e->K2));
+  EEA_HIP(e->d_phik.reserve(sizeof(R) * e->K2));
+  EEA_HIP(hipMemcpy(e->d_lamdak.p, lam.data(), sizeof(R) * e->K2, hipMemcpyHostToDevice));
+  EEA_HIP(hipMemset(e->d_phik.p, 0, sizeof(R) * e->K2));
+  return EEA_OK;
+}
+
+// coordinates of configTarget's grid: repeated += resolution (ergodic_control.hpp:387-408)
+template <typename R>
+std::vector<R> axis_coords(unsigned n, double resolution)
+{
+  std::vector<R> v(n);
+  double x = 0.0;
+  for (unsigned i = 0; i < n; ++i) {
+    v[i] = static_cast<R>(x);
+    x += resolution;
+  }
+  return v;
+}
+
+template <typename R>
+eea_status upload_axes_and_tables(eea_engine* e, unsigned nx, unsigned ny, hipStream_t s)
+{
+  const std::vector<R> xs = axis_coords<R>(nx, e->cfg.resolution);
+  const std::vector<R> ys = axis_coords<R>(ny, e->cfg.resolution);
+  EEA_HIP(e->d_xs.reserve(sizeof(R) * nx));
+  EEA_HIP(e->d_ys.reserve(sizeof(R) * ny));
+  EEA_HIP(e->d_cx.reserve(sizeof(R) * nx * e->K));
+  EEA_HIP(e->d_cy.reserve(sizeof(R) * ny * e->K));
+  EEA_HIP(e->d_work.reserve(sizeof(R) * eea::spatial_work_elems(nx, ny, e->K)));
+  EEA_HIP(hipMemcpyAsync(e->d_xs.p, xs.data(), sizeof(R) * nx, hipMemcpyHostToDevice, s));
+  EEA_HIP(hipMemcpyAsync(e->d_ys.p, ys.data(), sizeof(R) * ny, hipMemcpyHostToDevice, s));
+  // the copies read pageable host vectors that die with this scope
+  EEA_HIP(hipStreamSynchronize(s));
+  const R pi_lx = static_cast<R>(eea::kPi / e->lx), pi_ly = static_cast<R>(eea::kPi / e->ly);
+  EEA_HIP(eea::launch_cos_tables<R>(static_cast<const R*>(e->d_xs.p), nx, e->K, pi_lx,
+                                    static_cast<R*>(e->d_cx.p), s));
+  EEA_HIP(eea::launch_cos_tables_t<R>(static_cast<const R*>(e->d_ys.p), ny, e->K, pi_ly,
+                                      static_cast<R*>(e->d_cy.p), s));
+  return EEA_OK;
+}
+
+// Target::fill + Basis::spatialCoeff on the device
+template <typename R>
+eea_status rebuild_phik(eea_engine* e, hipStream_t s)
+{
+  // Add 1 to include the boundary (ergodic_control.hpp:383-385)
+  const unsigned nx = axis_length(0.0, e->lx, e->cfg.resolution) + 1;
+  const unsigned ny = axis_length(0.0, e->ly, e->cfg.resolution) + 1;
+  const size_t P = static_cast<size_t>(nx) * ny;
+  if (P == 0 || P > (static_cast<size_t>(1) << 31)) {
+    return fail(EEA_ERR_UNSUPPORTED, "target grid size out of range");
+  }
+  e->nx = nx;
+  e->ny = ny;
+  eea_status st = upload_axes_and_tables<R>(e, nx, ny, s);
+  if (st != EEA_OK) return st;
+
+  // Gaussian parameters as the reference prepares them: mean translated into the Fourier
+  // frame (target.hpp:99), cov_inv = inv(diagmat(sigma^2)) (target.hpp:69; 2x2 inverse)
+  const int ng = static_cast<int>(e->mu.size() / 2);
+  std::vector<R> g(static_cast<size_t>(4) * (ng ? ng : 1));
+  for (int i = 0; i < ng; ++i) {
+    const double a = e->sigma[2 * i] * e->sigma[2 * i], d = e->sigma[2 * i + 1] * e->sigma[2 * i + 1];
+    const double det = a * d - 0.0 * 0.0;
+    g[4 * i + 0] = static_cast<R>(e->mu[2 * i] - e->map_x);
+    g[4 * i + 1] = static_cast<R>(e->mu[2 * i + 1] - e->map_y);
+    g[4 * i + 2] = static_cast<R>(d / det);
+    g[4 * i + 3] = static_cast<R>(a / det);
+  }
+  const int fill_blocks = static_cast<int>((P + eea::kBlock - 1) / eea::kBlock);
+  EEA_HIP(e->d_gauss.reserve(sizeof(R) * g.size()));
+  EEA_HIP(e->d_phi.reserve(sizeof(R) * P));
+  EEA_HIP(e->d_sum.reserve(sizeof(R) * (static_cast<size_t>(fill_blocks) + 1)));
+  EEA_HIP(hipMemcpyAsync(e->d_gauss.p, g.data(), sizeof(R) * g.size(), hipMemcpyHostToDevice, s));
+  EEA_HIP(hipStreamSynchronize(s));
+
+  R* const d_partials = static_cast<R*>(e->d_sum.p) + 1;
+  int n_partials = 0;
+  EEA_HIP(eea::launch_target_fill<R>(static_cast<const R*>(e->d_xs.p), static_cast<const R*>(e->d_ys.p),
+                                     nx, ny, static_cast<const R*>(e->d_gauss.p), ng,
+                                     static_cast<R*>(e->d_phi.p), d_partials, &n_partials, s));
+  EEA_HIP(eea::launch_reduce_sum<R>(d_partials, n_partials, static_cast<R*>(e->d_sum.p), s));
+  EEA_HIP(eea::launch_scale_by_inv<R>(static_cast<R*>(e->d_phi.p), P, static_cast<const R*>(e->d_sum.p), s));
+  EEA_HIP(eea::launch_spatial_coeff<R>(static_cast<const R*>(e->d_phi.p), nx, ny, e->K,
+                                       static_cast<const R*>(e->d_cx.p), static_cast<const R*>(e->d_cy.p),
+                                       static_cast<R*>(e->d_work.p), static_cast<R*>(e->d_phik.p), s));
+  EEA_HIP(hipStreamSynchronize(s));
+  e->have_phik = true;
+  return EEA_OK;
+}
+
+template <typename R>
+eea_status set_target_grid_impl(eea_engine* e, unsigned nx, unsigned ny, const void* phi_vals,
+                                int on_device, hipStream_t s)
+{
+  const size_t P = static_cast<size_t>(nx) * ny;
+  e->nx = nx;
+  e->ny = ny;
+  eea_status st = upload_axes_and_tables<R>(e, nx, ny, s);
+  if (st != EEA_OK) return st;
+  const R* d_phi = static_cast<const R*>(phi_vals);
+  if (!on_device) {
+    EEA_HIP(e->d_phi.reserve(sizeof(R) * P));
+    EEA_HIP(hipMemcpyAsync(e->d_phi.p, phi_vals, sizeof(R) * P, hipMemcpyHostToDevice, s));
+    EEA_HIP(hipStreamSynchronize(s));
+    d_phi = static_cast<const R*>(e->d_phi.p);
+  }
+  EEA_HIP(eea::launch_spatial_coeff<R>(d_phi, nx, ny, e->K, static_cast<const R*>(e->d_cx.p),
+                                       static_cast<const R*>(e->d_cy.p), static_cast<R*>(e->d_work.p),
+                                       static_cast<R*>(e->d_phik.p), s));
+  EEA_HIP(hipStreamSynchronize(s));
+  e->have_phik = true;
+  return EEA_OK;
+}
+
+template <typename R>
+void fill_params(const eea_engine* e, eea::ControlParams<R>& p)
+{
+  std::memset(&p, 0, sizeof(p));
+  p.T = e->T;
+  p.K = e->K;
+  p.chunk = e->chunk;
+  p.dt = static_cast<R>(e->cfg.dt);
+  p.lx = static_cast<R>(e->lx);
+  p.ly = static_cast<R>(e->ly);
+  p.map_x = static_cast<R>(e->map_x);
+  p.map_y = static_cast<R>(e->map_y);
+  p.expl_weight = static_cast<R>(e->cfg.expl_weight);
+  p.pi_lx = static_cast<R>(eea::kPi / e->lx);
+  p.pi_ly = static_cast<R>(eea::kPi / e->ly);
+  for (int i = 0; i < 9; ++i) p.Rinv[i] = static_cast<R>(e->cfg.Rinv[i]);
+  for (int i = 0; i < 3; ++i) {
+    p.umin[i] = static_cast<R>(e->cfg.umin[i]);
+    p.umax[i] = static_cast<R>(e->cfg.umax[i]);
+  }
+  p.phik = static_cast<const R*>(e->d_phik.p);
+  p.lamdak = static_cast<const R*>(e->d_lamdak.p);
+}
+
+template <typename R>
+eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io, bool rollout_only,
+                              hipStream_t s)
+{
+  eea::ControlParams<R> p;
+  fill_params<R>(e, p);
+  p.pose = static_cast<const R*>(io->d_pose);
+  p.ut = static_cast<R*>(io->d_ut);
+  p.mem_cols = static_cast<const R*>(io->d_mem_cols);
+  p.n_mem = io->d_n_mem;
+  p.mem_stride = io->d_mem_cols ? io->mem_stride : 0u;
+  p.u0 = static_cast<R*>(io->d_u0);
+  p.traj = static_cast<R*>(io->d_traj);
+  p.ck = static_cast<R*>(io->d_ck);
+  p.edx = static_cast<R*>(io->d_edx);
+  p.bdx = static_cast<R*>(io->d_bdx);
+  p.rhot = static_cast<R*>(io->d_rhot);
+  p.status = io->d_status;
+  const int n_mem_max = rollout_only ? 0 : static_cast<int>(p.mem_stride);
+  const size_t lds = eea::control_lds_bytes<R>(p.T, p.K, n_mem_max, p.chunk);
+  if (lds > 160 * 1024) {
+    return fail(EEA_ERR_UNSUPPORTED, "horizon/memory/basis too large for one workgroup's 160 KiB LDS");
+  }
+  EEA_HIP(eea::launch_control<R>(p, B, e->cfg.model, n_mem_max, rollout_only, s));
+  return EEA_OK;
+}
+
+eea_status check_engine(const eea_engine* e)
+{
+  if (e == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null engine");
+  return EEA_OK;
+}
+}  // namespace
+
+extern "C" {
+
+const char* eea_last_error(void) { return g_err.c_str(); }
+unsigned eea_abi_version(void) { return EEA_ABI_VERSION; }
+
+eea_status eea_create(const eea_config* cfg, eea_engine** out)
+{
+  if (cfg == nullptr || out == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (cfg->model != EEA_MODEL_OMNI && cfg->model != EEA_MODEL_SIMPLE_CART) {
+    return fail(EEA_ERR_INVALID_ARGUMENT,
+                "model must be Omni or SimpleCart (Cart/Mecanum cannot run under ErgodicControl)");
+  }
+  if (cfg->precision != EEA_PREC_F64 && cfg->precision != EEA_PREC_F32) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "unknown precision");
+  }
+  // steps_ = static_cast<unsigned>(std::abs(horizon / dt))  (ergodic_control.hpp:199)
+  const double ratio = std::abs(cfg->horizon / cfg->dt);
+  if (!(ratio < 1.0e6)) return fail(EEA_ERR_INVALID_ARGUMENT, "horizon / dt out of range");
+  const unsigned steps = static_cast<unsigned>(ratio);
+  if (steps == 1) {
+    return fail(EEA_ERR_INVALID_ARGUMENT,
+                "Need at least two steps in forward simulation. Increase the horizon or decrease "
+                "the time step.");
+  }
+  if (steps == 0) return fail(EEA_ERR_INVALID_ARGUMENT, "horizon shorter than one time step");
+  if (cfg->num_basis == 0 || cfg->num_basis > static_cast<unsigned>(eea::kMaxBasis)) {
+    return fail(EEA_ERR_UNSUPPORTED, "num_basis must be in [1, 32]");
+  }
+  int ndev = 0;
+  EEA_HIP(hipGetDeviceCount(&ndev));
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(EEA_ERR_HIP, "no such HIP device");
+  EEA_HIP(hipSetDevice(cfg->device));
+
+  eea_engine* e = new eea_engine();
+  e->cfg = *cfg;
+  e->T = static_cast<int>(steps);
+  e->K = static_cast<int>(cfg->num_basis);
+  e->K2 = e->K * e->K;
+  e->f32 = cfg->precision == EEA_PREC_F32;
+  e->rs = e->f32 ? 4 : 8;
+  if (const char* c = std::getenv("EEA_CHUNK")) {
+    const int v = std::atoi(c);
+    if (v >= 64 && v <= 1024 && (v % 64) == 0) e->chunk = v;
+  }
+  eea_status st = e->f32 ? upload_lamdak<float>(e) : upload_lamdak<double>(e);
+  if (st != EEA_OK) {
+    eea_destroy(e);
+    return st;
+  }
+  hipError_t err = hipStreamCreateWithFlags(&e->stream1, hipStreamNonBlocking);
+  if (err == hipSuccess) {
+    err = hipHostMalloc(reinterpret_cast<void**>(&e->h_mail), sizeof(Mailbox), hipHostMallocMapped);
+  }
+  if (err == hipSuccess) {
+    std::memset(e->h_mail, 0, sizeof(Mailbox));
+    err = hipHostGetDevicePointer(&e->d_mail, e->h_mail, 0);
+  }
+  if (err == hipSuccess) err = e->d_ut1.reserve(e->rs * 3 * e->T);
+  if (err == hipSuccess) err = hipMemset(e->d_ut1.p, 0, e->rs * 3 * e->T);  // ut_ starts at zero (:201)
+  if (err == hipSuccess) err = e->d_traj1.reserve(e->rs * 3 * e->T);
+  if (err != hipSuccess) {
+    const std::string msg = std::string("engine allocation: ") + hipGetErrorString(err);
+    eea_destroy(e);
+    return fail(EEA_ERR_HIP, msg);
+  }
+  *out = e;
+  return EEA_OK;
+}
+
+void eea_destroy(eea_engine* e)
+{
+  if (e == nullptr) return;
+  (void)hipSetDevice(e->cfg.device);
+  if (e->stream1) {
+    (void)hipStreamSynchronize(e->stream1);
+    (void)hipStreamDestroy(e->stream1);
+  }
+  DevBuf* bufs[] = { &e->d_phik, &e->d_lamdak, &e->d_phi, &e->d_xs, &e->d_ys, &e->d_cx, &e->d_cy,
+                     &e->d_work, &e->d_gauss, &e->d_sum, &e->d_ut1, &e->d_traj1, &e->d_mem1 };
+  for (DevBuf* b : bufs) b->release();
+  if (e->h_mail) (void)hipHostFree(e->h_mail);
+  if (e->h_stage) (void)hipHostFree(e->h_stage);
+  delete e;
+}
+
+unsigned eea_steps(const eea_engine* e) { return e ? static_cast<unsigned>(e->T) : 0u; }
+unsigned eea_num_modes(const eea_engine* e) { return e ? static_cast<unsigned>(e->K2) : 0u; }
+size_t eea_real_size(const eea_engine* e) { return e ? e->rs : 0; }
+double eea_time_step(const eea_engine* e) { return e ? e->cfg.dt : 0.0; }
+
+eea_status eea_set_target_gaussians(eea_engine* e, unsigned n, const double* mu, const double* sigma)
+{
+  if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (n > 0 && (mu == nullptr || sigma == nullptr)) return fail(EEA_ERR_INVALID_ARGUMENT, "null target");
+  e->mu.assign(mu, mu + 2 * static_cast<size_t>(n));
+  e->sigma.assign(sigma, sigma + 2 * static_cast<size_t>(n));
+  e->have_gauss = true;
+  return EEA_OK;
+}
+
+eea_status eea_set_target_grid(eea_engine* e, unsigned nx, unsigned ny, const void* phi_vals,
+                               int on_device, double lx, double ly, void* stream)
+{
+  if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (phi_vals == nullptr || nx == 0 || ny == 0 || !(lx > 0.0) || !(ly > 0.0)) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "bad target grid");
+  }
+  eea_status st = use_device(e);
+  if (st != EEA_OK) return st;
+  e->lx = lx;
+  e->ly = ly;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return e->f32 ? set_target_grid_impl<float>(e, nx, ny, phi_vals, on_device, s)
+                : set_target_grid_impl<double>(e, nx, ny, phi_vals, on_device, s);
+}
+
+eea_status eea_config_domain(eea_engine* e, double xmin, double xmax, double ymin, double ymax,
+                             int* rebuilt, void* stream)
+{
+  if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (rebuilt) *rebuilt = 0;
+  // translation from map to fourier domain is refreshed on every call (:366-367)
+  e->map_x = xmin;
+  e->map_y = ymin;
+  const double mx = xmax - xmin, my = ymax - ymin;
+  // almost_equal, numerics.hpp:68-71
+  if (std::fabs(mx - e->lx) < 1.0e-12 && std::fabs(my - e->ly) < 1.0e-12) return EEA_OK;
+  if (!e->have_gauss) return fail(EEA_ERR_NO_TARGET, "configTarget before setTarget");
+  eea_status st = use_device(e);
+  if (st != EEA_OK) return st;
+  e->lx = mx;
+  e->ly = my;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  st = e->f32 ? rebuild_phik<float>(e, s) : rebuild_phik<double>(e, s);
+  if (st == EEA_OK && rebuilt) *rebuilt = 1;
+  return st;
+}
+
+static eea_status download_reals(eea_engine* e, const void* d, size_t n, double* out)
+{
+  eea_status st = use_device(e);
+  if (st != EEA_OK) return st;
+  if (e->f32) {
+    std::vector<float> tmp(n);
+    EEA_HIP(hipMemcpy(tmp.data(), d, sizeof(float) * n, hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; ++i) out[i] = tmp[i];
+  } else {
+    EEA_HIP(hipMemcpy(out, d, sizeof(double) * n, hipMemcpyDeviceToHost));
+  }
+  return EEA_OK;
+}
+
+eea_status eea_get_phik(eea_engine* e, double* h_phik)
+{
+  if (check_engine(e) != EEA_OK || h_phik == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  return download_reals(e, e->d_phik.p, e->K2, h_phik);
+}
+
+eea_status eea_get_lamdak(eea_engine* e, double* h_lamdak)
+{
+  if (check_engine(e) != EEA_OK || h_lamdak == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  return download_reals(e, e->d_lamdak.p, e->K2, h_lamdak);
+}
+
+eea_status eea_target_grid_size(const eea_engine* e, unsigned* nx, unsigned* ny)
+{
+  if (e == nullptr || nx == nullptr || ny == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  *nx = e->nx;
+  *ny = e->ny;
+  return EEA_OK;
+}
+
+eea_status eea_get_target_grid(eea_engine* e, double* h_phi_vals)
+{
+  if (check_engine(e) != EEA_OK || h_phi_vals == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  if (e->d_phi.p == nullptr || e->nx == 0) return fail(EEA_ERR_NO_TARGET, "no target grid on the device");
+  return download_reals(e, e->d_phi.p, static_cast<size_t>(e->nx) * e->ny, h_phi_vals);
+}
+
+eea_status eea_control_batch(eea_engine* e, unsigned B, const eea_batch_io* io, void* stream)
+{
+  if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (io == nullptr || io->d_pose == nullptr || io->d_ut == nullptr || io->d_u0 == nullptr) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "d_pose, d_ut and d_u0 are required");
+  }
+  if (!e->have_phik) return fail(EEA_ERR_NO_TARGET, "no phi_k: call eea_config_domain or eea_set_target_grid first");
+  eea_status st = use_device(e);
+  if (st != EEA_OK) return st;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return e->f32 ? control_batch_impl<float>(e, B, io, false, s)
+                : control_batch_impl<double>(e, B, io, false, s);
+}
+
+eea_status eea_rollout_batch(eea_engine* e, unsigned B, const void* d_pose, const void* d_ut,
+                             void* d_traj, int* d_status, void* stream)
+{
+  if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (d_pose == nullptr || d_ut == nullptr || d_traj == nullptr) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "d_pose, d_ut and d_traj are required");
+  }
+  eea_status st = use_device(e);
+  if (st != EEA_OK) return st;
+  eea_batch_io io;
+  std::memset(&io, 0, sizeof(io));
+  io.d_pose = d_pose;
+  io.d_ut = const_cast<void*>(d_ut);  // rollout_only never writes ut
+  io.d_traj = d_traj;
+  io.d_status = d_status;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return e->f32 ? control_batch_impl<float>(e, B, &io, true, s)
+                : control_batch_impl<double>(e, B, &io, true, s);
+}
+
+eea_status eea_control(eea_engine* e, double xmin, double xmax, double ymin, double ymax,
+                       const double x[3], const double* h_mem_cols, unsigned n_mem, double u_out[3])
+{
+  if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (x == nullptr || u_out == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  if (n_mem > 0 && h_mem_cols == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null mem_cols");
+  eea_status st = use_device(e);
+  if (st != EEA_OK) return st;
+  // pose_ = x; configTarget(grid)  (:227-230)
+  st = eea_config_domain(e, xmin, xmax, ymin, ymax, nullptr, e->stream1);
+  if (st != EEA_OK) return st;
+  if (!e->have_phik) return fail(EEA_ERR_NO_TARGET, "no target set");
+  for (int i = 0; i < 3; ++i) e->last_pose[i] = x[i];
+
+  eea_batch_io io;
+  std::memset(&io, 0, sizeof(io));
+  if (n_mem > 0) {
+    const size_t bytes = e->rs * 3 * n_mem;
+    st = stage_reserve(e, bytes);
+    if (st != EEA_OK) return st;
+    EEA_HIP(e->d_mem1.reserve(bytes));
+    if (e->f32) to_real<float>(h_mem_cols, static_cast<float*>(e->h_stage), 3 * static_cast<size_t>(n_mem));
+    else std::memcpy(e->h_stage, h_mem_cols, bytes);
+    EEA_HIP(hipMemcpyAsync(e->d_mem1.p, e->h_stage, bytes, hipMemcpyHostToDevice, e->stream1));
+    io.d_mem_cols = e->d_mem1.p;
+    io.mem_stride = n_mem;  // d_n_mem == NULL: every reserved column is valid
+  }
+  if (e->f32) to_real<float>(x, reinterpret_cast<float*>(e->h_mail->pose), 3);
+  else std::memcpy(e->h_mail->pose, x, sizeof(double) * 3);
+  e->h_mail->status = 0;
+  Mailbox* const dm = static_cast<Mailbox*>(e->d_mail);
+  io.d_pose = dm->pose;
+  io.d_u0 = dm->u0;
+  io.d_status = &dm->status;
+  io.d_ut = e->d_ut1.p;
+  st = e->f32 ? control_batch_impl<float>(e, 1, &io, false, e->stream1)
+              : control_batch_impl<double>(e, 1, &io, false, e->stream1);
+  if (st != EEA_OK) return st;
+  EEA_HIP(hipStreamSynchronize(e->stream1));
+  if (e->h_mail->status == EEA_ERR_INVALID_TWIST) {
+    return fail(EEA_ERR_INVALID_TWIST, "Invalid twist y-velocity must be 0.");
+  }
+  if (e->f32) {
+    const float* u = reinterpret_cast<const float*>(e->h_mail->u0);
+    for (int i = 0; i < 3; ++i) u_out[i] = u[i];
+  } else {
+    std::memcpy(u_out, e->h_mail->u0, sizeof(double) * 3);
+  }
+  return EEA_OK;
+}
+
+eea_status eea_opt_traj(eea_engine* e, double* h_traj)
+{
+  if (check_engine(e) != EEA_OK || h_traj == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  eea_status st = use_device(e);
+  if (st != EEA_OK) return st;
+  if (e->f32) to_real<float>(e->last_pose, reinterpret_cast<float*>(e->h_mail->pose), 3);
+  else std::memcpy(e->h_mail->pose, e->last_pose, sizeof(double) * 3);
+  e->h_mail->status = 0;
+  Mailbox* const dm = static_cast<Mailbox*>(e->d_mail);
+  st = eea_rollout_batch(e, 1, dm->pose, e->d_ut1.p, e->d_traj1.p, &dm->status, e->stream1);
+  if (st != EEA_OK) return st;
+  EEA_HIP(hipStreamSynchronize(e->stream1));
+  if (e->h_mail->status == EEA_ERR_INVALID_TWIST) {
+    return fail(EEA_ERR_INVALID_TWIST, "Invalid twist y-velocity must be 0.");
+  }
+  return download_reals(e, e->d_traj1.p, 3 * static_cast<size_t>(e->T), h_traj);
+}
+
+eea_status eea_get_ut(eea_engine* e, double* h_ut)
+{
+  if (check_engine(e) != EEA_OK || h_ut == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  EEA_HIP(hipStreamSynchronize(e->stream1));
+  return download_reals(e, e->d_ut1.p, 3 * static_cast<size_t>(e->T), h_ut);
+}
+
+eea_status eea_set_ut(eea_engine* e, const double* h_ut)
+{
+  if (check_engine(e) != EEA_OK || h_ut == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  eea_status st = use_device(e);
+  if (st != EEA_OK) return st;
+  const size_t n = 3 * static_cast<size_t>(e->T);
+  EEA_HIP(hipStreamSynchronize(e->stream1));
+  if (e->f32) {
+    std::vector<float> tmp(n);
+    to_real<float>(h_ut, tmp.data(), n);
+    EEA_HIP(hipMemcpy(e->d_ut1.p, tmp.data(), sizeof(float) * n, hipMemcpyHostToDevice));
+  } else {
+    EEA_HIP(hipMemcpy(e->d_ut1.p, h_ut, sizeof(double) * n, hipMemcpyHostToDevice));
+  }
+  return EEA_OK;
+}
+
+// ---- Basis free functions ------------------------------------------------------------------
+static eea_status basis_points(int device, double lx, double ly, unsigned K, const double* xs,
+                               const double* ys, const double* ws, unsigned P, double scale,
+                               double* out)
+{
+  if (K == 0 || K > static_cast<unsigned>(eea::kMaxBasis)) return fail(EEA_ERR_UNSUPPORTED, "num_basis must be in [1, 32]");
+  EEA_HIP(hipSetDevice(device));
+  const size_t K2 = static_cast<size_t>(K) * K;
+  DevBuf dx, dy, dw, dwork, dout;
+  auto cleanup = [&]() {
+    dx.release();
+    dy.release();
+    dw.release();
+    dwork.release();
+    dout.release();
+  };
+  hipError_t err = dx.reserve(sizeof(double) * (P ? P : 1));
+  if (err == hipSuccess) err = dy.reserve(sizeof(double) * (P ? P : 1));
+  if (err == hipSuccess && ws) err = dw.reserve(sizeof(double) * (P ? P : 1));
+  if (err == hipSuccess) err = dwork.reserve(sizeof(double) * eea::point_work_elems(P, K));
+  if (err == hipSuccess) err = dout.reserve(sizeof(double) * K2);
+  if (err == hipSuccess && P) err = hipMemcpy(dx.p, xs, sizeof(double) * P, hipMemcpyHostToDevice);
+  if (err == hipSuccess && P) err = hipMemcpy(dy.p, ys, sizeof(double) * P, hipMemcpyHostToDevice);
+  if (err == hipSuccess && P && ws) err = hipMemcpy(dw.p, ws, sizeof(double) * P, hipMemcpyHostToDevice);
+  if (err == hipSuccess) {
+    err = eea::launch_point_coeff<double>(static_cast<const double*>(dx.p), static_cast<const double*>(dy.p),
+                                          ws ? static_cast<const double*>(dw.p) : nullptr, P, K,
+                                          eea::kPi / lx, eea::kPi / ly, scale,
+                                          static_cast<double*>(dwork.p), static_cast<double*>(dout.p), nullptr);
+  }
+  if (err == hipSuccess) err = hipMemcpy(out, dout.p, sizeof(double) * K2, hipMemcpyDeviceToHost);
+  cleanup();
+  if (err != hipSuccess) return fail(EEA_ERR_HIP, std::string("basis op: ") + hipGetErrorString(err));
+  return EEA_OK;
+}
+
+eea_status eea_basis_traj_coeff(int device, double lx, double ly, unsigned num_basis,
+                                const double* h_xt, unsigned rows, unsigned n, double* h_ck)
+{
+  if (h_xt == nullptr || h_ck == nullptr || rows < 2 || n == 0) return fail(EEA_ERR_INVALID_ARGUMENT, "bad trajectory");
+  std::vector<double> xs(n), ys(n);
+  for (unsigned i = 0; i < n; ++i) {
+    xs[i] = h_xt[static_cast<size_t>(rows) * i];
+    ys[i] = h_xt[static_cast<size_t>(rows) * i + 1];
+  }
+  return basis_points(device, lx, ly, num_basis, xs.data(), ys.data(), nullptr, n, 1.0 / static_cast<double>(n), h_ck);
+}
+
+eea_status eea_basis_spatial_coeff(int device, double lx, double ly, unsigned num_basis,
+                                   const double* h_phi_vals, const double* h_phi_grid, unsigned P,
+                                   double* h_phik)
+{
+  if (h_phi_vals == nullptr || h_phi_grid == nullptr || h_phik == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  std::vector<double> xs(P), ys(P);
+  for (unsigned i = 0; i < P; ++i) {
+    xs[i] = h_phi_grid[2 * static_cast<size_t>(i)];
+    ys[i] = h_phi_grid[2 * static_cast<size_t>(i) + 1];
+  }
+  return basis_points(device, lx, ly, num_basis, xs.data(), ys.data(), h_phi_vals, P, 1.0, h_phik);
+}
+
+// ---- collision lookups ---------------------------------------------------------------------
+static eea_status make_collision_params(const eea_collision_cfg* cfg, eea::CollisionParams& c)
+{
+  if (cfg == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null collision config");
+  // Collision::Collision (collision.cpp:46-63)
+  if (cfg->search_radius < cfg->boundary_radius) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "Search radius must be at least the same size as the boundary radius");
+  }
+  if (cfg->occupied_threshold > 100.0 || cfg->occupied_threshold < 0.0) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "Occupied threshold must be between 0 and 100");
+  }
+  c.xmin = cfg->xmin;
+  c.ymin = cfg->ymin;
+  c.resolution = cfg->resolution;
+  c.xsize = cfg->xsize;
+  c.ysize = cfg->ysize;
+  // CollisionConfig radii in cells (collision.cpp:130-133)
+  c.r_bnd = static_cast<int>(std::floor(cfg->boundary_radius / cfg->resolution));
+  c.r_col = static_cast<int>(std::floor((cfg->boundary_radius + cfg->obstacle_threshold) / cfg->resolution));
+  c.r_max = static_cast<int>(std::floor(cfg->search_radius / cfg->resolution));
+  c.occupied_threshold = cfg->occupied_threshold;
+  return EEA_OK;
+}
+
+eea_status eea_collision_check_batch(int device, const eea_collision_cfg* cfg, const int8_t* d_grid,
+                                     const double* d_pose, unsigned P, int* d_hit, void* stream)
+{
+  eea::CollisionParams c;
+  eea_status st = make_collision_params(cfg, c);
+  if (st != EEA_OK) return st;
+  if (d_grid == nullptr || d_pose == nullptr || d_hit == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  EEA_HIP(hipSetDevice(device));
+  EEA_HIP(eea::launch_collision_check(c, d_grid, d_pose, P, d_hit, static_cast<hipStream_t>(stream)));
+  return EEA_OK;
+}
+
+eea_status eea_validate_control_batch(int device, const eea_collision_cfg* cfg, const int8_t* d_grid,
+                                      const double* d_x0, const double* d_u, double dt,
+                                      double horizon, unsigned P, int* d_valid, void* stream)
+{
+  eea::CollisionParams c;
+  eea_status st = make_collision_params(cfg, c);
+  if (st != EEA_OK) return st;
+  if (d_grid == nullptr || d_x0 == nullptr || d_u == nullptr || d_valid == nullptr) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  }
+  const unsigned steps = static_cast<unsigned>(std::abs(horizon / dt));  // numerics.hpp:317
+  EEA_HIP(hipSetDevice(device));
+  EEA_HIP(eea::launch_validate_control(c, d_grid, d_x0, d_u, dt, steps, P, d_valid,
+                                       static_cast<hipStream_t>(stream)));
+  return EEA_OK;
+}
+
+}  // extern "C"

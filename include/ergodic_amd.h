@@ -1,0 +1,185 @@
+/*
+ * ergodic_amd.h -- C ABI of the MI355X (gfx950) ergodic receding-horizon engine.
+ *
+ * This is the drop-in boundary for the hot path of bostoncleek/ergodic_exploration:
+ * one call of `ErgodicControl<ModelT>::control` (ergodic_control.hpp:224-311) plus the
+ * phi_k rebuild `configTarget` (ergodic_control.hpp:362-416), for ModelT in
+ * {models::Omni, models::SimpleCart}.  The reference has no FFI layer (its boundary is
+ * the C++ template class); each entry point below names the reference interface it
+ * replaces (file:line relative to the reference root).  INTEGRATION.md shows the binding a
+ * maintainer adds on the reference side.
+ *
+ * Conventions
+ *  - plain C types only; every function returns an eea_status (0 = ok); no exceptions
+ *    cross the ABI.  eea_last_error() gives the message of the last failure on the
+ *    calling thread.
+ *  - "real" = double (EEA_PREC_F64) or float (EEA_PREC_F32), fixed per engine.
+ *  - matrices use the reference's Armadillo layout: a "3 x T" matrix is T contiguous
+ *    [x, y, theta] (or [vx, vy, w]) triples (column-major).
+ *  - pointers named d_* are DEVICE pointers (HBM, caller-owned, same device as the
+ *    engine); pointers named h_* / plain arrays are host memory.
+ *  - `stream` is a hipStream_t passed as void* (NULL = the default stream); batch calls
+ *    are asynchronous on it.  One engine per host thread (reentrant across engines).
+ */
+#ifndef ERGODIC_AMD_H
+#define ERGODIC_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EEA_ABI_VERSION 1
+
+/* models usable with ErgodicControl (Cart/Mecanum cannot run under it) */
+enum { EEA_MODEL_OMNI = 0,        /* models::Omni        models/omni.hpp:164-215 */
+       EEA_MODEL_SIMPLE_CART = 1  /* models::SimpleCart  models/cart.hpp:152-206 */ };
+
+enum { EEA_PREC_F64 = 0, EEA_PREC_F32 = 1 };
+
+typedef enum {
+  EEA_OK = 0,
+  EEA_ERR_INVALID_ARGUMENT = 1, /* reference: std::invalid_argument from a constructor */
+  EEA_ERR_INVALID_TWIST = 2,    /* reference: SimpleCart::operator() throws, cart.hpp:167-170 */
+  EEA_ERR_UNSUPPORTED = 3,      /* size outside what the kernels are built for */
+  EEA_ERR_HIP = 4,              /* HIP runtime failure (no device, OOM, launch error) */
+  EEA_ERR_NO_TARGET = 5         /* control requested before any target was set */
+} eea_status;
+
+typedef struct eea_engine eea_engine;
+
+/* Constructor arguments of ErgodicControl (ergodic_control.hpp:90-94, 187-222).
+ * collision / buffer_size / batch_size are host-side concerns (the collision object is
+ * never read on this path; replay-memory sampling stays on the host, see mem_cols). */
+typedef struct {
+  int model;          /* EEA_MODEL_* */
+  int precision;      /* EEA_PREC_* */
+  int device;         /* HIP device ordinal */
+  double dt;          /* time step in integration */
+  double horizon;     /* control horizon; steps = (unsigned)|horizon/dt| (truncating) */
+  double resolution;  /* target grid resolution [m] */
+  double expl_weight; /* ergodic exploration weight */
+  unsigned num_basis; /* K: cosine basis functions per dimension (K^2 modes) */
+  double Rinv[9];     /* inverse control weights, column-major 3x3 */
+  double umin[3];     /* body twist lower limits */
+  double umax[3];     /* body twist upper limits */
+} eea_config;
+
+/* ---- life cycle -------------------------------------------------------------------- */
+/* ErgodicControl::ErgodicControl (ergodic_control.hpp:187-222).  EEA_ERR_INVALID_ARGUMENT
+ * if steps == 1 (the reference throws) or steps == 0 (the reference has UB). */
+eea_status eea_create(const eea_config* cfg, eea_engine** out);
+void eea_destroy(eea_engine* e);
+const char* eea_last_error(void);
+unsigned eea_abi_version(void);
+
+unsigned eea_steps(const eea_engine* e);      /* T = steps_ (ergodic_control.hpp:199) */
+unsigned eea_num_modes(const eea_engine* e);  /* K^2 */
+size_t eea_real_size(const eea_engine* e);    /* 8 or 4 */
+double eea_time_step(const eea_engine* e);    /* ErgodicControl::timeStep, :350-354 */
+
+/* ---- target distribution ----------------------------------------------------------- */
+/* ErgodicControl::setTarget with a Target built from Gaussians (ergodic_control.hpp:356-360,
+ * target.hpp:68-70): mu, sigma = 2 doubles per Gaussian, map frame.  As in the reference,
+ * phi_k is NOT recomputed until the map extent changes. */
+eea_status eea_set_target_gaussians(eea_engine* e, unsigned n, const double* mu, const double* sigma);
+
+/* Basis::spatialCoeff on an explicit target grid (basis.hpp:99, basis.cpp:122-133):
+ * phi_vals holds nx*ny reals, x fastest, on the grid configTarget builds for a domain
+ * lx x ly (coordinates j*resolution by accumulation).  Sets lx, ly and phi_k directly
+ * (no normalisation, as spatialCoeff).  phi_vals is a device pointer if on_device != 0. */
+eea_status eea_set_target_grid(eea_engine* e, unsigned nx, unsigned ny, const void* phi_vals,
+                               int on_device, double lx, double ly, void* stream);
+
+/* ErgodicControl::configTarget (ergodic_control.hpp:362-416): refreshes map_pos; rebuilds
+ * phi_k (Target::fill target.cpp:78-89 + Basis::spatialCoeff) only when the extent changed
+ * by >= 1e-12.  *rebuilt (optional) reports whether the rebuild ran. */
+eea_status eea_config_domain(eea_engine* e, double xmin, double xmax, double ymin, double ymax,
+                             int* rebuilt, void* stream);
+
+/* phi_k / lambda_k (basis.cpp:69-75) as doubles on the host, K^2 entries, col = k2*K + k1 */
+eea_status eea_get_phik(eea_engine* e, double* h_phik);
+eea_status eea_get_lamdak(eea_engine* e, double* h_lamdak);
+/* normalised target grid of the last rebuild (Target::fill output) : nx*ny doubles; sizes via
+ * eea_target_grid_size */
+eea_status eea_target_grid_size(const eea_engine* e, unsigned* nx, unsigned* ny);
+eea_status eea_get_target_grid(eea_engine* e, double* h_phi_vals);
+
+/* ---- the hot path: agent-batched ErgodicControl::control --------------------------- */
+/* Buffers of one batched call; B agents, each an independent reference ErgodicControl.
+ * All pointers are device pointers to `real`; optional ones may be NULL. */
+typedef struct {
+  const void* d_pose;     /* [B][3]     current state x (map frame)                     */
+  void* d_ut;             /* [B][T][3]  in: previous controls (warm start); out: updated
+                                        controls.  The shift-left-by-one of :233-234
+                                        happens inside the call                        */
+  const void* d_mem_cols; /* [B][mem_stride][3] optional: the columns
+                                        ReplayBuffer::sampleMemory would prepend
+                                        (buffer.cpp:64-111), map frame                 */
+  const int* d_n_mem;     /* [B] optional: valid columns per agent (<= mem_stride)     */
+  unsigned mem_stride;    /* columns reserved per agent in d_mem_cols                  */
+  void* d_u0;             /* [B][3]     out: ut.col(0) after the update (:310)         */
+  void* d_traj;           /* [B][T][3]  out, optional: rk4_.solve rollout (:237)       */
+  void* d_ck;             /* [B][K^2]   out, optional: trajectory coefficients (:267)  */
+  void* d_edx;            /* [B][T][3]  out, optional: gradErgodicMetric (:270)        */
+  void* d_bdx;            /* [B][T][3]  out, optional: gradBarrier (:273)              */
+  void* d_rhot;           /* [B][T][3]  out, optional: co-state (:277)                 */
+  int* d_status;          /* [B]        out, optional: per-agent eea_status            */
+} eea_batch_io;
+
+/* One receding-horizon optimisation per agent (ergodic_control.hpp:224-311, without the
+ * configTarget call: use eea_config_domain first).  Asynchronous on `stream`. */
+eea_status eea_control_batch(eea_engine* e, unsigned B, const eea_batch_io* io, void* stream);
+
+/* Forward rollout only: ErgodicControl::optTraj / path (ergodic_control.hpp:313-342),
+ * RungeKutta::solve (integrator.hpp:135-152).  d_ut is used as is (no shift). */
+eea_status eea_rollout_batch(eea_engine* e, unsigned B, const void* d_pose, const void* d_ut,
+                             void* d_traj, int* d_status, void* stream);
+
+/* ---- single agent, host pointers (what ErgodicControl<ModelT>::control binds to) ---- */
+/* vec control(const GridMap& grid, const vec& x) (ergodic_control.hpp:224-311) including
+ * configTarget(grid): grid bounds in, u = ut.col(0) out.  The warm-start controls live in
+ * the engine.  mem_cols: 3 x n_mem doubles (map frame) or NULL.  Synchronous. */
+eea_status eea_control(eea_engine* e, double xmin, double xmax, double ymin, double ymax,
+                       const double x[3], const double* h_mem_cols, unsigned n_mem,
+                       double u_out[3]);
+/* mat optTraj() const (ergodic_control.hpp:313-317): 3 x T doubles */
+eea_status eea_opt_traj(eea_engine* e, double* h_traj);
+/* read / overwrite the engine-held warm-start controls ut_ (3 x T doubles) */
+eea_status eea_get_ut(eea_engine* e, double* h_ut);
+eea_status eea_set_ut(eea_engine* e, const double* h_ut);
+
+/* ---- Basis hot loops as free functions (Basis::trajCoeff / spatialCoeff) ----------- */
+/* c_k = (1/n) sum_i f_k(xt_i)  (basis.cpp:109-120).  h_xt: rows x n column-major, rows >= 2 */
+eea_status eea_basis_traj_coeff(int device, double lx, double ly, unsigned num_basis,
+                                const double* h_xt, unsigned rows, unsigned n, double* h_ck);
+/* phi_k = sum_p f_k(grid_p) phi_vals_p  (basis.cpp:122-133) for an arbitrary point list.
+ * h_phi_grid: 2 x P column-major */
+eea_status eea_basis_spatial_coeff(int device, double lx, double ly, unsigned num_basis,
+                                   const double* h_phi_vals, const double* h_phi_grid, unsigned P,
+                                   double* h_phik);
+
+/* ---- next rows of the scope table: collision lookups ------------------------------- */
+/* Collision::collisionCheck (collision.cpp:126-141) for P poses on one occupancy grid
+ * (GridMap, grid.cpp:143-184).  d_grid: int8 row-major [ysize][xsize]; d_pose: [P][3]
+ * doubles; d_hit: [P] ints (1 = collision).  Bit-exact integer semantics incl. the
+ * world2Grid wrap of negative coordinates. */
+typedef struct {
+  double xmin, ymin, resolution;
+  unsigned xsize, ysize;
+  double boundary_radius, search_radius, obstacle_threshold, occupied_threshold;
+} eea_collision_cfg;
+eea_status eea_collision_check_batch(int device, const eea_collision_cfg* cfg, const int8_t* d_grid,
+                                     const double* d_pose, unsigned P, int* d_hit, void* stream);
+/* validate_control (numerics.hpp:312-330): integrate_twist rollout + collisionCheck per
+ * step; d_x0 [P][3], d_u [P][3] doubles; d_valid [P] ints (1 = collision free). */
+eea_status eea_validate_control_batch(int device, const eea_collision_cfg* cfg, const int8_t* d_grid,
+                                      const double* d_x0, const double* d_u, double dt,
+                                      double horizon, unsigned P, int* d_valid, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

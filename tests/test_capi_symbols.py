@@ -1,0 +1,50 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library builds for gfx950, loads without a
+GPU, exports every entry point include/ergodic_amd.h declares, and refuses to compute without a
+device (no CPU fallback)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from ergodic_exploration_amd import capi
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(capi.LIB_PATH), "run __graft_entry__.build() first"
+    L = C.CDLL(capi.LIB_PATH)
+    syms = capi.declared_symbols()
+    assert len(syms) >= 25
+    missing = [s for s in syms if not hasattr(L, s)]
+    assert missing == []
+    assert capi.lib().eea_abi_version() == 1
+
+
+def test_struct_layouts_match_header():
+    # sizes the C compiler gives the ABI structs (kept in sync with ergodic_amd.h by hand)
+    assert C.sizeof(capi.Config) == 3 * 4 + 4 + 4 * 8 + 8 + 15 * 8  # ints, pad, doubles, K+pad, arrays
+    assert C.sizeof(capi.BatchIO) == 12 * 8
+    assert C.sizeof(capi.CollisionCfg) == 3 * 8 + 2 * 4 + 4 * 8
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    cfg = capi.make_config(capi.MODEL_OMNI, 0.1, 2.0, 0.1, 1.0, 10, np.eye(3), [-1] * 3, [1] * 3)
+    with pytest.raises(capi.EngineError) as ei:
+        capi.Engine(cfg)
+    assert ei.value.status == capi.ERR_HIP
+
+
+def test_argument_errors_do_not_need_a_device():
+    L = capi.lib()
+    assert L.eea_create(None, None) == capi.ERR_INVALID_ARGUMENT
+    h = C.c_void_p()
+    bad = capi.make_config(capi.MODEL_OMNI, 0.1, 0.1, 0.1, 1.0, 10, np.eye(3), [-1] * 3, [1] * 3)
+    assert L.eea_create(C.byref(bad), C.byref(h)) == capi.ERR_INVALID_ARGUMENT  # steps == 1
+    assert b"two steps" in L.eea_last_error()
+    bad = capi.make_config(3, 0.1, 1.0, 0.1, 1.0, 10, np.eye(3), [-1] * 3, [1] * 3)
+    assert L.eea_create(C.byref(bad), C.byref(h)) == capi.ERR_INVALID_ARGUMENT  # Mecanum
+    bad = capi.make_config(capi.MODEL_OMNI, 0.1, 1.0, 0.1, 1.0, 64, np.eye(3), [-1] * 3, [1] * 3)
+    assert L.eea_create(C.byref(bad), C.byref(h)) == capi.ERR_UNSUPPORTED

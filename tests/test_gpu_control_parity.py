@@ -1,0 +1,242 @@
+"""GPU parity of the fused control kernel (through the C ABI) against the CPU oracle.
+
+Tolerances: c_k <= 1e-11 abs; trajectory, co-state, gradients and
+controls <= 1e-9 abs (the kernel re-associates the RK4 sums into scans and evaluates the
+separable basis by recurrence); headings compared modulo 2 pi.  fp32: <= 1e-4 on u.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import pyoracle as po
+from ergodic_exploration_amd import capi
+from tests.gpu_util import MAP_BOUNDS, MEANS, SIGMAS, angle_diff, make_pair, random_poses
+
+pytestmark = pytest.mark.gpu
+
+TOL_CK = 1e-11
+TOL = 1e-9
+
+
+def dev(a, dtype=torch.float64):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
+
+
+def run_batch_vs_oracle(model, K, horizon, dt, B, n_mem, calls, seed, precision=capi.PREC_F64,
+                        tol=TOL, tol_ck=TOL_CK, bounds=MAP_BOUNDS, means=MEANS, sigmas=SIGMAS):
+    rng = np.random.default_rng(seed)
+    eng, ors = make_pair(model, K, horizon, dt=dt, precision=precision, n_oracles=B, bounds=bounds,
+                         means=means, sigmas=sigmas)
+    T, K2 = eng.T, eng.K2
+    tdt = torch.float64 if precision == capi.PREC_F64 else torch.float32
+    poses = random_poses(rng, B, bounds)
+    # warm-start controls: random but inside the limits (SimpleCart: vy = 0)
+    ut0 = rng.uniform(-0.5, 0.5, (B, T, 3))
+    if model == "simple_cart":
+        ut0[:, :, 1] = 0.0
+    mem = None
+    if n_mem:
+        mem = random_poses(rng, B * n_mem, bounds).reshape(B, n_mem, 3)
+    d_pose, d_ut = dev(poses, tdt), dev(ut0, tdt)
+    d_u0 = torch.empty((B, 3), dtype=tdt, device="cuda")
+    outs = {k: torch.empty((B, T, 3), dtype=tdt, device="cuda") for k in ("traj", "edx", "bdx", "rhot")}
+    d_ck = torch.empty((B, K2), dtype=tdt, device="cuda")
+    d_status = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    d_mem = dev(mem, tdt) if n_mem else None
+    d_nmem = torch.full((B,), n_mem, dtype=torch.int32, device="cuda") if n_mem else None
+    for b in range(B):
+        ors[b].ut = ut0[b].T
+    worst = {}
+    for call in range(calls):
+        eng.control_batch(B, d_pose, d_ut, d_u0, mem_cols=d_mem, n_mem=d_nmem, mem_stride=n_mem,
+                          ck=d_ck, status=d_status, **outs)
+        torch.cuda.synchronize()
+        assert (d_status.cpu().numpy() == 0).all()
+        got = {k: v.cpu().numpy().astype(np.float64) for k, v in outs.items()}
+        got["ck"] = d_ck.cpu().numpy().astype(np.float64)
+        got["ut"] = d_ut.cpu().numpy().astype(np.float64)
+        got["u0"] = d_u0.cpu().numpy().astype(np.float64)
+        for b in range(B):
+            u, st = ors[b].control(bounds, poses[b], mem[b].T if n_mem else None, stages=True)
+            errs = {
+                "traj_xy": np.abs(got["traj"][b].T[:2] - st["traj"][:2]).max(),
+                "traj_th": np.abs(angle_diff(got["traj"][b].T[2], st["traj"][2])).max(),
+                "ck": np.abs(got["ck"][b] - st["ck"]).max(),
+                "edx": np.abs(got["edx"][b].T - st["edx"]).max(),
+                "bdx": np.abs(got["bdx"][b].T - st["bdx"]).max(),
+                "rhot": np.abs(got["rhot"][b].T - st["rhot"]).max(),
+                "ut": np.abs(got["ut"][b].T - st["ut"]).max(),
+                "u0": np.abs(got["u0"][b] - u).max(),
+            }
+            for k, v in errs.items():
+                worst[k] = max(worst.get(k, 0.0), float(v))
+            # feed the oracle's controls forward from the kernel's so both start each call
+            # from identical state (SURVEY.md section 7 "hard parts": never compare long closed loops)
+            ors[b].ut = got["ut"][b].T
+    eng.close()
+    assert worst["ck"] <= tol_ck, worst
+    for k in ("traj_xy", "traj_th", "edx", "bdx", "rhot", "ut", "u0"):
+        assert worst[k] <= tol, worst
+    return worst
+
+
+@pytest.mark.parametrize("model,K,horizon,dt,n_mem", [
+    ("omni", 5, 0.5, 0.1, 0),            # BASELINE config 1 (synthetic small)
+    ("simple_cart", 10, 2.0, 0.1, 0),    # BASELINE config 2
+    ("omni", 10, 5.0, 0.1, 7),           # yaml as shipped, memory <= batch
+    ("simple_cart", 10, 5.0, 0.1, 100),  # yaml as shipped, full memory batch
+    ("omni", 10, 20.0, 0.1, 0),          # metric point K=10 T=200
+    ("simple_cart", 10, 20.0, 0.1, 100), # metric point with memory
+])
+def test_stagewise_parity_f64(model, K, horizon, dt, n_mem):
+    run_batch_vs_oracle(model, K, horizon, dt, B=6, n_mem=n_mem, calls=3, seed=11)
+
+
+def test_generic_basis_count_and_long_horizon():
+    # K = 7 takes the runtime-K kernel; T = 300 > 256 exercises the chunked scans
+    run_batch_vs_oracle("omni", 7, 30.0, 0.1, B=3, n_mem=5, calls=2, seed=5)
+    run_batch_vs_oracle("simple_cart", 12, 3.0, 0.1, B=3, n_mem=0, calls=2, seed=6)
+
+
+def test_config3_shape_f64_and_f32():
+    # BASELINE config 3: Omni, K = 20, dt 0.02, horizon 5 (T = 250), 256 x 256 target grid
+    bounds = (0.0, 25.5, 0.0, 25.5)
+    means, sigmas = [[6.0, 6.0], [19.0, 12.0]], [[3.0, 3.0], [3.0, 3.0]]
+    run_batch_vs_oracle("omni", 20, 5.0, 0.02, B=2, n_mem=0, calls=2, seed=3, bounds=bounds,
+                        means=means, sigmas=sigmas)
+    # fp32 engine against the fp64 oracle: <= 1e-4 on controls, 5e-4 on the co-state
+    run_batch_vs_oracle("omni", 20, 5.0, 0.02, B=2, n_mem=0, calls=2, seed=3, bounds=bounds,
+                        means=means, sigmas=sigmas, precision=capi.PREC_F32, tol=5e-4, tol_ck=1e-5)
+
+
+def test_k30_t500_shape():
+    # BASELINE config 5 control shape (K = 30, T = 500) on the Gaussian target
+    run_batch_vs_oracle("omni", 30, 50.0, 0.1, B=1, n_mem=0, calls=1, seed=8)
+
+
+def test_survey_anchors_through_c_abi(anchors):
+    """End-to-end control() outputs of the reference's own sources through
+    the single-agent host entry point eea_control, closed loop."""
+    c = anchors["closed_loop_common"]
+    for key in ("omni_K10_T50", "simple_cart_K10_T20"):
+        a = anchors[key]
+        cm = {"omni": capi.MODEL_OMNI, "simple_cart": capi.MODEL_SIMPLE_CART}[a["model"]]
+        om = {"omni": po.MODEL_OMNI, "simple_cart": po.MODEL_SIMPLE_CART}[a["model"]]
+        lim = np.array(a["limits"])
+        eng = capi.Engine(capi.make_config(cm, c["dt"], a["horizon"], c["target_resolution"],
+                                           c["expl_weight"], a["num_basis"], np.diag(a["Rinv_diag"]),
+                                           -lim, lim))
+        eng.set_target_gaussians(c["means"], c["sigmas"])
+        x = np.array(c["x0"])
+        for i, exp in enumerate(a["u"]):
+            u = eng.control(c["map_bounds"], x)
+            assert np.abs(u - np.array(exp)).max() < 1e-9 * (10 ** i), (key, i, u, exp)
+            st, x = po.rk4_step_fwd(om, c["dt"], x, np.array(exp))  # drive with the reference's u
+            assert st == po.OK
+        eng.close()
+
+    a = anchors["memory_omni_K5"]
+    lim = np.array(a["limits"])
+    eng = capi.Engine(capi.make_config(capi.MODEL_OMNI, a["dt"], a["horizon"], a["target_resolution"],
+                                       1.0, a["num_basis"], np.diag(a["Rinv_diag"]), -lim, lim))
+    eng.set_target_gaussians(a["means"], a["sigmas"])
+    u = eng.control(a["map_bounds"], a["x"], np.array(a["memory"]).T)
+    assert np.abs(u - np.array(a["u"])).max() < 1e-9
+    eng.close()
+
+
+def test_single_agent_state_and_opt_traj():
+    """eea_control keeps ut_ in the engine (warm start), eea_opt_traj == optTraj()."""
+    eng, (orc,) = make_pair("omni", 10, 5.0)
+    x = np.array([1.0, 1.0, 0.3])
+    for _ in range(3):
+        u = eng.control(MAP_BOUNDS, x)
+        uo = orc.control(MAP_BOUNDS, x)
+        assert np.abs(u - uo).max() < 1e-8
+        assert np.abs(eng.get_ut() - orc.ut).max() < 1e-8
+        tr, tro = eng.opt_traj(), orc.opt_traj()
+        assert np.abs(tr[:2] - tro[:2]).max() < 1e-8
+        assert np.abs(angle_diff(tr[2], tro[2])).max() < 1e-8
+        orc.ut = eng.get_ut()
+        st, x = po.rk4_step_fwd(po.MODEL_OMNI, 0.1, x, u)
+    eng.close()
+
+
+def test_simple_cart_invalid_twist_status():
+    """SimpleCart::operator() throws on |u1| >= 1e-12 (cart.hpp:167-170): per-agent status,
+    the offending agent's buffers untouched, the others unaffected."""
+    eng, _ = make_pair("simple_cart", 10, 2.0, n_oracles=0)
+    B, T = 3, eng.T
+    rng = np.random.default_rng(0)
+    ut = rng.uniform(-0.3, 0.3, (B, T, 3))
+    ut[:, :, 1] = 0.0
+    ut[1, 5, 1] = 1e-3
+    d_ut = dev(ut)
+    d_pose = dev(random_poses(rng, B))
+    d_u0 = torch.zeros((B, 3), dtype=torch.float64, device="cuda")
+    d_status = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    eng.control_batch(B, d_pose, d_ut, d_u0, status=d_status)
+    torch.cuda.synchronize()
+    assert d_status.cpu().tolist() == [0, capi.ERR_INVALID_TWIST, 0]
+    assert np.array_equal(d_ut.cpu().numpy()[1], ut[1])
+    eng.set_ut(ut[1].T)
+    with pytest.raises(capi.EngineError) as ei:
+        eng.control(MAP_BOUNDS, [1.0, 1.0, 0.0])
+    assert ei.value.status == capi.ERR_INVALID_TWIST
+    eng.close()
+
+
+def test_constructor_errors():
+    with pytest.raises(capi.EngineError) as ei:  # horizon == dt -> steps == 1 (ergodic_control.hpp:212-216)
+        capi.Engine(capi.make_config(capi.MODEL_OMNI, 0.1, 0.1, 0.1, 1.0, 5, np.eye(3), [-1] * 3, [1] * 3))
+    assert ei.value.status == capi.ERR_INVALID_ARGUMENT
+    with pytest.raises(capi.EngineError):        # Cart / Mecanum are not usable with ErgodicControl
+        capi.Engine(capi.make_config(2, 0.1, 1.0, 0.1, 1.0, 5, np.eye(3), [-1] * 3, [1] * 3))
+    eng = capi.Engine(capi.make_config(capi.MODEL_OMNI, 0.1, 1.0, 0.1, 1.0, 5, np.eye(3), [-1] * 3, [1] * 3))
+    with pytest.raises(capi.EngineError) as ei:  # control before any target
+        eng.control(MAP_BOUNDS, [0, 0, 0])
+    assert ei.value.status == capi.ERR_NO_TARGET
+    eng.close()
+
+
+def test_full_size_batch_properties():
+    """BASELINE config 4 size (4096 agents, K = 10, T = 200): size-independent properties.
+    (a) mode (0,0) of c_k is exactly the mean of ones; (b) an agent's result does not depend on
+    its position in the batch (bitwise); (c) rolling out the updated controls reproduces the
+    next call's rollout shifted by one step; (d) controls respect the clamp limits."""
+    B = 4096
+    eng, _ = make_pair("omni", 10, 20.0, n_oracles=0)
+    T, K2 = eng.T, eng.K2
+    rng = np.random.default_rng(12345)
+    poses = random_poses(rng, B)
+    poses[B - 1] = poses[0]
+    d_pose = dev(poses)
+    d_ut = torch.zeros((B, T, 3), dtype=torch.float64, device="cuda")
+    d_u0 = torch.empty((B, 3), dtype=torch.float64, device="cuda")
+    d_ck = torch.empty((B, K2), dtype=torch.float64, device="cuda")
+    d_traj = torch.empty((B, T, 3), dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        eng.control_batch(B, d_pose, d_ut, d_u0, ck=d_ck, traj=d_traj)
+    torch.cuda.synchronize()
+    ck, ut, u0 = d_ck.cpu().numpy(), d_ut.cpu().numpy(), d_u0.cpu().numpy()
+    assert np.abs(ck[:, 0] - 1.0).max() < 1e-14
+    assert np.array_equal(ut[0], ut[B - 1]) and np.array_equal(u0[0], u0[B - 1])
+    assert np.array_equal(u0, ut[:, 0, :])
+    lim = np.array([1.0, 1.0, 2.0])
+    assert (np.abs(ut) <= lim + 0.0).all()
+    # (c): rollout of shifted controls == traj of the next control call
+    shifted = np.concatenate([ut[:, 1:, :], np.zeros((B, 1, 3))], axis=1)
+    d_sh = dev(shifted)
+    d_tr2 = torch.empty((B, T, 3), dtype=torch.float64, device="cuda")
+    eng.rollout_batch(B, d_pose, d_sh, d_tr2)
+    eng.control_batch(B, d_pose, d_ut, d_u0, traj=d_traj)
+    torch.cuda.synchronize()
+    assert torch.equal(d_tr2, d_traj)
+    # (b) again, against a B = 1 launch of the same agent
+    d_ut1 = dev(ut[7:8])
+    d_u01 = torch.empty((1, 3), dtype=torch.float64, device="cuda")
+    eng.control_batch(1, d_pose[7:8], d_ut1, d_u01)
+    torch.cuda.synchronize()
+    assert torch.equal(d_ut1[0], d_ut[7])
+    eng.close()

@@ -1,0 +1,151 @@
+"""GPU parity of the phi_k path (Target::fill + Basis::spatialCoeff behind configTarget) and of
+the Basis free operations against the CPU oracle.  fp64 tolerance: <= 1e-11 abs on phi_k / c_k
+(SURVEY.md 8(d)); the normalised target grid <= 1e-14 abs."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import pyoracle as po
+from ergodic_exploration_amd import capi
+from tests.gpu_util import MAP_BOUNDS, MEANS, SIGMAS
+
+pytestmark = pytest.mark.gpu
+
+
+def _engine(K, resolution=0.1, precision=capi.PREC_F64):
+    return capi.Engine(capi.make_config(capi.MODEL_OMNI, 0.1, 2.0, resolution, 1.0, K, np.eye(3),
+                                        [-1] * 3, [1] * 3, precision=precision))
+
+
+def _oracle_phik(K, bounds, means, sigmas, resolution=0.1):
+    o = po.ErgodicControl(po.MODEL_OMNI, 0.1, 2.0, resolution, 1.0, K, np.eye(3), [-1] * 3, [1] * 3)
+    o.set_target(means, sigmas)
+    assert o.config_target(bounds) == 1
+    return o
+
+
+@pytest.mark.parametrize("K,bounds,means,sigmas", [
+    (10, MAP_BOUNDS, MEANS, SIGMAS),                                     # 121 x 61 points
+    (5, (0.0, 12.0, 0.0, 6.0), [[2.5, 2.5]], [[1.5, 1.5]]),              # config 1
+    (20, (0.0, 25.5, 0.0, 25.5), [[6.0, 6.0], [19.0, 12.0]], [[3.0, 3.0], [3.0, 3.0]]),  # 256 x 256
+    (7, (-3.0, 30.3, 2.0, 9.7), [[1.0, 4.0], [20.0, 8.0], [12.0, 3.0]],
+     [[2.0, 1.0], [4.0, 2.5], [0.7, 0.9]]),                              # ragged 334 x 78, 3 Gaussians
+])
+def test_phik_matches_oracle(K, bounds, means, sigmas):
+    eng = _engine(K)
+    eng.set_target_gaussians(means, sigmas)
+    assert eng.config_domain(bounds) is True
+    o = _oracle_phik(K, bounds, means, sigmas)
+    assert np.abs(eng.phik() - o.phik).max() < 1e-11
+    assert np.abs(eng.lamdak() - o.lamdak).max() < 1e-15
+    # Target::fill output
+    lx, ly = bounds[1] - bounds[0], bounds[3] - bounds[2]
+    pv, nx, ny = eng.target_grid()
+    g = po.phi_grid(nx, ny, 0.1)
+    assert nx == po.lib().eo_axis_length(0.0, lx, 0.1) + 1 and ny == po.lib().eo_axis_length(0.0, ly, 0.1) + 1
+    ref = po.target_fill(means, sigmas, [bounds[0], bounds[2]], g)
+    assert np.abs(pv - ref).max() < 1e-14
+    assert abs(pv.sum() - 1.0) < 1e-12
+    eng.close()
+
+
+def test_phik_anchor_from_reference(anchors):
+    a = anchors["phik_K10_121x61_trans0"]
+    eng = _engine(a["num_basis"], a["resolution"])
+    eng.set_target_gaussians(a["means"], a["sigmas"])
+    eng.config_domain((0.0, a["lx"], 0.0, a["ly"]))  # origin (0,0): trans = 0
+    pk = eng.phik()
+    K = a["num_basis"]
+    assert abs(pk[0] - a["phik_0"]) < 1e-11
+    assert abs(pk[1] - a["phik_1"]) < 1e-11
+    assert abs(pk[K] - a["phik_K"]) < 1e-11
+    eng.close()
+
+
+def test_rebuild_rule():
+    """configTarget rebuilds only when the extent changes by >= 1e-12; map_pos follows every
+    call; a later setTarget alone does not rebuild (ergodic_control.hpp:366-377)."""
+    eng = _engine(10)
+    eng.set_target_gaussians(MEANS, SIGMAS)
+    assert eng.config_domain(MAP_BOUNDS) is True
+    pk = eng.phik()
+    assert eng.config_domain(MAP_BOUNDS) is False
+    assert eng.config_domain((0.0, 12.0, 0.0, 6.0)) is False      # origin moved, same extent
+    eng.set_target_gaussians([[1.0, 1.0]], [[0.5, 0.5]])
+    assert eng.config_domain((0.0, 12.0, 0.0, 6.0)) is False
+    assert np.array_equal(eng.phik(), pk)
+    assert eng.config_domain((0.0, 12.0 + 5e-13, 0.0, 6.0)) is False
+    assert eng.config_domain((0.0, 12.5, 0.0, 6.0)) is True       # map grew
+    o = _oracle_phik(10, (0.0, 12.5, 0.0, 6.0), [[1.0, 1.0]], [[0.5, 0.5]])
+    assert np.abs(eng.phik() - o.phik).max() < 1e-11
+    eng.close()
+
+
+def test_set_target_grid_entropy_surrogate():
+    """BASELINE config 5 entry (reduced): explicit target grid from an int8 occupancy map through
+    entropy() (numerics.hpp:164-179), normalised to sum 1 -> Basis::spatialCoeff."""
+    rng = np.random.default_rng(2024)
+    nx = ny = 129
+    res = 0.1
+    lx = ly = (nx - 1) * res
+    blocks = rng.choice(np.array([0, 100, -1], dtype=np.int8), size=(ny // 16 + 1, nx // 16 + 1), p=[0.7, 0.1, 0.2])
+    occ = np.kron(blocks, np.ones((16, 16), dtype=np.int8))[:ny, :nx]
+    ent = np.array([po.lib().eo_entropy(float(v) / 100.0) for v in occ.reshape(-1)])
+    phi = ent / ent.sum()
+    K = 12
+    eng = _engine(K, res)
+    eng.set_target_grid(nx, ny, torch.as_tensor(phi).cuda(), lx, ly)
+    g = po.phi_grid(nx, ny, res)
+    ref = po.spatial_coeff(lx, ly, K, phi, g)
+    assert np.abs(eng.phik() - ref).max() < 1e-11
+    # host-pointer form, and linearity of spatialCoeff in phi_vals
+    eng.set_target_grid(nx, ny, 2.0 * phi, lx, ly)
+    assert np.abs(eng.phik() - 2.0 * ref).max() < 2e-11
+    eng.close()
+
+
+def test_phik_f32():
+    eng = _engine(20, precision=capi.PREC_F32)
+    bounds = (0.0, 25.5, 0.0, 25.5)
+    means, sigmas = [[6.0, 6.0], [19.0, 12.0]], [[3.0, 3.0], [3.0, 3.0]]
+    eng.set_target_gaussians(means, sigmas)
+    eng.config_domain(bounds)
+    o = _oracle_phik(20, bounds, means, sigmas)
+    assert np.abs(eng.phik() - o.phik).max() < 2e-5
+    eng.close()
+
+
+def test_large_grid_property():
+    """1024 x 1024 grid, K = 30 (config 5 size): phi_k(0,0) = sum(phi) = 1, and the separable
+    kernel agrees with the point-list kernel (different code path) to 1e-11."""
+    nx = ny = 1024
+    res = 0.1
+    lx = ly = (nx - 1) * res
+    rng = np.random.default_rng(7)
+    phi = rng.random(nx * ny)
+    phi /= phi.sum()
+    K = 30
+    eng = _engine(K, res)
+    eng.set_target_grid(nx, ny, torch.as_tensor(phi).cuda(), lx, ly)
+    pk = eng.phik()
+    assert abs(pk[0] - 1.0) < 1e-12
+    g = po.phi_grid(nx, ny, res)
+    pk2 = capi.basis_spatial_coeff(lx, ly, K, phi, g)
+    assert np.abs(pk - pk2).max() < 1e-11
+    eng.close()
+
+
+def test_basis_free_functions():
+    rng = np.random.default_rng(3)
+    lx, ly, K = 12.0, 6.0, 10
+    xt = np.vstack([rng.uniform(0, lx, 333), rng.uniform(0, ly, 333), rng.uniform(-3, 3, 333)])
+    assert np.abs(capi.basis_traj_coeff(lx, ly, K, xt) - po.traj_coeff(lx, ly, K, xt)).max() < 1e-12
+    P = 5000
+    grid = np.vstack([rng.uniform(0, lx, P), rng.uniform(0, ly, P)])
+    pv = rng.random(P)
+    assert np.abs(capi.basis_spatial_coeff(lx, ly, K, pv, grid) -
+                  po.spatial_coeff(lx, ly, K, pv, grid)).max() < 1e-10
+    # single point == fourierBasis
+    x = np.array([[3.3], [1.7]])
+    assert np.abs(capi.basis_traj_coeff(lx, ly, 5, x) - po.fourier_basis(lx, ly, 5, x[:, 0])).max() < 1e-15
