@@ -55,21 +55,24 @@ def cpu_baseline(args, T, seconds):
     model = po.MODEL_SIMPLE_CART if args.model == "simple_cart" else po.MODEL_OMNI
     cfg = po.make_config(model, args.dt, args.horizon, 0.1, 1.0, args.num_basis, Rinv, -lim, lim)
     rng = np.random.default_rng(12345)
-    ncores = os.cpu_count() or 1
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
 
     def poses(n):
         return np.stack([rng.uniform(-0.5, 10.5, n), rng.uniform(-0.5, 4.5, n), rng.uniform(-np.pi, np.pi, n)], 1)
 
-    # calibrate on a tiny sample, then size the timed sample to the budget
-    sec, _ = po.bench_control(cfg, MEANS, SIGMAS, MAP_BOUNDS, poses(4), 5, 1)
-    per_opt = max(sec / 20.0, 1e-6)
+    # calibrate each leg on a tiny sample, then size its timed sample to the budget, so the
+    # default run stays bounded whatever the host's core count / CPU quota is
     calls = 10
-    n1 = max(4, int(seconds / per_opt / calls))
+    sec, _ = po.bench_control(cfg, MEANS, SIGMAS, MAP_BOUNDS, poses(4), 5, 1)
+    rate1 = 20.0 / max(sec, 1e-6)
+    n1 = max(4, int(seconds * rate1 / calls))
     sec1, _ = po.bench_control(cfg, MEANS, SIGMAS, MAP_BOUNDS, poses(n1), calls, 1)
     one = {"value": n1 * calls / sec1, "unit": "optimisations/s", "cores": 1, "kind": "port",
            "sample": "%d agents x %d control() calls, oracle/ergodic_oracle.c gcc -O2, 1 thread, %.1f s"
                      % (n1, calls, sec1)}
-    nall = max(ncores, int(seconds / per_opt / calls) * ncores)
+    secc, _ = po.bench_control(cfg, MEANS, SIGMAS, MAP_BOUNDS, poses(2 * ncores), 3, ncores)
+    raten = 6.0 * ncores / max(secc, 1e-6)
+    nall = max(ncores, int(seconds * raten / calls))
     secn, _ = po.bench_control(cfg, MEANS, SIGMAS, MAP_BOUNDS, poses(nall), calls, ncores)
     allc = {"value": nall * calls / secn, "unit": "optimisations/s", "cores": ncores, "kind": "port",
             "sample": "%d agents x %d control() calls, one agent per thread, %d threads, %.1f s"

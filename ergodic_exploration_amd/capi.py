@@ -73,6 +73,13 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError("libergodic_amd.so is missing: run __graft_entry__.build() "
                                "(hipcc --offload-arch=gfx950); there is no CPU fallback")
+        # One HIP runtime per process: the tests and bench.py hand torch-allocated device
+        # memory and streams to the engine, so torch's bundled libamdhip64 must be the
+        # instance this library binds to (loading the system one first gives two runtimes).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.eea_last_error.restype = C.c_char_p
         L.eea_steps.restype = C.c_uint
