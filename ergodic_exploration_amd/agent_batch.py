@@ -1,0 +1,54 @@
+"""Agent-batch sharding across the GPUs of one node (one process per GPU).
+
+Agents are independent `ErgodicControl` instances, so the batch shards with no data-path
+collective; the only exchange is the all-gather of the per-agent trajectory coefficients c_k
+(K^2 reals per agent) that decentralised ergodic control shares between agents (reference
+README ref. [2]).  `backend="nccl"` is RCCL over xGMI on ROCm; `gloo` is used by the CPU tests.
+"""
+
+
+def shard_range(n_agents, rank, world):
+    """Contiguous block of agents owned by `rank`: [first, last)."""
+    if world <= 0 or not (0 <= rank < world):
+        raise ValueError("bad rank/world")
+    first = (n_agents * rank) // world
+    last = (n_agents * (rank + 1)) // world
+    return first, last
+
+
+def shard_sizes(n_agents, world):
+    return [shard_range(n_agents, r, world)[1] - shard_range(n_agents, r, world)[0] for r in range(world)]
+
+
+def gather_ck(ck_local, out=None, group=None, async_op=False):
+    """All-gather of per-agent c_k: ck_local [B_local, K2] -> [world * B_local, K2] in rank
+    order (equal shard sizes, one in-place collective).  Returns (tensor, work)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if out is None:
+        out = torch.empty((world * ck_local.shape[0],) + tuple(ck_local.shape[1:]),
+                          dtype=ck_local.dtype, device=ck_local.device)
+    work = dist.all_gather_into_tensor(out, ck_local.contiguous(), group=group, async_op=async_op)
+    return out, work
+
+
+def gather_ck_ragged(ck_local, n_agents, group=None):
+    """All-gather for unequal shards (n_agents not divisible by the world size): shards are
+    padded to the largest one so a single equal-size collective still does the exchange."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    sizes = shard_sizes(n_agents, world)
+    smax = max(sizes)
+    padded = torch.zeros((smax,) + tuple(ck_local.shape[1:]), dtype=ck_local.dtype, device=ck_local.device)
+    padded[:ck_local.shape[0]] = ck_local
+    out = torch.empty((world * smax,) + tuple(ck_local.shape[1:]), dtype=ck_local.dtype,
+                      device=ck_local.device)
+    dist.all_gather_into_tensor(out, padded, group=group)
+    return torch.cat([out[r * smax:r * smax + sizes[r]] for r in range(world)], 0)
+
+
+def consensus_ck(ck_all):
+    """Mean of the agents' c_k: the shared statistic of decentralised ergodic control."""
+    return ck_all.mean(dim=0)

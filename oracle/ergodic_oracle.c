@@ -370,6 +370,19 @@ void eo_grad_fourier_basis(double lx, double ly, unsigned num_basis, const doubl
 
 /* basis.cpp:109-120: (1/N) * sum(fk_mat, 1); Armadillo's sum(M,1) adds the
  * columns in order starting from zeros */
+static void traj_coeff_ws(double lx, double ly, unsigned num_basis, const double* xt, unsigned rows,
+                          unsigned n, double* ck, double* fk)
+{
+  const unsigned total = num_basis * num_basis;
+  for (unsigned m = 0; m < total; m++) ck[m] = 0.0;
+  for (unsigned i = 0; i < n; i++) {
+    eo_fourier_basis(lx, ly, num_basis, xt + (size_t)rows * i, fk);
+    for (unsigned m = 0; m < total; m++) ck[m] += fk[m];
+  }
+  const double inv = 1.0 / (double)n;
+  for (unsigned m = 0; m < total; m++) ck[m] = inv * ck[m];
+}
+
 void eo_traj_coeff(double lx, double ly, unsigned num_basis, const double* xt, unsigned rows,
                    unsigned n, double* ck)
 {
@@ -675,6 +688,10 @@ struct eo_control {
   unsigned n_gauss;
   double* mu;
   double* sigma;
+  /* scratch reused across control() calls (no arithmetic meaning): keeps the timed CPU
+   * baseline free of allocator contention when one agent runs per thread */
+  double *w_traj, *w_xt_total, *w_ck, *w_edx, *w_bdx, *w_rhot, *w_fk, *w_dfk, *w_diff;
+  unsigned w_ncap;
 };
 
 /* ergodic_control.hpp:187-222 */
@@ -697,6 +714,19 @@ int eo_control_create(const eo_control_config* cfg, eo_control** out)
   eo_basis_init(ec->K, ec->k, ec->lamdak);
   ec->lx = 0.0;
   ec->ly = 0.0;
+  {
+    const size_t T3 = (size_t)3 * (steps ? steps : 1), K2 = ec->K2 ? ec->K2 : 1;
+    ec->w_traj = (double*)malloc(sizeof(double) * T3);
+    ec->w_edx = (double*)malloc(sizeof(double) * T3);
+    ec->w_bdx = (double*)malloc(sizeof(double) * T3);
+    ec->w_rhot = (double*)malloc(sizeof(double) * T3);
+    ec->w_ck = (double*)malloc(sizeof(double) * K2);
+    ec->w_fk = (double*)malloc(sizeof(double) * K2);
+    ec->w_diff = (double*)malloc(sizeof(double) * K2);
+    ec->w_dfk = (double*)malloc(sizeof(double) * 2 * K2);
+    ec->w_ncap = steps;
+    ec->w_xt_total = (double*)malloc(sizeof(double) * T3);
+  }
   *out = ec;
   return EO_OK;
 }
@@ -710,6 +740,15 @@ void eo_control_destroy(eo_control* ec)
   free(ec->k);
   free(ec->mu);
   free(ec->sigma);
+  free(ec->w_traj);
+  free(ec->w_xt_total);
+  free(ec->w_ck);
+  free(ec->w_edx);
+  free(ec->w_bdx);
+  free(ec->w_rhot);
+  free(ec->w_fk);
+  free(ec->w_dfk);
+  free(ec->w_diff);
   free(ec);
 }
 
@@ -790,8 +829,8 @@ static void grad_ergodic_metric(const eo_control* ec, const double* ck, const do
                                 double* edx)
 {
   const unsigned K2 = ec->K2;
-  double* fourier_diff = (double*)malloc(sizeof(double) * K2);
-  double* dfk = (double*)malloc(sizeof(double) * 2 * K2);
+  double* fourier_diff = ec->w_diff;
+  double* dfk = ec->w_dfk;
   for (unsigned m = 0; m < K2; m++) fourier_diff[m] = ec->lamdak[m] * (ck[m] - ec->phik[m]);
   for (unsigned i = 0; i < ec->steps; i++) {
     eo_grad_fourier_basis(ec->lx, ec->ly, ec->K, xt + 3 * (size_t)i, dfk);
@@ -808,8 +847,6 @@ static void grad_ergodic_metric(const eo_control* ec, const double* ck, const do
     edx[3 * i + 0] *= ec->cfg.expl_weight;
     edx[3 * i + 1] *= ec->cfg.expl_weight;
   }
-  free(dfk);
-  free(fourier_diff);
 }
 
 /* ergodic_control.hpp:453-474 */
@@ -882,16 +919,18 @@ int eo_control_step(eo_control* ec, double xmin, double xmax, double ymin, doubl
   ec->ut[3 * (T - 1) + 2] = 0.0;
 
   /* :237 forward simulation */
-  double* traj = (double*)malloc(sizeof(double) * 3 * T);
+  double* traj = ec->w_traj;
   int st = eo_rk4_solve_fwd(ec->cfg.model, NULL, ec->cfg.dt, ec->cfg.horizon, ec->pose, ec->ut, traj);
-  if (st != EO_OK) {
-    free(traj);
-    return st;
-  }
+  if (st != EO_OK) return st;
 
   /* :240 sampleMemory (buffer.cpp:64-111): sampled columns first, rollout last */
   const unsigned N = T + n_mem;
-  double* xt_total = (double*)malloc(sizeof(double) * 3 * N);
+  if (N > ec->w_ncap) {
+    free(ec->w_xt_total);
+    ec->w_xt_total = (double*)malloc(sizeof(double) * 3 * (size_t)N);
+    ec->w_ncap = N;
+  }
+  double* xt_total = ec->w_xt_total;
   if (n_mem) memcpy(xt_total, mem_cols, sizeof(double) * 3 * n_mem);
   memcpy(xt_total + 3 * (size_t)n_mem, traj, sizeof(double) * 3 * T);
 
@@ -904,13 +943,13 @@ int eo_control_step(eo_control* ec, double xmin, double xmax, double ymin, doubl
   /* :264 last T columns */
   const double* xt = xt_total + 3 * (size_t)(N - T);
 
-  double* ck = (double*)malloc(sizeof(double) * ec->K2);
-  double* edx = (double*)malloc(sizeof(double) * 3 * T);
-  double* bdx = (double*)malloc(sizeof(double) * 3 * T);
-  double* rhot = (double*)malloc(sizeof(double) * 3 * T);
+  double* ck = ec->w_ck;
+  double* edx = ec->w_edx;
+  double* bdx = ec->w_bdx;
+  double* rhot = ec->w_rhot;
 
   /* :267 */
-  eo_traj_coeff(ec->lx, ec->ly, ec->K, xt_total, 3, N, ck);
+  traj_coeff_ws(ec->lx, ec->ly, ec->K, xt_total, 3, N, ck, ec->w_fk);
   /* :270 */
   grad_ergodic_metric(ec, ck, xt, edx);
   /* :273 */
@@ -936,12 +975,6 @@ int eo_control_step(eo_control* ec, double xmin, double xmax, double ymin, doubl
   u_out[1] = ec->ut[1];
   u_out[2] = ec->ut[2];
 
-  free(rhot);
-  free(bdx);
-  free(edx);
-  free(ck);
-  free(xt_total);
-  free(traj);
   return EO_OK;
 }
 

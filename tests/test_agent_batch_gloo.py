@@ -1,0 +1,83 @@
+"""N > 1 path on CPU: world_size-2 gloo processes shard an agent batch, each computes its agents'
+c_k (with the CPU oracle standing in for the device kernel, which is the checker's only role here)
+and all-gathers them; the result must equal the single-process batch in agent order."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from ergodic_exploration_amd import agent_batch as ab
+
+
+def test_shard_ranges_cover_batch():
+    for n, w in [(4096, 8), (4096, 1), (10, 4), (7, 2), (3, 8)]:
+        ranges = [ab.shard_range(n, r, w) for r in range(w)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n
+        for a, b in zip(ranges[:-1], ranges[1:]):
+            assert a[1] == b[0]
+        assert sum(ab.shard_sizes(n, w)) == n
+    with pytest.raises(ValueError):
+        ab.shard_range(4, 2, 2)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ck_for(agent_ids):
+    from oracle import pyoracle as po
+    K, lx, ly, T = 5, 12.0, 6.0, 20
+    out = np.empty((len(agent_ids), K * K))
+    for i, a in enumerate(agent_ids):
+        rng = np.random.default_rng(1000 + a)
+        xt = np.vstack([rng.uniform(0, lx, T), rng.uniform(0, ly, T), np.zeros(T)])
+        out[i] = po.traj_coeff(lx, ly, K, xt)
+    return out
+
+
+def _worker(rank, world, port, n_agents, ragged, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    first, last = ab.shard_range(n_agents, rank, world)
+    ck_local = torch.as_tensor(_ck_for(range(first, last)))
+    if ragged:
+        ck_all = ab.gather_ck_ragged(ck_local, n_agents)
+    else:
+        ck_all, _ = ab.gather_ck(ck_local)
+        # async form used by bench.py
+        out2, work = ab.gather_ck(ck_local, async_op=True)
+        work.wait()
+        assert torch.equal(out2, ck_all)
+    mean = ab.consensus_ck(ck_all)
+    if rank == 0:
+        q.put((ck_all.numpy(), mean.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_agents,ragged", [(8, False), (7, True)])
+def test_gather_ck_world2_gloo(n_agents, ragged):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_agents, ragged, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    ck_all, mean = q.get(timeout=60)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    ref = _ck_for(range(n_agents))
+    assert np.array_equal(ck_all, ref)
+    assert np.allclose(mean, ref.mean(0), atol=1e-15)

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Prints the worst |GPU - oracle| per stage for the parity configurations (run on the GPU box);
+the output is committed under profiles/ as the measured parity margin."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from ergodic_exploration_amd import capi  # noqa: E402
+from tests import test_gpu_control_parity as t  # noqa: E402
+
+CASES = [("omni", 5, 0.5, 0.1, 0), ("simple_cart", 10, 2.0, 0.1, 0), ("omni", 10, 5.0, 0.1, 7),
+         ("simple_cart", 10, 5.0, 0.1, 100), ("omni", 10, 20.0, 0.1, 0), ("simple_cart", 10, 20.0, 0.1, 100),
+         ("omni", 7, 30.0, 0.1, 5), ("omni", 30, 50.0, 0.1, 0)]
+print("fp64: worst abs difference kernel vs oracle over B agents x calls")
+for model, K, hor, dt, n_mem in CASES:
+    B = 1 if K >= 30 else 4
+    w = t.run_batch_vs_oracle(model, K, hor, dt, B=B, n_mem=n_mem, calls=2, seed=21)
+    print("%-12s K=%-2d T=%-3d n_mem=%-3d " % (model, K, int(abs(hor / dt) + 1e-9), n_mem) +
+          " ".join("%s=%.1e" % (k, v) for k, v in sorted(w.items())))
+bounds = (0.0, 25.5, 0.0, 25.5)
+means, sigmas = [[6.0, 6.0], [19.0, 12.0]], [[3.0, 3.0], [3.0, 3.0]]
+for prec, name, tol, tck in ((capi.PREC_F64, "f64", 1e-9, 1e-11), (capi.PREC_F32, "f32", 5e-4, 1e-5)):
+    w = t.run_batch_vs_oracle("omni", 20, 5.0, 0.02, B=2, n_mem=0, calls=2, seed=3, bounds=bounds, means=means,
+                              sigmas=sigmas, precision=prec, tol=tol, tol_ck=tck)
+    print("config3 %s  K=20 T=250 " % name + " ".join("%s=%.1e" % (k, v) for k, v in sorted(w.items())))
