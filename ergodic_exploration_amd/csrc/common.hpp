@@ -28,6 +28,7 @@ struct ControlParams
   unsigned mem_stride;
   R dt, lx, ly, map_x, map_y, expl_weight;
   R pi_lx, pi_ly;     // PI / lx, PI / ly (basis.cpp:85)
+  R inv_lx, inv_ly;   // 1 / lx, 1 / ly (sin/cos(pi x / lx) evaluation)
   R Rinv[9];          // column-major
   R umin[3], umax[3];
   const R* phik;      // [K^2]
@@ -54,6 +55,16 @@ size_t control_lds_bytes(int T, int K, int n_mem_max, int chunk);
 template <typename R>
 hipError_t launch_control(const ControlParams<R>& p, unsigned B, int model, int n_mem_max,
                           bool rollout_only, hipStream_t stream);
+
+// first version of the control kernel (control_kernel_v1.hip), kept as the A/B baseline
+namespace v1
+{
+template <typename R>
+size_t control_lds_bytes(int T, int K, int n_mem_max, int chunk);
+template <typename R>
+hipError_t launch_control(const ControlParams<R>& p, unsigned B, int model, int n_mem_max,
+                          bool rollout_only, hipStream_t stream);
+}  // namespace v1
 
 // ---- phi_k path ----------------------------------------------------------------------
 // cos tables: out[k * n + i] = cos((k * pi_over_l) * coord[i]), k < K
@@ -126,6 +137,20 @@ __device__ __forceinline__ void sincos_r<float>(float a, float* s, float* c)
   sincosf(a, s, c);
 }
 
+// sin(pi t), cos(pi t): exact argument reduction, no large-argument path
+template <typename R>
+__device__ __forceinline__ void sincospi_r(R t, R* s, R* c);
+template <>
+__device__ __forceinline__ void sincospi_r<double>(double t, double* s, double* c)
+{
+  sincospi(t, s, c);
+}
+template <>
+__device__ __forceinline__ void sincospi_r<float>(float t, float* s, float* c)
+{
+  sincospif(t, s, c);
+}
+
 // numerics.hpp:78-90 of the reference: wrap to [-pi, pi)
 template <typename R>
 __device__ __forceinline__ R wrap_pi(R rad)
@@ -153,6 +178,35 @@ __device__ __forceinline__ R wave_inclusive_scan(R v)
     const R t = __shfl_up(v, o, kWave);
     if (lane >= o) v += t;
   }
+  return v;
+}
+
+// ---- DPP scans: row shifts inside 16-lane rows, row broadcasts across rows; no LDS traffic
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_or_zero(double v)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or_zero(float v)
+{
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+
+// wave64 inclusive sum scan: row_shr 1,2,4,8 then row_bcast15 (rows 1,3) and row_bcast31
+// (rows 2,3).  Lanes without a source keep the identity 0.
+template <typename R>
+__device__ __forceinline__ R wave_inclusive_scan_dpp(R v)
+{
+  v += dpp_or_zero<0x111, 0xf>(v);
+  v += dpp_or_zero<0x112, 0xf>(v);
+  v += dpp_or_zero<0x114, 0xf>(v);
+  v += dpp_or_zero<0x118, 0xf>(v);
+  v += dpp_or_zero<0x142, 0xa>(v);
+  v += dpp_or_zero<0x143, 0xc>(v);
   return v;
 }
 

@@ -1,4 +1,6 @@
-// Fused receding-horizon ergodic control kernel for gfx950 (MI355X), version 2.
+// Fused receding-horizon ergodic control kernel for gfx950 (MI355X) -- FIRST VERSION (v1).
+// Kept selectable (EEA_CONTROL_IMPL=v1) as the A/B baseline of control_kernel.hip; same
+// algorithm, plain sincos, ds_bpermute scans, VALU contraction, no LDS aliasing.
 //
 // One workgroup (256 threads = 4 wavefronts) per agent performs one complete
 // `ErgodicControl<ModelT>::control` call (reference ergodic_control.hpp:224-311, minus
@@ -10,56 +12,43 @@
 //   -> control update + clamp (:438-451).
 //
 // It is not a translation of the reference's loops.  Three identities of the reference's
-// own formulas make the horizon parallel (derivations in DESIGN.md section 2):
+// own formulas make the horizon parallel (derivations in DESIGN.md):
 //   1. The basis is separable, f_k(x,y) = cos(a_k1 x) cos(b_k2 y) (basis.cpp:85), and
-//      cos(k a), sin(k a) follow from one sincos by the angle-addition recurrence.
+//      cos(k a), sin(k a) follow from one sincos by the angle-addition recurrence, so a
+//      point costs 2 sincos + O(K) flops instead of 2K^2 (4K^2) libm calls.
 //   2. For Omni/SimpleCart theta' = w does not depend on the state, so RK4 collapses to
 //      Simpson's rule in closed form and the rollout is two prefix sums over the horizon.
 //   3. fdx has only A(0,2), A(1,2) non-zero and edx(2) = bdx(2) = 0, so the co-state pass is
 //      two chained suffix sums (RK4 == trapezoid there).
-//
-// CDNA4 mapping (what changed against control_kernel_v1.hip):
-//   * horizon scans: DPP row shifts / row broadcasts inside each 64-lane wavefront (no LDS
-//     traffic), one LDS hop between the 4 wavefronts;
-//   * c_k = (1/N) Cx Cy^T is the one GEMM-shaped piece: each wavefront stages the cos tables of
-//     16 of its points in a private LDS tile laid out [point][k] so that the MFMA operand of
-//     lane l is the contiguous element (4g + l/16) * KS + l%16, and accumulates with
-//     v_mfma_f64_16x16x4_f64 (v_mfma_f32_16x16x4_f32 for fp32); no workgroup barrier inside;
-//   * sin(pi t) / cos(pi t) evaluation (exact argument reduction) for headings and basis angles;
-//   * LDS regions with disjoint lifetimes are aliased: 32 KB per agent at K=10, T=200 (fp64),
-//     4 workgroups per CU.
+// The horizon scans use wavefront shuffles (__shfl_up over 64 lanes) plus one LDS hop
+// between the 4 wavefronts; basis tables and lambda_k (c_k - phi_k) live in LDS.
 #include "common.hpp"
 
 namespace eea
 {
+namespace v1
+{
 namespace
 {
-constexpr int kWaves = kBlock / kWave;
-constexpr int kSub = 16;     // points staged per wavefront per MFMA pass
-constexpr int kTabPad = 32;  // operand reads of the last point run past its row (garbage modes)
-
-__host__ __device__ inline int up4(int n) { return (n + 3) & ~3; }
-__host__ __device__ inline int table_stride(int K) { return (K + 1) & ~1; }  // even: 16-byte rows
-__host__ __device__ inline int wave_tab_elems(int K) { return up4(2 * kSub * table_stride(K) + kTabPad); }
-
-// LDS carve (element offsets; every segment a multiple of 4 elements => 16-byte aligned)
+// LDS carve (element offsets, every segment a multiple of 4 elements so that all bases
+// stay 16-byte aligned for float and double).
 struct LdsLayout
 {
-  int vx, vy, w;           // shifted controls, SoA [T]
-  int ct, st;              // cos/sin of the pre-step heading, [T+1] (index T = final heading)
-  int px, py;              // points in the Fourier frame, [Nmax] (memory first, rollout last)
-  int c1x, s1x, c1y, s1y;  // sin/cos(pi x / lx), sin/cos(pi y / ly) per point, [Nmax]
-  int g0, g1;              // edx + bdx rows 0,1, [T]
-  int D;                   // lambda_k * (c_k - phi_k), [K^2]
-  int sw;                  // scan scratch + flags
-  int E;                   // lifetime-disjoint union:
-                           //   forward pass : mid-stage cos/sin [T] x 2
-                           //   c_k          : per-wavefront MFMA tiles, then the cross-wave reduction
-                           //   backward pass: co-state rows [T+1] x 3
+  int vx, vy, w;      // shifted controls, SoA [T]
+  int ct, st;         // cos/sin of the pre-step heading, [T+1] (index T = final heading)
+  int px, py;         // points in the Fourier frame, [Nmax] (memory first, rollout last)
+  int c1x, s1x, c1y, s1y;  // sincos(pi/lx * x), sincos(pi/ly * y) per point, [Nmax]
+  int g0, g1;         // edx + bdx rows 0,1, [T]; before that: mid-stage cos/sin
+  int r0, r1, r2;     // co-state rows, [T+1] (index T = terminal condition 0)
+  int D;              // lambda_k * (c_k - phi_k), [K^2]
+  int sw;             // scan scratch
+  int tab;            // basis tables of one chunk: [chunk][K] x 2; aliased by the reduction
   int total;
 };
 
-__host__ __device__ inline LdsLayout lds_layout(int T, int Nmax, int K)
+__host__ __device__ inline int up4(int n) { return (n + 3) & ~3; }
+
+__host__ __device__ inline LdsLayout lds_layout(int T, int Nmax, int K, int chunk)
 {
   LdsLayout L;
   int o = 0;
@@ -76,58 +65,36 @@ __host__ __device__ inline LdsLayout lds_layout(int T, int Nmax, int K)
   L.s1y = o; o += up4(Nmax);
   L.g0 = o; o += up4(T);
   L.g1 = o; o += up4(T);
+  L.r0 = o; o += up4(T + 1);
+  L.r1 = o; o += up4(T + 1);
+  L.r2 = o; o += up4(T + 1);
   L.D = o; o += up4(K * K);
   L.sw = o; o += 16;
-  L.E = o;
-  int e = 2 * up4(T);
-  const int tab = kWaves * wave_tab_elems(K);
-  const int red = kWaves * K * K;
-  const int rho = 3 * up4(T + 1);
-  e = e > tab ? e : tab;
-  e = e > red ? e : red;
-  e = e > rho ? e : rho;
-  o += up4(e);
+  L.tab = o;
+  const int tab = 2 * chunk * K;
+  o += up4(tab > 4 * kBlock ? tab : 4 * kBlock);
   L.total = o;
   return L;
 }
 
-// ---- workgroup scans on top of the DPP wavefront scan -------------------------------------
+// inclusive scan of a pair; scratch s_w needs 2 * (kBlock / kWave) reals
 template <typename R>
-__device__ __forceinline__ R block_scan(R v, R* s_w, R& total)
+__device__ __forceinline__ void block_inclusive_scan2(R& a, R& b, R* s_w, R& tot_a, R& tot_b)
 {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = threadIdx.x / kWave;
-  const R s = wave_inclusive_scan_dpp(v);
-  if (lane == kWave - 1) s_w[wave] = s;
-  __syncthreads();
-  R off = R(0), tot = R(0);
-#pragma unroll
-  for (int w = 0; w < kWaves; ++w) {
-    const R ws = s_w[w];
-    if (w < wave) off += ws;
-    tot += ws;
-  }
-  __syncthreads();
-  total = tot;
-  return s + off;
-}
-
-template <typename R>
-__device__ __forceinline__ void block_scan2(R& a, R& b, R* s_w, R& tot_a, R& tot_b)
-{
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x / kWave;
-  const R sa = wave_inclusive_scan_dpp(a);
-  const R sb = wave_inclusive_scan_dpp(b);
+  constexpr int NW = kBlock / kWave;
+  const R sa = wave_inclusive_scan(a);
+  const R sb = wave_inclusive_scan(b);
   if (lane == kWave - 1) {
     s_w[wave] = sa;
-    s_w[kWaves + wave] = sb;
+    s_w[NW + wave] = sb;
   }
   __syncthreads();
   R oa = R(0), ob = R(0), ta = R(0), tb = R(0);
 #pragma unroll
-  for (int w = 0; w < kWaves; ++w) {
-    const R wa = s_w[w], wb = s_w[kWaves + w];
+  for (int w = 0; w < NW; ++w) {
+    const R wa = s_w[w], wb = s_w[NW + w];
     if (w < wave) {
       oa += wa;
       ob += wb;
@@ -140,41 +107,6 @@ __device__ __forceinline__ void block_scan2(R& a, R& b, R* s_w, R& tot_a, R& tot
   b = sb + ob;
   tot_a = ta;
   tot_b = tb;
-}
-
-// ---- matrix cores: D = A(16x4) B(4x16) + C, one operand element per lane -----------------------
-// A[i][k]: lane = 16 k + i;  B[k][j]: lane = 16 k + j.  C/D: col = lane % 16 and
-// row = lane/16 + 4 r (f64) or 4 (lane/16) + r (f32), r = accumulator register.
-template <typename R>
-struct Mfma;
-template <>
-struct Mfma<double>
-{
-  using acc_t = double __attribute__((ext_vector_type(4)));
-  static __device__ __forceinline__ acc_t run(double a, double b, acc_t c)
-  {
-    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-  }
-  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
-};
-template <>
-struct Mfma<float>
-{
-  using acc_t = float __attribute__((ext_vector_type(4)));
-  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c)
-  {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-  }
-  static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
-};
-
-// orders a wavefront's own LDS writes before its own LDS reads (same-wave DS ops execute in
-// order; this only stops the compiler from moving them across)
-__device__ __forceinline__ void wave_lds_fence()
-{
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // model right-hand side x/y components at heading (c, s) (omni.hpp:177-181, cart.hpp:172)
@@ -190,27 +122,20 @@ __device__ __forceinline__ void model_xy(R vx, R vy, R c, R s, R& fx, R& fy)
   }
 }
 
-// Register budget: waves per SIMD the kernel is compiled for (VGPR + AGPR <= 512 / waves).
-// K <= 12 keeps the basis rows of the gradient in 128 registers (4 workgroups per CU, matching
-// the LDS footprint); larger K needs the wider budget.
-constexpr int min_waves_per_simd(int KC) { return (KC > 20) ? 2 : ((KC > 12) ? 3 : 4); }
-
 template <typename R, int MODEL, int KC>
-__global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel(
-    const ControlParams<R> p, const int Nmax, const int rollout_only)
+__global__ __launch_bounds__(kBlock) void control_kernel(const ControlParams<R> p, const int Nmax,
+                                                         const int rollout_only)
 {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   R* const sm = reinterpret_cast<R*>(smem_raw);
 
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
-  const int lane = tid & (kWave - 1);
-  const int wave = tid / kWave;
   const int T = p.T;
   const int K = (KC > 0) ? KC : p.K;
   const int K2 = K * K;
-  const int KS = table_stride(K);
-  const LdsLayout L = lds_layout(T, Nmax, K);
+  const int CH = p.chunk;
+  const LdsLayout L = lds_layout(T, Nmax, K, CH);
 
   R* const s_vx = sm + L.vx;
   R* const s_vy = sm + L.vy;
@@ -225,9 +150,14 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
   R* const s_s1y = sm + L.s1y;
   R* const s_g0 = sm + L.g0;
   R* const s_g1 = sm + L.g1;
+  R* const s_r0 = sm + L.r0;
+  R* const s_r1 = sm + L.r1;
+  R* const s_r2 = sm + L.r2;
   R* const s_D = sm + L.D;
   R* const s_sw = sm + L.sw;
-  R* const s_E = sm + L.E;
+  R* const s_tabx = sm + L.tab;
+  R* const s_taby = s_tabx + CH * K;
+  // all LDS lives in the dynamic region so that its base stays 16-byte aligned
   int& s_bad = *reinterpret_cast<int*>(s_sw + 12);
 
   int nmem = 0;
@@ -273,7 +203,6 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
 
   const R dt = p.dt;
   const R dt6 = dt / R(6);
-  const R inv_pi = static_cast<R>(1.0 / kPi);
   R* const traj = (p.traj != nullptr) ? p.traj + 3 * static_cast<size_t>(T) * b : nullptr;
 
   // ---- forward pass, heading: theta_i = wrap(theta_{i-1} + dt/6 (w + 2w + 2w + w))
@@ -288,7 +217,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
         d = dt6 * (((w + R(2) * w) + R(2) * w) + w);
       }
       R tot;
-      const R inc = block_scan(d, s_sw, tot);
+      const R inc = block_inclusive_scan(d, s_sw, &tot);
       if (i < T) {
         const R th = wrap_pi(carry + inc);
         s_ct[i + 1] = th;  // angle for now; replaced by its cosine below
@@ -300,18 +229,18 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
   }
   __syncthreads();
 
-  // sin/cos of every pre-step heading (index T: final heading) and of the RK4 mid stage
+  // sincos of every pre-step heading (index T: final heading) and of the RK4 mid stage
   // theta + dt (0.5 w) shared by k2 and k3 (integrator.hpp:179-180)
-  R* const s_cm = s_E;
-  R* const s_sm = s_E + up4(T);
+  R* const s_cm = s_g0;  // mid-stage cos/sin, dead before g0/g1 are produced
+  R* const s_sm = s_g1;
   for (int i = tid; i <= T; i += kBlock) {
     const R a = s_ct[i];
     R s, c;
-    sincospi_r(a * inv_pi, &s, &c);
+    sincos_r(a, &s, &c);
     if (i < T) {
       const R mid = a + dt * (R(0.5) * s_w[i]);
       R sm_, cm_;
-      sincospi_r(mid * inv_pi, &sm_, &cm_);
+      sincos_r(mid, &sm_, &cm_);
       s_cm[i] = cm_;
       s_sm[i] = sm_;
     }
@@ -336,7 +265,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
         dy = dt6 * (((k1y + R(2) * k2y) + R(2) * k2y) + k4y);
       }
       R tx, ty;
-      block_scan2(dx, dy, s_sw, tx, ty);
+      block_inclusive_scan2(dx, dy, s_sw, tx, ty);
       if (i < T) {
         const R X = cx + dx, Y = cy + dy;
         if (traj != nullptr) {
@@ -363,52 +292,46 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
   }
   __syncthreads();
 
-  // ---- one sin/cos pair per axis per point: angle = pi x / lx (basis.cpp:85 with k = 1)
+  // ---- one sincos per axis per point; cos(k a), sin(k a) follow by recurrence
   for (int q = tid; q < N; q += kBlock) {
     R s, c;
-    sincospi_r(s_px[q] * p.inv_lx, &s, &c);
+    sincos_r(p.pi_lx * s_px[q], &s, &c);
     s_c1x[q] = c;
     s_s1x[q] = s;
-    sincospi_r(s_py[q] * p.inv_ly, &s, &c);
+    sincos_r(p.pi_ly * s_py[q], &s, &c);
     s_c1y[q] = c;
     s_s1y[q] = s;
   }
   __syncthreads();
 
-  // ---- c_k = (1/N) sum_p cos(a_k1 x_p) cos(b_k2 y_p)  (basis.cpp:109-120) on the matrix cores
+  // ---- c_k = (1/N) sum_p cos(a_k1 x_p) cos(b_k2 y_p)  (basis.cpp:109-120)
+  // Tables of one chunk of points go to LDS as [point][k]; 2x2 register tiles of modes are
+  // accumulated by (tile, point-group) threads and reduced over the groups at the end.
   {
-    using M = Mfma<R>;
-    using acc_t = typename M::acc_t;
-    constexpr int NT = (KC > 0) ? ((KC + 15) / 16) : 2;  // 16x16 tiles per dimension
-    const int nt = (K + 15) / 16;
-    acc_t acc[NT][NT];
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-      for (int c = 0; c < NT; ++c) acc[a][c] = acc_t{ R(0), R(0), R(0), R(0) };
+    const int ntx = (K + 1) / 2;
+    const int ntiles = ntx * ntx;
+    const int G = kBlock / ntiles;
+    const int tile = tid % ntiles;
+    const int grp = tid / ntiles;
+    const bool active = grp < G;
+    const int i2 = 2 * (tile % ntx);  // x modes i2, i2+1
+    const int j2 = 2 * (tile / ntx);  // y modes j2, j2+1
+    const bool i_pair = (i2 + 1) < K;
+    const bool j_pair = (j2 + 1) < K;
+    R a00 = R(0), a10 = R(0), a01 = R(0), a11 = R(0);
 
-    R* const tabx = s_E + wave * wave_tab_elems(K);
-    R* const taby = tabx + kSub * KS;
-    const int sub = lane >> 4;  // which 16-point pass stages this lane's point
-    const int pl = lane & 15;
-
-    for (int c0 = 0; c0 < N; c0 += kBlock) {
-      const int q = c0 + wave * kWave + lane;
-      int nvalid = N - (c0 + wave * kWave);
-      nvalid = nvalid < 0 ? 0 : (nvalid > kWave ? kWave : nvalid);
-      const bool have = q < N;
-      const R c1 = have ? s_c1x[q] : R(0), s1 = have ? s_s1x[q] : R(0);
-      const R d1 = have ? s_c1y[q] : R(0), e1 = have ? s_s1y[q] : R(0);
-
-      constexpr int KA = KC > 0 ? KC : 1;
-      R cxr[KA], cyr[KA];
-      if (KC > 0) {
-        // cos(k a) for k < K by the angle-addition recurrence; zero rows for padding points
-        R ck = have ? R(1) : R(0), sk = R(0), dk = have ? R(1) : R(0), ek = R(0);
-#pragma unroll
-        for (int k = 0; k < KA; ++k) {
-          cxr[k] = ck;
-          cyr[k] = dk;
+    for (int c0 = 0; c0 < N; c0 += CH) {
+      const int npts = (N - c0) < CH ? (N - c0) : CH;
+      for (int pl = tid; pl < npts; pl += kBlock) {
+        const int q = c0 + pl;
+        const R c1 = s_c1x[q], s1 = s_s1x[q];
+        const R d1 = s_c1y[q], e1 = s_s1y[q];
+        R ck = R(1), sk = R(0), dk = R(1), ek = R(0);
+        R* const tx = s_tabx + pl * K;
+        R* const ty = s_taby + pl * K;
+        for (int k = 0; k < K; ++k) {
+          tx[k] = ck;
+          ty[k] = dk;
           const R cn = ck * c1 - sk * s1;
           sk = sk * c1 + ck * s1;
           ck = cn;
@@ -417,76 +340,40 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
           dk = dn;
         }
       }
-
-      for (int s = 0; s < kWave / kSub; ++s) {
-        if (s * kSub >= nvalid) break;  // wave-uniform
-        if (sub == s) {
-          R* const tx = tabx + pl * KS;
-          R* const ty = taby + pl * KS;
-          if (KC > 0) {
-#pragma unroll
-            for (int k = 0; k < KA; ++k) {
-              tx[k] = cxr[k];
-              ty[k] = cyr[k];
-            }
-          } else {
-            R ck = have ? R(1) : R(0), sk = R(0), dk = have ? R(1) : R(0), ek = R(0);
-            for (int k = 0; k < K; ++k) {
-              tx[k] = ck;
-              ty[k] = dk;
-              const R cn = ck * c1 - sk * s1;
-              sk = sk * c1 + ck * s1;
-              ck = cn;
-              const R dn = dk * d1 - ek * e1;
-              ek = ek * d1 + dk * e1;
-              dk = dn;
-            }
-          }
+      __syncthreads();
+      if (active) {
+        for (int pl = grp; pl < npts; pl += G) {
+          const R* const tx = s_tabx + pl * K;
+          const R* const ty = s_taby + pl * K;
+          const R x0_ = tx[i2];
+          const R x1_ = i_pair ? tx[i2 + 1] : R(0);
+          const R y0_ = ty[j2];
+          const R y1_ = j_pair ? ty[j2 + 1] : R(0);
+          a00 += x0_ * y0_;
+          a10 += x1_ * y0_;
+          a01 += x0_ * y1_;
+          a11 += x1_ * y1_;
         }
-        wave_lds_fence();
-#pragma unroll
-        for (int g = 0; g < kSub / 4; ++g) {
-          if (s * kSub + 4 * g < nvalid) {  // wave-uniform
-            const int off = (4 * g + sub) * KS + pl;  // = (4g + lane/16) * KS + lane%16
-            R av[NT], bv[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-              av[t] = (t < nt) ? tabx[off + 16 * t] : R(0);
-              bv[t] = (t < nt) ? taby[off + 16 * t] : R(0);
-            }
-#pragma unroll
-            for (int a = 0; a < NT; ++a)
-#pragma unroll
-              for (int c = 0; c < NT; ++c)
-                if (a < nt && c < nt) acc[a][c] = M::run(av[a], bv[c], acc[a][c]);
-          }
-        }
-        wave_lds_fence();
       }
+      __syncthreads();
     }
 
-    // cross-wavefront reduction: red[wave][mode], mode = k2*K + k1 (basis.cpp:58-66)
-    __syncthreads();  // every wavefront is done with its tile before the region is reused
-    R* const s_red = s_E;
-    {
-      const int j = lane & 15;
-#pragma unroll
-      for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int c = 0; c < NT; ++c)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int k1 = 16 * a + M::row(lane, r);
-            const int k2 = 16 * c + j;
-            if (a < nt && c < nt && k1 < K && k2 < K) s_red[wave * K2 + k2 * K + k1] = acc[a][c][r];
-          }
+    // reduce over point groups: s_red[grp][mode], mode = k2*K + k1 (basis.cpp:58-66)
+    R* const s_red = s_tabx;
+    if (active) {
+      R* const r = s_red + grp * K2;
+      r[j2 * K + i2] = a00;
+      if (i_pair) r[j2 * K + i2 + 1] = a10;
+      if (j_pair) {
+        r[(j2 + 1) * K + i2] = a01;
+        if (i_pair) r[(j2 + 1) * K + i2 + 1] = a11;
+      }
     }
     __syncthreads();
     const R invN = R(1) / static_cast<R>(N);
     for (int m = tid; m < K2; m += kBlock) {
       R s = R(0);
-#pragma unroll
-      for (int w = 0; w < kWaves; ++w) s += s_red[w * K2 + m];
+      for (int g = 0; g < G; ++g) s += s_red[g * K2 + m];
       const R c = invN * s;
       if (p.ck != nullptr) p.ck[static_cast<size_t>(b) * K2 + m] = c;
       // fourier_diff = lamdak % (ck - phik)  (ergodic_control.hpp:422)
@@ -578,14 +465,9 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
       o[1] = b1;
       o[2] = R(0);
     }
-    s_g0[i] = ex + b0;
+    s_g0[i] = ex + b0;  // overwrites the mid-stage cos/sin of the same index (dead)
     s_g1[i] = ey + b1;
   }
-
-  // co-state rows live in the union region (the MFMA tiles are dead: barrier after s_D)
-  R* const s_r0 = s_E;
-  R* const s_r1 = s_E + up4(T + 1);
-  R* const s_r2 = s_E + 2 * up4(T + 1);
   if (tid == 0) {
     s_r0[T] = R(0);  // rhoT_ = 0 (ergodic_control.hpp:203)
     s_r1[T] = R(0);
@@ -604,7 +486,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
         h1 = dt * s_g1[i];
       }
       R t0, t1;
-      block_scan2(h0, h1, s_sw, t0, t1);
+      block_inclusive_scan2(h0, h1, s_sw, t0, t1);
       if (i >= 0) {
         s_r0[i] = c0 + h0;
         s_r1[i] = c1 + h1;
@@ -638,7 +520,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
         qv = dt * (sE + R(0.5) * dt * sG);
       }
       R tot;
-      const R inc = block_scan(qv, s_sw, tot);
+      const R inc = block_inclusive_scan(qv, s_sw, &tot);
       if (i >= 0) s_r2[i] = c2 + inc;
       c2 += tot;
     }
@@ -719,9 +601,9 @@ hipError_t launch_model(const ControlParams<R>& p, unsigned B, int Nmax, bool ro
 }  // namespace
 
 template <typename R>
-size_t control_lds_bytes(int T, int K, int n_mem_max, int /*chunk*/)
+size_t control_lds_bytes(int T, int K, int n_mem_max, int chunk)
 {
-  return static_cast<size_t>(lds_layout(T, T + n_mem_max, K).total) * sizeof(R);
+  return static_cast<size_t>(lds_layout(T, T + n_mem_max, K, chunk).total) * sizeof(R);
 }
 
 template <typename R>
@@ -741,4 +623,5 @@ template hipError_t launch_control<double>(const ControlParams<double>&, unsigne
                                            hipStream_t);
 template hipError_t launch_control<float>(const ControlParams<float>&, unsigned, int, int, bool,
                                           hipStream_t);
+}  // namespace v1
 }  // namespace eea

@@ -77,6 +77,7 @@ struct eea_engine
   bool f32 = false;
   size_t rs = 8;  // sizeof(real)
   int chunk = 128;
+  bool impl_v1 = false;  // EEA_CONTROL_IMPL=v1 selects the first kernel version (A/B baseline)
 
   // Basis state (basis_.lx_, ly_ start at 0: ergodic_control.hpp:208)
   double lx = 0.0, ly = 0.0, map_x = 0.0, map_y = 0.0;
@@ -266,6 +267,8 @@ void fill_params(const eea_engine* e, eea::ControlParams<R>& p)
   p.expl_weight = static_cast<R>(e->cfg.expl_weight);
   p.pi_lx = static_cast<R>(eea::kPi / e->lx);
   p.pi_ly = static_cast<R>(eea::kPi / e->ly);
+  p.inv_lx = static_cast<R>(1.0 / e->lx);
+  p.inv_ly = static_cast<R>(1.0 / e->ly);
   for (int i = 0; i < 9; ++i) p.Rinv[i] = static_cast<R>(e->cfg.Rinv[i]);
   for (int i = 0; i < 3; ++i) {
     p.umin[i] = static_cast<R>(e->cfg.umin[i]);
@@ -294,11 +297,16 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
   p.rhot = static_cast<R*>(io->d_rhot);
   p.status = io->d_status;
   const int n_mem_max = rollout_only ? 0 : static_cast<int>(p.mem_stride);
-  const size_t lds = eea::control_lds_bytes<R>(p.T, p.K, n_mem_max, p.chunk);
+  const size_t lds = e->impl_v1 ? eea::v1::control_lds_bytes<R>(p.T, p.K, n_mem_max, p.chunk)
+                                : eea::control_lds_bytes<R>(p.T, p.K, n_mem_max, p.chunk);
   if (lds > 160 * 1024) {
     return fail(EEA_ERR_UNSUPPORTED, "horizon/memory/basis too large for one workgroup's 160 KiB LDS");
   }
-  EEA_HIP(eea::launch_control<R>(p, B, e->cfg.model, n_mem_max, rollout_only, s));
+  if (e->impl_v1) {
+    EEA_HIP(eea::v1::launch_control<R>(p, B, e->cfg.model, n_mem_max, rollout_only, s));
+  } else {
+    EEA_HIP(eea::launch_control<R>(p, B, e->cfg.model, n_mem_max, rollout_only, s));
+  }
   return EEA_OK;
 }
 
@@ -354,6 +362,7 @@ eea_status eea_create(const eea_config* cfg, eea_engine** out)
     const int v = std::atoi(c);
     if (v >= 64 && v <= 1024 && (v % 64) == 0) e->chunk = v;
   }
+  if (const char* c = std::getenv("EEA_CONTROL_IMPL")) e->impl_v1 = std::strcmp(c, "v1") == 0;
   eea_status st = e->f32 ? upload_lamdak<float>(e) : upload_lamdak<double>(e);
   if (st != EEA_OK) {
     eea_destroy(e);
