@@ -11,7 +11,8 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "lib", "libergodic_amd.so")
+# EEA_LIB_VARIANT selects an A/B build of the same sources (csrc/Makefile VARIANT=...)
+LIB_PATH = os.path.join(_HERE, "lib", "libergodic_amd%s.so" % os.environ.get("EEA_LIB_VARIANT", ""))
 HEADER_PATH = os.path.join(ROOT, "include", "ergodic_amd.h")
 
 MODEL_OMNI, MODEL_SIMPLE_CART = 0, 1
@@ -100,6 +101,7 @@ def lib():
         L.eea_target_grid_size.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
         L.eea_get_target_grid.argtypes = [C.c_void_p, C.c_void_p]
         L.eea_control_batch.argtypes = [C.c_void_p, C.c_uint, C.POINTER(BatchIO), C.c_void_p]
+        L.eea_debug_phase_timing.argtypes = [C.c_void_p, C.c_uint, C.POINTER(BatchIO), C.c_void_p, C.c_void_p]
         L.eea_rollout_batch.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]
         L.eea_control.argtypes = [C.c_void_p] + [C.c_double] * 4 + [C.c_void_p, C.c_void_p, C.c_uint,
@@ -216,6 +218,11 @@ class Engine:
         io.d_traj, io.d_ck, io.d_edx, io.d_bdx = _ptr(traj), _ptr(ck), _ptr(edx), _ptr(bdx)
         io.d_rhot, io.d_status = _ptr(rhot), _ptr(status)
         check(lib().eea_control_batch(self.h, B, C.byref(io), C.c_void_p(stream or 0)))
+
+    def debug_phase_timing(self, B, pose, ut, u0, stamps, ck=None, stream=None):
+        io = BatchIO()
+        io.d_pose, io.d_ut, io.d_u0, io.d_ck = _ptr(pose), _ptr(ut), _ptr(u0), _ptr(ck)
+        check(lib().eea_debug_phase_timing(self.h, B, C.byref(io), C.c_void_p(stream or 0), _ptr(stamps)))
 
     def rollout_batch(self, B, pose, ut, traj, status=None, stream=None):
         check(lib().eea_rollout_batch(self.h, B, _ptr(pose), _ptr(ut), _ptr(traj), _ptr(status),

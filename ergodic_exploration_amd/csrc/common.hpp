@@ -45,6 +45,7 @@ struct ControlParams
   R* bdx;
   R* rhot;
   int* status;
+  long long* dbg;     // phase-timing stamps [B][4 waves][16] (diagnostic build only), else null
 };
 
 template <typename R>
@@ -55,6 +56,10 @@ size_t control_lds_bytes(int T, int K, int n_mem_max, int chunk);
 template <typename R>
 hipError_t launch_control(const ControlParams<R>& p, unsigned B, int model, int n_mem_max,
                           bool rollout_only, hipStream_t stream);
+
+// diagnostic instantiation (K = 10, fp64) that records per-phase shader-clock stamps into p.dbg
+hipError_t launch_control_timing(const ControlParams<double>& p, unsigned B, int model, int n_mem_max,
+                                 hipStream_t stream);
 
 // first version of the control kernel (control_kernel_v1.hip), kept as the A/B baseline
 namespace v1

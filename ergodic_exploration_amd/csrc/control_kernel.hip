@@ -1,704 +1,10 @@
-// Fused receding-horizon ergodic control kernel for gfx950 (MI355X), version 2.
-//
-// One workgroup (256 threads = 4 wavefronts) per agent performs one complete
-// `ErgodicControl<ModelT>::control` call (reference ergodic_control.hpp:224-311, minus
-// configTarget) for ModelT in {Omni, SimpleCart}:
-//
-//   shift controls (:233-234) -> forward RK4 rollout (integrator.hpp:135-152,176-184)
-//   -> c_k (basis.cpp:109-120) -> ergodic-metric gradient (:418-436) + barrier (:453-474)
-//   -> backward co-state RK4 (integrator.hpp:154-174,186-194; rhodot :65-69)
-//   -> control update + clamp (:438-451).
-//
-// It is not a translation of the reference's loops.  Three identities of the reference's
-// own formulas make the horizon parallel (derivations in DESIGN.md section 2):
-//   1. The basis is separable, f_k(x,y) = cos(a_k1 x) cos(b_k2 y) (basis.cpp:85), and
-//      cos(k a), sin(k a) follow from one sincos by the angle-addition recurrence.
-//   2. For Omni/SimpleCart theta' = w does not depend on the state, so RK4 collapses to
-//      Simpson's rule in closed form and the rollout is two prefix sums over the horizon.
-//   3. fdx has only A(0,2), A(1,2) non-zero and edx(2) = bdx(2) = 0, so the co-state pass is
-//      two chained suffix sums (RK4 == trapezoid there).
-//
-// CDNA4 mapping (what changed against control_kernel_v1.hip):
-//   * horizon scans: DPP row shifts / row broadcasts inside each 64-lane wavefront (no LDS
-//     traffic), one LDS hop between the 4 wavefronts;
-//   * c_k = (1/N) Cx Cy^T is the one GEMM-shaped piece: each wavefront stages the cos tables of
-//     16 of its points in a private LDS tile laid out [point][k] so that the MFMA operand of
-//     lane l is the contiguous element (4g + l/16) * KS + l%16, and accumulates with
-//     v_mfma_f64_16x16x4_f64 (v_mfma_f32_16x16x4_f32 for fp32); no workgroup barrier inside;
-//   * sin(pi t) / cos(pi t) evaluation (exact argument reduction) for headings and basis angles;
-//   * LDS regions with disjoint lifetimes are aliased: 32 KB per agent at K=10, T=200 (fp64),
-//     4 workgroups per CU.
-#include "common.hpp"
+// Instantiations and dispatch of the fused control kernel (control_kernel_impl.hpp).
+#include "control_kernel_impl.hpp"
 
 namespace eea
 {
 namespace
 {
-constexpr int kWaves = kBlock / kWave;
-constexpr int kSub = 16;     // points staged per wavefront per MFMA pass
-constexpr int kTabPad = 32;  // operand reads of the last point run past its row (garbage modes)
-
-__host__ __device__ inline int up4(int n) { return (n + 3) & ~3; }
-__host__ __device__ inline int table_stride(int K) { return (K + 1) & ~1; }  // even: 16-byte rows
-__host__ __device__ inline int wave_tab_elems(int K) { return up4(2 * kSub * table_stride(K) + kTabPad); }
-
-// LDS carve (element offsets; every segment a multiple of 4 elements => 16-byte aligned)
-struct LdsLayout
-{
-  int vx, vy, w;           // shifted controls, SoA [T]
-  int ct, st;              // cos/sin of the pre-step heading, [T+1] (index T = final heading)
-  int px, py;              // points in the Fourier frame, [Nmax] (memory first, rollout last)
-  int c1x, s1x, c1y, s1y;  // sin/cos(pi x / lx), sin/cos(pi y / ly) per point, [Nmax]
-  int g0, g1;              // edx + bdx rows 0,1, [T]
-  int D;                   // lambda_k * (c_k - phi_k), [K^2]
-  int sw;                  // scan scratch + flags
-  int E;                   // lifetime-disjoint union:
-                           //   forward pass : mid-stage cos/sin [T] x 2
-                           //   c_k          : per-wavefront MFMA tiles, then the cross-wave reduction
-                           //   backward pass: co-state rows [T+1] x 3
-  int total;
-};
-
-__host__ __device__ inline LdsLayout lds_layout(int T, int Nmax, int K)
-{
-  LdsLayout L;
-  int o = 0;
-  L.vx = o; o += up4(T);
-  L.vy = o; o += up4(T);
-  L.w = o; o += up4(T);
-  L.ct = o; o += up4(T + 1);
-  L.st = o; o += up4(T + 1);
-  L.px = o; o += up4(Nmax);
-  L.py = o; o += up4(Nmax);
-  L.c1x = o; o += up4(Nmax);
-  L.s1x = o; o += up4(Nmax);
-  L.c1y = o; o += up4(Nmax);
-  L.s1y = o; o += up4(Nmax);
-  L.g0 = o; o += up4(T);
-  L.g1 = o; o += up4(T);
-  L.D = o; o += up4(K * K);
-  L.sw = o; o += 16;
-  L.E = o;
-  int e = 2 * up4(T);
-  const int tab = kWaves * wave_tab_elems(K);
-  const int red = kWaves * K * K;
-  const int rho = 3 * up4(T + 1);
-  e = e > tab ? e : tab;
-  e = e > red ? e : red;
-  e = e > rho ? e : rho;
-  o += up4(e);
-  L.total = o;
-  return L;
-}
-
-// ---- workgroup scans on top of the DPP wavefront scan -------------------------------------
-template <typename R>
-__device__ __forceinline__ R block_scan(R v, R* s_w, R& total)
-{
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x / kWave;
-  const R s = wave_inclusive_scan_dpp(v);
-  if (lane == kWave - 1) s_w[wave] = s;
-  __syncthreads();
-  R off = R(0), tot = R(0);
-#pragma unroll
-  for (int w = 0; w < kWaves; ++w) {
-    const R ws = s_w[w];
-    if (w < wave) off += ws;
-    tot += ws;
-  }
-  __syncthreads();
-  total = tot;
-  return s + off;
-}
-
-template <typename R>
-__device__ __forceinline__ void block_scan2(R& a, R& b, R* s_w, R& tot_a, R& tot_b)
-{
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x / kWave;
-  const R sa = wave_inclusive_scan_dpp(a);
-  const R sb = wave_inclusive_scan_dpp(b);
-  if (lane == kWave - 1) {
-    s_w[wave] = sa;
-    s_w[kWaves + wave] = sb;
-  }
-  __syncthreads();
-  R oa = R(0), ob = R(0), ta = R(0), tb = R(0);
-#pragma unroll
-  for (int w = 0; w < kWaves; ++w) {
-    const R wa = s_w[w], wb = s_w[kWaves + w];
-    if (w < wave) {
-      oa += wa;
-      ob += wb;
-    }
-    ta += wa;
-    tb += wb;
-  }
-  __syncthreads();
-  a = sa + oa;
-  b = sb + ob;
-  tot_a = ta;
-  tot_b = tb;
-}
-
-// ---- matrix cores: D = A(16x4) B(4x16) + C, one operand element per lane -----------------------
-// A[i][k]: lane = 16 k + i;  B[k][j]: lane = 16 k + j.  C/D: col = lane % 16 and
-// row = lane/16 + 4 r (f64) or 4 (lane/16) + r (f32), r = accumulator register.
-template <typename R>
-struct Mfma;
-template <>
-struct Mfma<double>
-{
-  using acc_t = double __attribute__((ext_vector_type(4)));
-  static __device__ __forceinline__ acc_t run(double a, double b, acc_t c)
-  {
-    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-  }
-  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
-};
-template <>
-struct Mfma<float>
-{
-  using acc_t = float __attribute__((ext_vector_type(4)));
-  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c)
-  {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-  }
-  static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
-};
-
-// orders a wavefront's own LDS writes before its own LDS reads (same-wave DS ops execute in
-// order; this only stops the compiler from moving them across)
-__device__ __forceinline__ void wave_lds_fence()
-{
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-
-// model right-hand side x/y components at heading (c, s) (omni.hpp:177-181, cart.hpp:172)
-template <typename R, int MODEL>
-__device__ __forceinline__ void model_xy(R vx, R vy, R c, R s, R& fx, R& fy)
-{
-  if (MODEL == kModelOmni) {
-    fx = vx * c - vy * s;
-    fy = vx * s + vy * c;
-  } else {
-    fx = vx * c;
-    fy = vx * s;
-  }
-}
-
-// Register budget: waves per SIMD the kernel is compiled for (VGPR + AGPR <= 512 / waves).
-// K <= 12 keeps the basis rows of the gradient in 128 registers (4 workgroups per CU, matching
-// the LDS footprint); larger K needs the wider budget.
-constexpr int min_waves_per_simd(int KC) { return (KC > 20) ? 2 : ((KC > 12) ? 3 : 4); }
-
-template <typename R, int MODEL, int KC>
-__global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel(
-    const ControlParams<R> p, const int Nmax, const int rollout_only)
-{
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  R* const sm = reinterpret_cast<R*>(smem_raw);
-
-  const int b = blockIdx.x;
-  const int tid = threadIdx.x;
-  const int lane = tid & (kWave - 1);
-  const int wave = tid / kWave;
-  const int T = p.T;
-  const int K = (KC > 0) ? KC : p.K;
-  const int K2 = K * K;
-  const int KS = table_stride(K);
-  const LdsLayout L = lds_layout(T, Nmax, K);
-
-  R* const s_vx = sm + L.vx;
-  R* const s_vy = sm + L.vy;
-  R* const s_w = sm + L.w;
-  R* const s_ct = sm + L.ct;
-  R* const s_st = sm + L.st;
-  R* const s_px = sm + L.px;
-  R* const s_py = sm + L.py;
-  R* const s_c1x = sm + L.c1x;
-  R* const s_s1x = sm + L.s1x;
-  R* const s_c1y = sm + L.c1y;
-  R* const s_s1y = sm + L.s1y;
-  R* const s_g0 = sm + L.g0;
-  R* const s_g1 = sm + L.g1;
-  R* const s_D = sm + L.D;
-  R* const s_sw = sm + L.sw;
-  R* const s_E = sm + L.E;
-  int& s_bad = *reinterpret_cast<int*>(s_sw + 12);
-
-  int nmem = 0;
-  if (p.mem_cols != nullptr && !rollout_only) {
-    nmem = (p.n_mem != nullptr) ? p.n_mem[b] : static_cast<int>(p.mem_stride);
-    nmem = nmem < 0 ? 0 : (nmem > static_cast<int>(p.mem_stride) ? static_cast<int>(p.mem_stride) : nmem);
-  }
-  const int N = T + nmem;
-
-  const R* const pose = p.pose + 3 * static_cast<size_t>(b);
-  R* const ut = p.ut + 3 * static_cast<size_t>(T) * b;
-  const R x0 = pose[0], y0 = pose[1], th0 = pose[2];
-
-  if (tid == 0) s_bad = 0;
-  __syncthreads();
-
-  // ---- controls: shift left by one column, last column zero (ergodic_control.hpp:233-234)
-  {
-    bool bad = false;
-    for (int i = tid; i < T; i += kBlock) {
-      const int src = rollout_only ? i : i + 1;
-      R vx = R(0), vy = R(0), w = R(0);
-      if (src < T) {
-        vx = ut[3 * src + 0];
-        vy = ut[3 * src + 1];
-        w = ut[3 * src + 2];
-      }
-      s_vx[i] = vx;
-      s_vy[i] = vy;
-      s_w[i] = w;
-      // SimpleCart::operator() rejects a lateral velocity (cart.hpp:167-170)
-      if (MODEL == kModelSimpleCart && !(fabs(vy) < R(1.0e-12))) bad = true;
-    }
-    if (bad) s_bad = 1;
-  }
-  __syncthreads();
-  if (s_bad) {
-    // the reference throws out of rk4_.solve; nothing else of this agent is touched
-    if (tid == 0 && p.status != nullptr) p.status[b] = 2;  // EEA_ERR_INVALID_TWIST
-    return;
-  }
-  if (tid == 0 && p.status != nullptr) p.status[b] = 0;
-
-  const R dt = p.dt;
-  const R dt6 = dt / R(6);
-  const R inv_pi = static_cast<R>(1.0 / kPi);
-  R* const traj = (p.traj != nullptr) ? p.traj + 3 * static_cast<size_t>(T) * b : nullptr;
-
-  // ---- forward pass, heading: theta_i = wrap(theta_{i-1} + dt/6 (w + 2w + 2w + w))
-  //      (integrator.hpp:146-148,183) == wrap(theta_0 + prefix sum) up to rounding
-  {
-    R carry = th0;
-    for (int base = 0; base < T; base += kBlock) {
-      const int i = base + tid;
-      R d = R(0);
-      if (i < T) {
-        const R w = s_w[i];
-        d = dt6 * (((w + R(2) * w) + R(2) * w) + w);
-      }
-      R tot;
-      const R inc = block_scan(d, s_sw, tot);
-      if (i < T) {
-        const R th = wrap_pi(carry + inc);
-        s_ct[i + 1] = th;  // angle for now; replaced by its cosine below
-        if (traj != nullptr) traj[3 * i + 2] = th;
-      }
-      carry += tot;
-    }
-    if (tid == 0) s_ct[0] = th0;
-  }
-  __syncthreads();
-
-  // sin/cos of every pre-step heading (index T: final heading) and of the RK4 mid stage
-  // theta + dt (0.5 w) shared by k2 and k3 (integrator.hpp:179-180)
-  R* const s_cm = s_E;
-  R* const s_sm = s_E + up4(T);
-  for (int i = tid; i <= T; i += kBlock) {
-    const R a = s_ct[i];
-    R s, c;
-    sincospi_r(a * inv_pi, &s, &c);
-    if (i < T) {
-      const R mid = a + dt * (R(0.5) * s_w[i]);
-      R sm_, cm_;
-      sincospi_r(mid * inv_pi, &sm_, &cm_);
-      s_cm[i] = cm_;
-      s_sm[i] = sm_;
-    }
-    s_ct[i] = c;
-    s_st[i] = s;
-  }
-  __syncthreads();
-
-  // ---- forward pass, position: x_i = x_{i-1} + dt/6 (k1 + 2 k2 + 2 k3 + k4), k2 == k3
-  {
-    R cx = x0, cy = y0;
-    for (int base = 0; base < T; base += kBlock) {
-      const int i = base + tid;
-      R dx = R(0), dy = R(0);
-      if (i < T) {
-        const R vx = s_vx[i], vy = s_vy[i];
-        R k1x, k1y, k2x, k2y, k4x, k4y;
-        model_xy<R, MODEL>(vx, vy, s_ct[i], s_st[i], k1x, k1y);
-        model_xy<R, MODEL>(vx, vy, s_cm[i], s_sm[i], k2x, k2y);
-        model_xy<R, MODEL>(vx, vy, s_ct[i + 1], s_st[i + 1], k4x, k4y);
-        dx = dt6 * (((k1x + R(2) * k2x) + R(2) * k2x) + k4x);
-        dy = dt6 * (((k1y + R(2) * k2y) + R(2) * k2y) + k4y);
-      }
-      R tx, ty;
-      block_scan2(dx, dy, s_sw, tx, ty);
-      if (i < T) {
-        const R X = cx + dx, Y = cy + dy;
-        if (traj != nullptr) {
-          traj[3 * i + 0] = X;
-          traj[3 * i + 1] = Y;
-        }
-        // map frame -> Fourier frame (ergodic_control.hpp:243-244)
-        s_px[nmem + i] = X - p.map_x;
-        s_py[nmem + i] = Y - p.map_y;
-      }
-      cx += tx;
-      cy += ty;
-    }
-  }
-  if (rollout_only) return;
-
-  // sampled past states are prepended (buffer.cpp:78-108) and shifted like the rollout
-  if (nmem > 0) {
-    const R* const mem = p.mem_cols + 3 * static_cast<size_t>(p.mem_stride) * b;
-    for (int j = tid; j < nmem; j += kBlock) {
-      s_px[j] = mem[3 * j + 0] - p.map_x;
-      s_py[j] = mem[3 * j + 1] - p.map_y;
-    }
-  }
-  __syncthreads();
-
-  // ---- one sin/cos pair per axis per point: angle = pi x / lx (basis.cpp:85 with k = 1)
-  for (int q = tid; q < N; q += kBlock) {
-    R s, c;
-    sincospi_r(s_px[q] * p.inv_lx, &s, &c);
-    s_c1x[q] = c;
-    s_s1x[q] = s;
-    sincospi_r(s_py[q] * p.inv_ly, &s, &c);
-    s_c1y[q] = c;
-    s_s1y[q] = s;
-  }
-  __syncthreads();
-
-  // ---- c_k = (1/N) sum_p cos(a_k1 x_p) cos(b_k2 y_p)  (basis.cpp:109-120) on the matrix cores
-  {
-    using M = Mfma<R>;
-    using acc_t = typename M::acc_t;
-    constexpr int NT = (KC > 0) ? ((KC + 15) / 16) : 2;  // 16x16 tiles per dimension
-    const int nt = (K + 15) / 16;
-    acc_t acc[NT][NT];
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-      for (int c = 0; c < NT; ++c) acc[a][c] = acc_t{ R(0), R(0), R(0), R(0) };
-
-    R* const tabx = s_E + wave * wave_tab_elems(K);
-    R* const taby = tabx + kSub * KS;
-    const int sub = lane >> 4;  // which 16-point pass stages this lane's point
-    const int pl = lane & 15;
-
-    for (int c0 = 0; c0 < N; c0 += kBlock) {
-      const int q = c0 + wave * kWave + lane;
-      int nvalid = N - (c0 + wave * kWave);
-      nvalid = nvalid < 0 ? 0 : (nvalid > kWave ? kWave : nvalid);
-      const bool have = q < N;
-      const R c1 = have ? s_c1x[q] : R(0), s1 = have ? s_s1x[q] : R(0);
-      const R d1 = have ? s_c1y[q] : R(0), e1 = have ? s_s1y[q] : R(0);
-
-      constexpr int KA = KC > 0 ? KC : 1;
-      R cxr[KA], cyr[KA];
-      if (KC > 0) {
-        // cos(k a) for k < K by the angle-addition recurrence; zero rows for padding points
-        R ck = have ? R(1) : R(0), sk = R(0), dk = have ? R(1) : R(0), ek = R(0);
-#pragma unroll
-        for (int k = 0; k < KA; ++k) {
-          cxr[k] = ck;
-          cyr[k] = dk;
-          const R cn = ck * c1 - sk * s1;
-          sk = sk * c1 + ck * s1;
-          ck = cn;
-          const R dn = dk * d1 - ek * e1;
-          ek = ek * d1 + dk * e1;
-          dk = dn;
-        }
-      }
-
-      for (int s = 0; s < kWave / kSub; ++s) {
-        if (s * kSub >= nvalid) break;  // wave-uniform
-        if (sub == s) {
-          R* const tx = tabx + pl * KS;
-          R* const ty = taby + pl * KS;
-          if (KC > 0) {
-#pragma unroll
-            for (int k = 0; k < KA; ++k) {
-              tx[k] = cxr[k];
-              ty[k] = cyr[k];
-            }
-          } else {
-            R ck = have ? R(1) : R(0), sk = R(0), dk = have ? R(1) : R(0), ek = R(0);
-            for (int k = 0; k < K; ++k) {
-              tx[k] = ck;
-              ty[k] = dk;
-              const R cn = ck * c1 - sk * s1;
-              sk = sk * c1 + ck * s1;
-              ck = cn;
-              const R dn = dk * d1 - ek * e1;
-              ek = ek * d1 + dk * e1;
-              dk = dn;
-            }
-          }
-        }
-        wave_lds_fence();
-#pragma unroll
-        for (int g = 0; g < kSub / 4; ++g) {
-          if (s * kSub + 4 * g < nvalid) {  // wave-uniform
-            const int off = (4 * g + sub) * KS + pl;  // = (4g + lane/16) * KS + lane%16
-            R av[NT], bv[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-              av[t] = (t < nt) ? tabx[off + 16 * t] : R(0);
-              bv[t] = (t < nt) ? taby[off + 16 * t] : R(0);
-            }
-#pragma unroll
-            for (int a = 0; a < NT; ++a)
-#pragma unroll
-              for (int c = 0; c < NT; ++c)
-                if (a < nt && c < nt) acc[a][c] = M::run(av[a], bv[c], acc[a][c]);
-          }
-        }
-        wave_lds_fence();
-      }
-    }
-
-    // cross-wavefront reduction: red[wave][mode], mode = k2*K + k1 (basis.cpp:58-66)
-    __syncthreads();  // every wavefront is done with its tile before the region is reused
-    R* const s_red = s_E;
-    {
-      const int j = lane & 15;
-#pragma unroll
-      for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int c = 0; c < NT; ++c)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int k1 = 16 * a + M::row(lane, r);
-            const int k2 = 16 * c + j;
-            if (a < nt && c < nt && k1 < K && k2 < K) s_red[wave * K2 + k2 * K + k1] = acc[a][c][r];
-          }
-    }
-    __syncthreads();
-    const R invN = R(1) / static_cast<R>(N);
-    for (int m = tid; m < K2; m += kBlock) {
-      R s = R(0);
-#pragma unroll
-      for (int w = 0; w < kWaves; ++w) s += s_red[w * K2 + m];
-      const R c = invN * s;
-      if (p.ck != nullptr) p.ck[static_cast<size_t>(b) * K2 + m] = c;
-      // fourier_diff = lamdak % (ck - phik)  (ergodic_control.hpp:422)
-      s_D[m] = p.lamdak[m] * (c - p.phik[m]);
-    }
-    __syncthreads();
-  }
-
-  // ---- ergodic-metric gradient (:418-436, basis.cpp:91-107) and barrier (:453-474)
-  //   edx_x = w sum_k2 cos(b y) [ sum_k1 D(k1,k2) (-a_k1 sin(a_k1 x)) ]
-  //   edx_y = w sum_k2 (-b_k2 sin(b y)) [ sum_k1 D(k1,k2) cos(a_k1 x) ]
-  for (int i = tid; i < T; i += kBlock) {
-    const int q = nmem + i;
-    const R c1 = s_c1x[q], s1 = s_s1x[q];
-    const R d1 = s_c1y[q], e1 = s_s1y[q];
-    R Ex = R(0), Ey = R(0);
-    if (KC > 0) {
-      constexpr int KA = KC > 0 ? KC : 1;
-      R cxa[KA], sxa[KA];
-      {
-        R ck = R(1), sk = R(0);
-#pragma unroll
-        for (int k = 0; k < KA; ++k) {
-          cxa[k] = ck;
-          sxa[k] = -(static_cast<R>(k) * p.pi_lx) * sk;
-          const R cn = ck * c1 - sk * s1;
-          sk = sk * c1 + ck * s1;
-          ck = cn;
-        }
-      }
-      R dk = R(1), ek = R(0);
-      for (int k2 = 0; k2 < KA; ++k2) {
-        const R* const Drow = s_D + k2 * KA;
-        R t1 = R(0), t2 = R(0);
-#pragma unroll
-        for (int k1 = 0; k1 < KA; ++k1) {
-          const R d = Drow[k1];
-          t1 += d * sxa[k1];
-          t2 += d * cxa[k1];
-        }
-        Ex += dk * t1;
-        Ey += (-(static_cast<R>(k2) * p.pi_ly) * ek) * t2;
-        const R dn = dk * d1 - ek * e1;
-        ek = ek * d1 + dk * e1;
-        dk = dn;
-      }
-    } else {
-      R dk = R(1), ek = R(0);
-      for (int k2 = 0; k2 < K; ++k2) {
-        const R* const Drow = s_D + k2 * K;
-        R t1 = R(0), t2 = R(0);
-        R ck = R(1), sk = R(0);
-        for (int k1 = 0; k1 < K; ++k1) {
-          const R d = Drow[k1];
-          t1 += d * (-(static_cast<R>(k1) * p.pi_lx) * sk);
-          t2 += d * ck;
-          const R cn = ck * c1 - sk * s1;
-          sk = sk * c1 + ck * s1;
-          ck = cn;
-        }
-        Ex += dk * t1;
-        Ey += (-(static_cast<R>(k2) * p.pi_ly) * ek) * t2;
-        const R dn = dk * d1 - ek * e1;
-        ek = ek * d1 + dk * e1;
-        dk = dn;
-      }
-    }
-    const R ex = Ex * p.expl_weight, ey = Ey * p.expl_weight;
-
-    const R x = s_px[q], y = s_py[q];
-    const R eps = R(0.05), weight = R(25);
-    R b0 = R(0), b1 = R(0);
-    b0 += R(2) * static_cast<R>(x > p.lx - eps) * (x - (p.lx - eps));
-    b1 += R(2) * static_cast<R>(y > p.ly - eps) * (y - (p.ly - eps));
-    b0 += R(2) * static_cast<R>(x < eps) * (x - eps);
-    b1 += R(2) * static_cast<R>(y < eps) * (y - eps);
-    b0 *= weight;
-    b1 *= weight;
-
-    if (p.edx != nullptr) {
-      R* const o = p.edx + 3 * (static_cast<size_t>(T) * b + i);
-      o[0] = ex;
-      o[1] = ey;
-      o[2] = R(0);
-    }
-    if (p.bdx != nullptr) {
-      R* const o = p.bdx + 3 * (static_cast<size_t>(T) * b + i);
-      o[0] = b0;
-      o[1] = b1;
-      o[2] = R(0);
-    }
-    s_g0[i] = ex + b0;
-    s_g1[i] = ey + b1;
-  }
-
-  // co-state rows live in the union region (the MFMA tiles are dead: barrier after s_D)
-  R* const s_r0 = s_E;
-  R* const s_r1 = s_E + up4(T + 1);
-  R* const s_r2 = s_E + 2 * up4(T + 1);
-  if (tid == 0) {
-    s_r0[T] = R(0);  // rhoT_ = 0 (ergodic_control.hpp:203)
-    s_r1[T] = R(0);
-    s_r2[T] = R(0);
-  }
-  __syncthreads();
-
-  // ---- backward pass rows 0,1: rho_i = rho_{i+1} + dt g_i  (suffix sums)
-  {
-    R c0 = R(0), c1 = R(0);
-    for (int base = 0; base < T; base += kBlock) {
-      const int i = T - 1 - (base + tid);
-      R h0 = R(0), h1 = R(0);
-      if (i >= 0) {
-        h0 = dt * s_g0[i];
-        h1 = dt * s_g1[i];
-      }
-      R t0, t1;
-      block_scan2(h0, h1, s_sw, t0, t1);
-      if (i >= 0) {
-        s_r0[i] = c0 + h0;
-        s_r1[i] = c1 + h1;
-      }
-      c0 += t0;
-      c1 += t1;
-    }
-  }
-  __syncthreads();
-
-  // ---- backward pass row 2: rho2_i = rho2_{i+1} + dt (S_i(rho_{i+1}) + dt/2 S_i(g_i)),
-  //      S_i(v) = A(0,2) v0 + A(1,2) v1 with A = fdx(x_i, u_i) (omni.hpp:194-197, cart.hpp:183-186)
-  {
-    R c2 = R(0);
-    for (int base = 0; base < T; base += kBlock) {
-      const int i = T - 1 - (base + tid);
-      R qv = R(0);
-      if (i >= 0) {
-        const R c = s_ct[i + 1], s = s_st[i + 1];
-        const R vx = s_vx[i], vy = s_vy[i];
-        R a02, a12;
-        if (MODEL == kModelOmni) {
-          a02 = -vx * s - vy * c;
-          a12 = vx * c - vy * s;
-        } else {
-          a02 = -vx * s;
-          a12 = vx * c;
-        }
-        const R sE = a02 * s_r0[i + 1] + a12 * s_r1[i + 1];
-        const R sG = a02 * s_g0[i] + a12 * s_g1[i];
-        qv = dt * (sE + R(0.5) * dt * sG);
-      }
-      R tot;
-      const R inc = block_scan(qv, s_sw, tot);
-      if (i >= 0) s_r2[i] = c2 + inc;
-      c2 += tot;
-    }
-  }
-  __syncthreads();
-
-  // ---- u_i = clamp(-Rinv B(x_i)^T rho_i)  (ergodic_control.hpp:438-451)
-  for (int i = tid; i < T; i += kBlock) {
-    const R rho0 = s_r0[i], rho1 = s_r1[i], rho2 = s_r2[i];
-    const R c = s_ct[i + 1], s = s_st[i + 1];
-    R v0, v1, v2;
-    if (MODEL == kModelOmni) {  // omni.hpp:205-212
-      v0 = c * rho0 + s * rho1;
-      v1 = -s * rho0 + c * rho1;
-      v2 = rho2;
-    } else {  // cart.hpp:194-203
-      v0 = c * rho0 + s * rho1;
-      v1 = R(0);
-      v2 = rho2;
-    }
-    const R t0 = -v0, t1 = -v1, t2 = -v2;
-    R u[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      const R ur = (p.Rinv[r] * t0 + p.Rinv[r + 3] * t1) + p.Rinv[r + 6] * t2;
-      u[r] = clamp_std(ur, p.umin[r], p.umax[r]);
-    }
-    ut[3 * i + 0] = u[0];
-    ut[3 * i + 1] = u[1];
-    ut[3 * i + 2] = u[2];
-    if (p.rhot != nullptr) {
-      R* const o = p.rhot + 3 * (static_cast<size_t>(T) * b + i);
-      o[0] = rho0;
-      o[1] = rho1;
-      o[2] = rho2;
-    }
-    if (i == 0) {
-      R* const o = p.u0 + 3 * static_cast<size_t>(b);
-      o[0] = u[0];
-      o[1] = u[1];
-      o[2] = u[2];
-    }
-  }
-}
-
-template <typename R, int MODEL, int KC>
-hipError_t launch_one(const ControlParams<R>& p, unsigned B, int Nmax, bool rollout_only,
-                      size_t lds, hipStream_t stream)
-{
-  auto kern = control_kernel<R, MODEL, KC>;
-  if (lds > 64 * 1024) {
-    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                             hipFuncAttributeMaxDynamicSharedMemorySize,
-                                             static_cast<int>(lds));
-    if (e != hipSuccess) return e;
-  }
-  hipLaunchKernelGGL(kern, dim3(B), dim3(kBlock), lds, stream, p, Nmax, rollout_only ? 1 : 0);
-  return hipGetLastError();
-}
-
 template <typename R, int MODEL>
 hipError_t launch_model(const ControlParams<R>& p, unsigned B, int Nmax, bool rollout_only,
                         size_t lds, hipStream_t stream)

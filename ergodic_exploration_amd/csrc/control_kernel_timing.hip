@@ -1,0 +1,18 @@
+// Diagnostic build of the fused control kernel with phase stamps (EEA_TIMING): K = 10, fp64 only.
+// Not used by the product path; reached through eea_debug_phase_timing.
+#define EEA_TIMING 1
+#include "control_kernel_impl.hpp"
+
+namespace eea
+{
+hipError_t launch_control_timing(const ControlParams<double>& p, unsigned B, int model, int n_mem_max,
+                                 hipStream_t stream)
+{
+  if (B == 0) return hipSuccess;
+  if (p.K != 10) return hipErrorInvalidValue;
+  const int Nmax = p.T + n_mem_max;
+  const size_t lds = static_cast<size_t>(lds_layout(p.T, Nmax, p.K).total) * sizeof(double);
+  if (model == kModelOmni) return launch_one<double, kModelOmni, 10>(p, B, Nmax, false, lds, stream);
+  return launch_one<double, kModelSimpleCart, 10>(p, B, Nmax, false, lds, stream);
+}
+}  // namespace eea

@@ -280,7 +280,7 @@ void fill_params(const eea_engine* e, eea::ControlParams<R>& p)
 
 template <typename R>
 eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io, bool rollout_only,
-                              hipStream_t s)
+                              hipStream_t s, long long* d_stamps = nullptr)
 {
   eea::ControlParams<R> p;
   fill_params<R>(e, p);
@@ -302,7 +302,14 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
   if (lds > 160 * 1024) {
     return fail(EEA_ERR_UNSUPPORTED, "horizon/memory/basis too large for one workgroup's 160 KiB LDS");
   }
-  if (e->impl_v1) {
+  if (d_stamps != nullptr) {
+    if constexpr (sizeof(R) == 8) {
+      p.dbg = d_stamps;
+      EEA_HIP(eea::launch_control_timing(p, B, e->cfg.model, n_mem_max, s));
+    } else {
+      return fail(EEA_ERR_UNSUPPORTED, "phase timing is built for fp64 only");
+    }
+  } else if (e->impl_v1) {
     EEA_HIP(eea::v1::launch_control<R>(p, B, e->cfg.model, n_mem_max, rollout_only, s));
   } else {
     EEA_HIP(eea::launch_control<R>(p, B, e->cfg.model, n_mem_max, rollout_only, s));
@@ -510,6 +517,20 @@ eea_status eea_control_batch(eea_engine* e, unsigned B, const eea_batch_io* io, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   return e->f32 ? control_batch_impl<float>(e, B, io, false, s)
                 : control_batch_impl<double>(e, B, io, false, s);
+}
+
+eea_status eea_debug_phase_timing(eea_engine* e, unsigned B, const eea_batch_io* io, void* stream,
+                                  long long* d_stamps)
+{
+  if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (io == nullptr || io->d_pose == nullptr || io->d_ut == nullptr || io->d_u0 == nullptr || d_stamps == nullptr) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "d_pose, d_ut, d_u0 and d_stamps are required");
+  }
+  if (!e->have_phik) return fail(EEA_ERR_NO_TARGET, "no phi_k");
+  if (e->f32 || e->K != 10) return fail(EEA_ERR_UNSUPPORTED, "phase timing is built for fp64, K = 10 only");
+  eea_status st = use_device(e);
+  if (st != EEA_OK) return st;
+  return control_batch_impl<double>(e, B, io, false, static_cast<hipStream_t>(stream), d_stamps);
 }
 
 eea_status eea_rollout_batch(eea_engine* e, unsigned B, const void* d_pose, const void* d_ut,

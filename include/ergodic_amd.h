@@ -133,6 +133,12 @@ typedef struct {
  * configTarget call: use eea_config_domain first).  Asynchronous on `stream`. */
 eea_status eea_control_batch(eea_engine* e, unsigned B, const eea_batch_io* io, void* stream);
 
+/* Diagnostic (not part of the reference surface): same as eea_control_batch for an fp64,
+ * K = 10 engine, through an instrumented build that records the shader clock of every
+ * wavefront at 12 phase boundaries: d_stamps [B][4][16] int64 (tools/phase_timing.py). */
+eea_status eea_debug_phase_timing(eea_engine* e, unsigned B, const eea_batch_io* io, void* stream,
+                                  long long* d_stamps);
+
 /* Forward rollout only: ErgodicControl::optTraj / path (ergodic_control.hpp:313-342),
  * RungeKutta::solve (integrator.hpp:135-152).  d_ut is used as is (no shift). */
 eea_status eea_rollout_batch(eea_engine* e, unsigned B, const void* d_pose, const void* d_ut,
