@@ -113,6 +113,8 @@ def lib():
                                            C.c_uint, C.c_uint, C.c_void_p]
         L.eea_basis_spatial_coeff.argtypes = [C.c_int, C.c_double, C.c_double, C.c_uint, C.c_void_p,
                                               C.c_void_p, C.c_uint, C.c_void_p]
+        L.eea_rk4_rollout.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.eea_target_fill.argtypes = [C.c_int, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
         L.eea_collision_check_batch.argtypes = [C.c_int, C.POINTER(CollisionCfg), C.c_void_p,
                                                 C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p]
         L.eea_validate_control_batch.argtypes = [C.c_int, C.POINTER(CollisionCfg), C.c_void_p,
@@ -275,6 +277,29 @@ def basis_spatial_coeff(lx, ly, K, phi_vals, grid, device=0):
     g = np.ascontiguousarray(np.asarray(grid, dtype=np.float64).T)
     out = np.empty(K * K)
     check(lib().eea_basis_spatial_coeff(device, lx, ly, K, _ptr(pv), _ptr(g), pv.size, _ptr(out)))
+    return out
+
+
+def rk4_rollout(model, dt, horizon, x0, ut, device=0):
+    """RungeKutta::solve for Omni / SimpleCart on the device. ut (3, T) -> xt (3, T)"""
+    import numpy as np
+    x0 = np.ascontiguousarray(x0, dtype=np.float64)
+    a = np.ascontiguousarray(np.asarray(ut, dtype=np.float64).T)
+    T = a.shape[0]
+    out = np.empty((T, 3))
+    check(lib().eea_rk4_rollout(device, model, dt, horizon, _ptr(x0), _ptr(a), _ptr(out)))
+    return out.T.copy()
+
+
+def target_fill(mu, sigma, trans, grid, device=0):
+    import numpy as np
+    mu = np.ascontiguousarray(mu, dtype=np.float64).reshape(-1)
+    sigma = np.ascontiguousarray(sigma, dtype=np.float64).reshape(-1)
+    trans = np.ascontiguousarray(trans, dtype=np.float64)
+    g = np.ascontiguousarray(np.asarray(grid, dtype=np.float64).T)
+    out = np.empty(g.shape[0])
+    check(lib().eea_target_fill(device, mu.size // 2, _ptr(mu), _ptr(sigma), _ptr(trans), _ptr(g),
+                                g.shape[0], _ptr(out)))
     return out
 
 

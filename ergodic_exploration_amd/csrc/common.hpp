@@ -86,6 +86,12 @@ template <typename R>
 hipError_t launch_target_fill(const R* d_xs, const R* d_ys, int nx, int ny, const R* d_gauss,
                               int n_gauss, R* d_phi, R* d_partials, int* n_partials, hipStream_t s);
 
+// same on an arbitrary point list (d_px, d_py: P coordinates each)
+template <typename R>
+hipError_t launch_target_fill_points(const R* d_px, const R* d_py, unsigned P, const R* d_gauss,
+                                     int n_gauss, R* d_phi, R* d_partials, int* n_partials,
+                                     hipStream_t s);
+
 // deterministic sum of n values -> d_out[0]
 template <typename R>
 hipError_t launch_reduce_sum(const R* d_in, int n, R* d_out, hipStream_t s);

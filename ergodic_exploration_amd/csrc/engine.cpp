@@ -707,6 +707,107 @@ eea_status eea_basis_spatial_coeff(int device, double lx, double ly, unsigned nu
   return basis_points(device, lx, ly, num_basis, xs.data(), ys.data(), h_phi_vals, P, 1.0, h_phik);
 }
 
+eea_status eea_rk4_rollout(int device, int model, double dt, double horizon, const double x0[3],
+                           const double* h_ut, double* h_xt)
+{
+  if (x0 == nullptr || h_ut == nullptr || h_xt == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  if (model != EEA_MODEL_OMNI && model != EEA_MODEL_SIMPLE_CART) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "device rollout needs a body-twist model (Omni / SimpleCart)");
+  }
+  const double ratio = std::abs(horizon / dt);
+  if (!(ratio < 1.0e6)) return fail(EEA_ERR_INVALID_ARGUMENT, "horizon / dt out of range");
+  const unsigned steps = static_cast<unsigned>(ratio);  // integrator.hpp:141
+  if (steps == 0) return EEA_OK;
+  EEA_HIP(hipSetDevice(device));
+  DevBuf dpose, dut, dtraj, dstat;
+  hipError_t err = dpose.reserve(sizeof(double) * 3);
+  if (err == hipSuccess) err = dut.reserve(sizeof(double) * 3 * steps);
+  if (err == hipSuccess) err = dtraj.reserve(sizeof(double) * 3 * steps);
+  if (err == hipSuccess) err = dstat.reserve(sizeof(int));
+  if (err == hipSuccess) err = hipMemcpy(dpose.p, x0, sizeof(double) * 3, hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemcpy(dut.p, h_ut, sizeof(double) * 3 * steps, hipMemcpyHostToDevice);
+  int status = 0;
+  if (err == hipSuccess) {
+    eea::ControlParams<double> p;
+    std::memset(&p, 0, sizeof(p));
+    p.T = static_cast<int>(steps);
+    p.K = 1;
+    p.chunk = 64;
+    p.dt = dt;
+    p.lx = p.ly = 1.0;
+    p.inv_lx = p.inv_ly = 1.0;
+    p.pose = static_cast<const double*>(dpose.p);
+    p.ut = static_cast<double*>(dut.p);
+    p.traj = static_cast<double*>(dtraj.p);
+    p.status = static_cast<int*>(dstat.p);
+    if (eea::control_lds_bytes<double>(p.T, p.K, 0, p.chunk) > 160 * 1024) {
+      err = hipErrorInvalidValue;
+    } else {
+      err = eea::launch_control<double>(p, 1, model, 0, true, nullptr);
+    }
+  }
+  if (err == hipSuccess) err = hipMemcpy(&status, dstat.p, sizeof(int), hipMemcpyDeviceToHost);
+  if (err == hipSuccess && status == 0) err = hipMemcpy(h_xt, dtraj.p, sizeof(double) * 3 * steps, hipMemcpyDeviceToHost);
+  dpose.release();
+  dut.release();
+  dtraj.release();
+  dstat.release();
+  if (err != hipSuccess) return fail(EEA_ERR_HIP, std::string("rk4 rollout: ") + hipGetErrorString(err));
+  if (status == EEA_ERR_INVALID_TWIST) return fail(EEA_ERR_INVALID_TWIST, "Invalid twist y-velocity must be 0.");
+  return EEA_OK;
+}
+
+eea_status eea_target_fill(int device, unsigned n_gauss, const double* mu, const double* sigma,
+                           const double trans[2], const double* h_phi_grid, unsigned P,
+                           double* h_phi_vals)
+{
+  if (trans == nullptr || h_phi_grid == nullptr || h_phi_vals == nullptr || (n_gauss > 0 && (mu == nullptr || sigma == nullptr))) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  }
+  if (P == 0) return EEA_OK;
+  EEA_HIP(hipSetDevice(device));
+  std::vector<double> xs(P), ys(P), g(4 * static_cast<size_t>(n_gauss ? n_gauss : 1));
+  for (unsigned i = 0; i < P; ++i) {
+    xs[i] = h_phi_grid[2 * static_cast<size_t>(i)];
+    ys[i] = h_phi_grid[2 * static_cast<size_t>(i) + 1];
+  }
+  for (unsigned i = 0; i < n_gauss; ++i) {  // target.hpp:69,99
+    const double a = sigma[2 * i] * sigma[2 * i], d = sigma[2 * i + 1] * sigma[2 * i + 1];
+    const double det = a * d - 0.0 * 0.0;
+    g[4 * i + 0] = mu[2 * i] - trans[0];
+    g[4 * i + 1] = mu[2 * i + 1] - trans[1];
+    g[4 * i + 2] = d / det;
+    g[4 * i + 3] = a / det;
+  }
+  const int blocks = static_cast<int>((P + eea::kBlock - 1) / eea::kBlock);
+  DevBuf dx, dy, dg, dphi, dsum;
+  hipError_t err = dx.reserve(sizeof(double) * P);
+  if (err == hipSuccess) err = dy.reserve(sizeof(double) * P);
+  if (err == hipSuccess) err = dg.reserve(sizeof(double) * g.size());
+  if (err == hipSuccess) err = dphi.reserve(sizeof(double) * P);
+  if (err == hipSuccess) err = dsum.reserve(sizeof(double) * (static_cast<size_t>(blocks) + 1));
+  if (err == hipSuccess) err = hipMemcpy(dx.p, xs.data(), sizeof(double) * P, hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemcpy(dy.p, ys.data(), sizeof(double) * P, hipMemcpyHostToDevice);
+  if (err == hipSuccess) err = hipMemcpy(dg.p, g.data(), sizeof(double) * g.size(), hipMemcpyHostToDevice);
+  int n_partials = 0;
+  double* const d_partials = dsum.p ? static_cast<double*>(dsum.p) + 1 : nullptr;
+  if (err == hipSuccess) {
+    err = eea::launch_target_fill_points<double>(static_cast<const double*>(dx.p), static_cast<const double*>(dy.p), P,
+                                                 static_cast<const double*>(dg.p), static_cast<int>(n_gauss),
+                                                 static_cast<double*>(dphi.p), d_partials, &n_partials, nullptr);
+  }
+  if (err == hipSuccess) err = eea::launch_reduce_sum<double>(d_partials, n_partials, static_cast<double*>(dsum.p), nullptr);
+  if (err == hipSuccess) err = eea::launch_scale_by_inv<double>(static_cast<double*>(dphi.p), P, static_cast<const double*>(dsum.p), nullptr);
+  if (err == hipSuccess) err = hipMemcpy(h_phi_vals, dphi.p, sizeof(double) * P, hipMemcpyDeviceToHost);
+  dx.release();
+  dy.release();
+  dg.release();
+  dphi.release();
+  dsum.release();
+  if (err != hipSuccess) return fail(EEA_ERR_HIP, std::string("target fill: ") + hipGetErrorString(err));
+  return EEA_OK;
+}
+
 // ---- collision lookups ---------------------------------------------------------------------
 static eea_status make_collision_params(const eea_collision_cfg* cfg, eea::CollisionParams& c)
 {

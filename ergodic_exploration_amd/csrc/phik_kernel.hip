@@ -100,6 +100,28 @@ __global__ __launch_bounds__(kBlock) void target_fill_kernel(const R* __restrict
 }
 
 template <typename R>
+__global__ __launch_bounds__(kBlock) void target_fill_points_kernel(const R* __restrict__ px,
+                                                                    const R* __restrict__ py, unsigned P,
+                                                                    const R* __restrict__ gauss, int n_gauss,
+                                                                    R* __restrict__ phi,
+                                                                    R* __restrict__ partials)
+{
+  __shared__ R s_w[kBlock / kWave];
+  const unsigned q = blockIdx.x * kBlock + threadIdx.x;
+  R val = R(0);
+  if (q < P) {
+    const R x = px[q], y = py[q];
+    for (int g = 0; g < n_gauss; ++g) {
+      const R dx = x - gauss[4 * g + 0], dy = y - gauss[4 * g + 1];
+      val += exp_r(R(-0.5) * ((dx * gauss[4 * g + 2]) * dx + (dy * gauss[4 * g + 3]) * dy));
+    }
+    phi[q] = val;
+  }
+  const R t = block_sum(val, s_w);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
+template <typename R>
 __global__ __launch_bounds__(kBlock) void reduce_sum_kernel(const R* __restrict__ in, int n,
                                                             R* __restrict__ out)
 {
@@ -306,6 +328,19 @@ hipError_t launch_target_fill(const R* d_xs, const R* d_ys, int nx, int ny, cons
 }
 
 template <typename R>
+hipError_t launch_target_fill_points(const R* d_px, const R* d_py, unsigned P, const R* d_gauss,
+                                     int n_gauss, R* d_phi, R* d_partials, int* n_partials,
+                                     hipStream_t s)
+{
+  const int blocks = static_cast<int>((P + kBlock - 1) / kBlock);
+  *n_partials = blocks;
+  if (blocks == 0) return hipSuccess;
+  hipLaunchKernelGGL(target_fill_points_kernel<R>, dim3(blocks), dim3(kBlock), 0, s, d_px, d_py, P,
+                     d_gauss, n_gauss, d_phi, d_partials);
+  return hipGetLastError();
+}
+
+template <typename R>
 hipError_t launch_reduce_sum(const R* d_in, int n, R* d_out, hipStream_t s)
 {
   hipLaunchKernelGGL(reduce_sum_kernel<R>, dim3(1), dim3(kBlock), 0, s, d_in, n, d_out);
@@ -388,6 +423,8 @@ hipError_t launch_point_coeff(const R* d_x, const R* d_y, const R* d_w, unsigned
   template hipError_t launch_cos_tables_t<R>(const R*, int, int, R, R*, hipStream_t);               \
   template hipError_t launch_target_fill<R>(const R*, const R*, int, int, const R*, int, R*, R*,    \
                                             int*, hipStream_t);                                     \
+  template hipError_t launch_target_fill_points<R>(const R*, const R*, unsigned, const R*, int, R*,  \
+                                                   R*, int*, hipStream_t);                           \
   template hipError_t launch_reduce_sum<R>(const R*, int, R*, hipStream_t);                         \
   template hipError_t launch_scale_by_inv<R>(R*, size_t, const R*, hipStream_t);                    \
   template hipError_t launch_spatial_coeff<R>(const R*, int, int, int, const R*, const R*, R*, R*,  \

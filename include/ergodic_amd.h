@@ -167,6 +167,17 @@ eea_status eea_basis_spatial_coeff(int device, double lx, double ly, unsigned nu
                                    const double* h_phi_vals, const double* h_phi_grid, unsigned P,
                                    double* h_phik);
 
+/* RungeKutta::solve (forward, integrator.hpp:135-152) for a body-twist model without an
+ * engine: x0[3], h_ut 3 x steps, h_xt out 3 x steps, steps = (unsigned)|horizon/dt|.
+ * EEA_ERR_INVALID_TWIST mirrors SimpleCart's throw. */
+eea_status eea_rk4_rollout(int device, int model, double dt, double horizon, const double x0[3],
+                           const double* h_ut, double* h_xt);
+/* Target::fill (target.cpp:78-89) on an arbitrary point list: h_phi_grid 2 x P, trans[2];
+ * h_phi_vals out, normalised to sum 1. */
+eea_status eea_target_fill(int device, unsigned n_gauss, const double* mu, const double* sigma,
+                           const double trans[2], const double* h_phi_grid, unsigned P,
+                           double* h_phi_vals);
+
 /* ---- next rows of the scope table: collision lookups ------------------------------- */
 /* Collision::collisionCheck (collision.cpp:126-141) for P poses on one occupancy grid
  * (GridMap, grid.cpp:143-184).  d_grid: int8 row-major [ysize][xsize]; d_pose: [P][3]
