@@ -106,7 +106,7 @@ int exploration_main(int argc, char** argv, bool is_cart)
     ergodic_control.addStateMemory(pose);
     const ee::vec u = ergodic_control.control(grid, pose);
     const bool safe = ee::validate_control(collision, grid, pose, u, val_dt, val_horizon);
-    std::printf("tick %3d pose %.6f %.6f %.6f  cmd_vel %.17g %.17g %.17g  %s\n", t, pose(0), pose(1), pose(2),
+    std::printf("tick %3d pose %.17g %.17g %.17g  cmd_vel %.17g %.17g %.17g  %s\n", t, pose(0), pose(1), pose(2),
                 u(0), u(1), u(2), safe ? "ok" : "collision-predicted");
     pose = sim.step(model, pose, safe ? u : ee::vec{ 0.0, 0.0, 0.0 });
     pose(2) = ee::normalize_angle_PI(pose(2));

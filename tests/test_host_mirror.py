@@ -60,9 +60,9 @@ def test_entry_points_follow_the_oracle(name, model, cfg):
     bounds = (-1.0, 11.0, -1.0, 5.0)
     memory = []
     for t in range(ticks):
-        x = poses[t]  # printed with 6 decimals: drive the oracle from the same printed pose
+        x = poses[t]  # printed with 17 significant digits: the oracle sees the engine's exact pose
         memory.append(x.copy())
-        # the engine saw the unrounded pose; the tolerance covers the 5e-7 print rounding
         u = ec.control(bounds, x, np.array(memory).T)
-        assert np.abs(got[t] - u).max() < 5e-5, (t, got[t], u)
-        ec.ut = ec.ut  # keep the oracle's own warm start
+        # both loops run from a zero warm start; rounding differences (~1e-13 per call) are
+        # amplified by the warm-start feedback, roughly 10x per tick
+        assert np.abs(got[t] - u).max() < 1e-6, (t, got[t], u)
