@@ -1,4 +1,6 @@
 // Instantiations and dispatch of the fused control kernel (control_kernel_impl.hpp).
+#include <cstdlib>
+
 #include "control_kernel_impl.hpp"
 
 namespace eea
@@ -36,7 +38,13 @@ hipError_t launch_control(const ControlParams<R>& p, unsigned B, int model, int 
 {
   if (B == 0) return hipSuccess;
   const int Nmax = p.T + n_mem_max;
-  const size_t lds = control_lds_bytes<R>(p.T, p.K, n_mem_max, p.chunk);
+  size_t lds = control_lds_bytes<R>(p.T, p.K, n_mem_max, p.chunk);
+  // occupancy experiment knob (tools/ab_bench.sh): extra dynamic LDS per workgroup in KiB
+  static const int pad_kib = [] {
+    const char* v = std::getenv("EEA_LDS_PAD_KIB");
+    return v ? std::atoi(v) : 0;
+  }();
+  if (pad_kib > 0 && lds + static_cast<size_t>(pad_kib) * 1024 <= 160 * 1024) lds += static_cast<size_t>(pad_kib) * 1024;
   if (model == kModelOmni) return launch_model<R, kModelOmni>(p, B, Nmax, rollout_only, lds, stream);
   return launch_model<R, kModelSimpleCart>(p, B, Nmax, rollout_only, lds, stream);
 }

@@ -108,7 +108,7 @@ template <typename R>
 __device__ __forceinline__ R block_scan(R v, R* s_w, R& total)
 {
   const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x / kWave;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // provably wave-uniform
   const R s = wave_inclusive_scan_dpp(v);
   if (lane == kWave - 1) s_w[wave] = s;
   __syncthreads();
@@ -128,7 +128,7 @@ template <typename R>
 __device__ __forceinline__ void block_scan2(R& a, R& b, R* s_w, R& tot_a, R& tot_b)
 {
   const int lane = threadIdx.x & (kWave - 1);
-  const int wave = threadIdx.x / kWave;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const R sa = wave_inclusive_scan_dpp(a);
   const R sb = wave_inclusive_scan_dpp(b);
   if (lane == kWave - 1) {
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
   const int b = blockIdx.x;
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
-  const int wave = tid / kWave;
+  const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);
   const int T = p.T;
   const int K = (KC > 0) ? KC : p.K;
   const int K2 = K * K;
@@ -304,7 +304,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
   EEA_STAMP(1);
 
   const R dt = p.dt;
-  const R dt6 = dt / R(6);
+  const R dt6 = p.dt6;
   const R inv_pi = static_cast<R>(1.0 / kPi);
   R* const traj = (p.traj != nullptr) ? p.traj + 3 * static_cast<size_t>(T) * b : nullptr;
 
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
   //          == wrap(theta_0 + prefix sum) up to rounding
   // position: x_i = x_{i-1} + dt/6 (k1 + 2 k2 + 2 k3 + k4) with k2 == k3 (integrator.hpp:176-184)
   {
-    R carry_th = th0, carry_x = x0, carry_y = y0;
+    R carry_th = wrap_pi_fast(th0), carry_x = x0, carry_y = y0;
     for (int base = 0; base < T; base += kBlock) {
       const int i = base + tid;
       const bool act = i < T;
@@ -330,9 +330,10 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
       // by k2 and k3 (integrator.hpp:179-180), post-step heading
       R cm = R(0), smid = R(0);
       if (act) {
-        const R th_pre = (i == 0) ? th0 : wrap_pi_fast(carry_th + (inc - d));
-        const R th_post = wrap_pi_fast(carry_th + inc);
-        if (traj != nullptr) traj[3 * i + 2] = th_post;
+        // sin(pi t), cos(pi t) reduce any argument exactly: only the reported heading is wrapped
+        const R th_pre = carry_th + (inc - d);
+        const R th_post = carry_th + inc;
+        if (traj != nullptr) traj[3 * i + 2] = wrap_pi_fast(th_post);
         R s, c;
         sincospi_r(th_pre * inv_pi, &s, &c);
         s_ct[i] = c;
@@ -455,8 +456,8 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
         }
       }
 
-      for (int s = 0; s < kWave / kSub; ++s) {
-        if (s * kSub >= nvalid) break;  // wave-uniform
+      // stage one pass of 16 points (this lane's point if it belongs to pass s)
+      auto stage = [&](int s) {
         if (sub == s) {
           R* const tx = tabx + pl * KS;
           R* const ty = taby + pl * KS;
@@ -480,25 +481,44 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
             }
           }
         }
-        wave_lds_fence();
+      };
+      // four points per matrix instruction: operand of lane l = element (4g + l/16) * KS + l%16
+      auto mma_group = [&](int g) {
+        const int off = (4 * g + sub) * KS + pl;
+        R av[NT], bv[NT];
 #pragma unroll
-        for (int g = 0; g < kSub / 4; ++g) {
-          if (s * kSub + 4 * g < nvalid) {  // wave-uniform
-            const int off = (4 * g + sub) * KS + pl;  // = (4g + lane/16) * KS + lane%16
-            R av[NT], bv[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-              av[t] = (t < nt) ? tabx[off + 16 * t] : R(0);
-              bv[t] = (t < nt) ? taby[off + 16 * t] : R(0);
-            }
-#pragma unroll
-            for (int a = 0; a < NT; ++a)
-#pragma unroll
-              for (int c = 0; c < NT; ++c)
-                if (a < nt && c < nt) acc[a][c] = M::run(av[a], bv[c], acc[a][c]);
-          }
+        for (int t = 0; t < NT; ++t) {
+          av[t] = (t < nt) ? tabx[off + 16 * t] : R(0);
+          bv[t] = (t < nt) ? taby[off + 16 * t] : R(0);
         }
-        wave_lds_fence();
+#pragma unroll
+        for (int a = 0; a < NT; ++a)
+#pragma unroll
+          for (int c = 0; c < NT; ++c)
+            if (a < nt && c < nt) acc[a][c] = M::run(av[a], bv[c], acc[a][c]);
+      };
+
+      if (nvalid == kWave) {
+        // full wavefront (the common case): no bounds tests, everything unrolled
+#pragma unroll
+        for (int s = 0; s < kWave / kSub; ++s) {
+          stage(s);
+          wave_lds_fence();
+#pragma unroll
+          for (int g = 0; g < kSub / 4; ++g) mma_group(g);
+          wave_lds_fence();
+        }
+      } else {
+        for (int s = 0; s < kWave / kSub; ++s) {
+          if (s * kSub >= nvalid) break;  // wave-uniform
+          stage(s);
+          wave_lds_fence();
+#pragma unroll
+          for (int g = 0; g < kSub / 4; ++g) {
+            if (s * kSub + 4 * g < nvalid) mma_group(g);  // wave-uniform
+          }
+          wave_lds_fence();
+        }
       }
     }
 
