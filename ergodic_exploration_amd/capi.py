@@ -47,6 +47,13 @@ class CollisionCfg(C.Structure):
                 ("occupied_threshold", C.c_double)]
 
 
+class DwaCfg(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("dt", "horizon", "acc_dt", "acc_lim_x", "acc_lim_y", "acc_lim_th",
+                                          "max_vel_x", "min_vel_x", "max_vel_y", "min_vel_y",
+                                          "max_rot_vel", "min_rot_vel")] + \
+               [(n, C.c_uint) for n in ("vx_samples", "vy_samples", "vth_samples")]
+
+
 def build(force=False):
     """hipcc --offload-arch=gfx950 build of the library (csrc/Makefile)."""
     args = ["make", "-s", "-j4", "-C", os.path.join(_HERE, "csrc")]
@@ -115,6 +122,9 @@ def lib():
                                               C.c_void_p, C.c_uint, C.c_void_p]
         L.eea_rk4_rollout.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         L.eea_target_fill.argtypes = [C.c_int, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
+        L.eea_dwa_control_batch.argtypes = [C.c_int, C.POINTER(CollisionCfg), C.POINTER(DwaCfg), C.c_void_p,
+                                            C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint,
+                                            C.c_double, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
         L.eea_collision_check_batch.argtypes = [C.c_int, C.POINTER(CollisionCfg), C.c_void_p,
                                                 C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p]
         L.eea_validate_control_batch.argtypes = [C.c_int, C.POINTER(CollisionCfg), C.c_void_p,
@@ -318,3 +328,12 @@ def validate_control_batch(cfg, grid, x0, u, dt, horizon, valid, device=0, strea
     check(lib().eea_validate_control_batch(device, C.byref(cfg), _ptr(grid), _ptr(x0), _ptr(u), dt,
                                            horizon, x0.shape[0], _ptr(valid),
                                            C.c_void_p(stream or 0)))
+
+
+def dwa_control_batch(ccfg, dcfg, grid, x0, vb, u_opt, found, vref=None, xt_ref=None, dt_ref=0.0, device=0,
+                      stream=None):
+    """DynamicWindow::control for P robots; xt_ref device tensor [P][n_ref][3] or None"""
+    n_ref = xt_ref.shape[1] if xt_ref is not None else 0
+    check(lib().eea_dwa_control_batch(device, C.byref(ccfg), C.byref(dcfg), _ptr(grid), _ptr(x0), _ptr(vb),
+                                      _ptr(vref), _ptr(xt_ref), n_ref, dt_ref, x0.shape[0], _ptr(u_opt),
+                                      _ptr(found), C.c_void_p(stream or 0)))

@@ -133,7 +133,131 @@ __global__ __launch_bounds__(kBlock) void validate_control_kernel(const Collisio
   }
   valid[q] = ok;
 }
+// DynamicWindow::control (dynamic_window.cpp:92-286): one workgroup per robot, one lane per
+// velocity sample; lane 0 then takes the first strict minimum in the reference's loop order.
+constexpr int kDwaBlock = 128;
+__global__ __launch_bounds__(kDwaBlock) void dwa_control_kernel(const CollisionParams c, const DwaParams d,
+                                                               const int8_t* __restrict__ grid,
+                                                               const double* __restrict__ x0s,
+                                                               const double* __restrict__ vbs,
+                                                               const double* __restrict__ vrefs,
+                                                               const double* __restrict__ xt_refs,
+                                                               unsigned n_ref, double dt_ref,
+                                                               double* __restrict__ u_opt,
+                                                               int* __restrict__ found)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* const s_cost = reinterpret_cast<double*>(smem_raw);
+  const unsigned r = blockIdx.x;
+  const double* const x0 = x0s + 3 * static_cast<size_t>(r);
+  const double* const vb = vbs + 3 * static_cast<size_t>(r);
+  const unsigned nsamp = d.ns[0] * d.ns[1] * d.ns[2];
+  constexpr double kMax = 1.7976931348623157e308;
+
+  // window (dynamic_window.cpp:191-235)
+  double lower[3], delta[3];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    lower[a] = fmax(vb[a] - d.acc_lim[a] * d.acc_dt, d.vmin[a]);
+    const double upper = fmin(vb[a] + d.acc_lim[a] * d.acc_dt, d.vmax[a]);
+    delta[a] = (d.ns[a] > 1) ? (upper - lower[a]) / static_cast<double>(d.ns[a] - 1) : 0.0;
+  }
+  const double tf = static_cast<double>(n_ref) * dt_ref;
+  const double* const xr = (xt_refs != nullptr) ? xt_refs + 3 * static_cast<size_t>(n_ref) * r : nullptr;
+
+  for (unsigned sidx = threadIdx.x; sidx < nsamp; sidx += kDwaBlock) {
+    // sample (i, j, k) in the reference's loop order; values by repeated += like the reference
+    const unsigned k = sidx % d.ns[2], j = (sidx / d.ns[2]) % d.ns[1], i = sidx / (d.ns[2] * d.ns[1]);
+    double u0 = lower[0], u1 = lower[1], u2 = lower[2];
+    for (unsigned q = 0; q < i; ++q) u0 += delta[0];
+    for (unsigned q = 0; q < j; ++q) u1 += delta[1];
+    for (unsigned q = 0; q < k; ++q) u2 += delta[2];
+
+    // constant-twist displacement in the body frame (numerics.hpp:273-297)
+    double d0, d1, d2;
+    if (fabs(u2 - 0.0) < 1.0e-12) {
+      d0 = u0 * d.dt;
+      d1 = u1 * d.dt;
+      d2 = 0.0;
+    } else {
+      const double vb0 = u0 * d.dt, vb1 = u1 * d.dt, vb2 = u2 * d.dt;
+      double sn, cs;
+      sincos(vb2, &sn, &cs);
+      d0 = (vb0 * sn + vb1 * (cs - 1.0)) / vb2;
+      d1 = (vb1 * sn + vb0 * (1.0 - cs)) / vb2;
+      d2 = vb2;
+    }
+    double x = x0[0], y = x0[1], th = x0[2];
+    double cost = 0.0, t = 0.0;
+    bool hit = false;
+    for (unsigned st = 0; st < d.steps; ++st) {
+      double sn, cs;
+      sincos(th, &sn, &cs);
+      x = x + (cs * d0 + (-sn) * d1);
+      y = y + (sn * d0 + cs * d1);
+      th = wrap_pi<double>(th + d2);
+      if (collision_check(c, grid, x, y)) {
+        hit = true;
+        break;
+      }
+      if (xr != nullptr) {
+        const unsigned jj = cast_u32_x86(round(static_cast<double>(n_ref - 1) * t / tf));
+        const double ex = xr[3 * jj + 0] - x, ey = xr[3 * jj + 1] - y;
+        cost += sqrt(ex * ex + ey * ey);
+        cost += fabs(wrap_pi<double>(wrap_pi<double>(xr[3 * jj + 2]) - th));
+        t += d.dt;
+      }
+    }
+    if (hit) {
+      cost = kMax;
+    } else if (xr == nullptr) {
+      const double* const vref = vrefs + 3 * static_cast<size_t>(r);
+      const double e0 = vref[0] - u0, e1 = vref[1] - u1, e2 = vref[2] - u2;
+      cost = (e0 * e0 + e2 * e2) + e1 * e1;
+    }
+    s_cost[sidx] = cost;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double best = kMax;
+    unsigned arg = 0;
+    for (unsigned sidx = 0; sidx < nsamp; ++sidx) {
+      if (s_cost[sidx] < best) {
+        best = s_cost[sidx];
+        arg = sidx;
+      }
+    }
+    const bool ok = !(fabs(best - kMax) < 1.0e-12);
+    double o0 = 0.0, o1 = 0.0, o2 = 0.0;  // u_opt stays zero when nothing beat the initial maximum
+    if (best < kMax) {
+      const unsigned k = arg % d.ns[2], j = (arg / d.ns[2]) % d.ns[1], i = arg / (d.ns[2] * d.ns[1]);
+      o0 = lower[0];
+      o1 = lower[1];
+      o2 = lower[2];
+      for (unsigned q = 0; q < i; ++q) o0 += delta[0];
+      for (unsigned q = 0; q < j; ++q) o1 += delta[1];
+      for (unsigned q = 0; q < k; ++q) o2 += delta[2];
+    }
+    u_opt[3 * static_cast<size_t>(r) + 0] = o0;
+    u_opt[3 * static_cast<size_t>(r) + 1] = o1;
+    u_opt[3 * static_cast<size_t>(r) + 2] = o2;
+    found[r] = ok ? 1 : 0;
+  }
+}
 }  // namespace
+
+hipError_t launch_dwa_control(const CollisionParams& c, const DwaParams& d, const int8_t* d_grid,
+                              const double* d_x0, const double* d_vb, const double* d_vref,
+                              const double* d_xt_ref, unsigned n_ref, double dt_ref, unsigned P,
+                              double* d_u_opt, int* d_found, hipStream_t s)
+{
+  if (P == 0) return hipSuccess;
+  const size_t lds = sizeof(double) * static_cast<size_t>(d.ns[0]) * d.ns[1] * d.ns[2];
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(dwa_control_kernel, dim3(P), dim3(kDwaBlock), lds, s, c, d, d_grid, d_x0, d_vb, d_vref,
+                     d_xt_ref, n_ref, dt_ref, d_u_opt, d_found);
+  return hipGetLastError();
+}
 
 hipError_t launch_collision_check(const CollisionParams& c, const int8_t* d_grid,
                                   const double* d_pose, unsigned P, int* d_hit, hipStream_t s)

@@ -130,6 +130,17 @@ hipError_t launch_validate_control(const CollisionParams& c, const int8_t* d_gri
                                    const double* d_x0, const double* d_u, double dt, unsigned steps,
                                    unsigned P, int* d_valid, hipStream_t s);
 
+struct DwaParams
+{
+  double dt, acc_dt, acc_lim[3], vmax[3], vmin[3];
+  unsigned ns[3];  // vx, vy, vth samples (>= 1)
+  unsigned steps;  // (unsigned)|horizon / dt|
+};
+hipError_t launch_dwa_control(const CollisionParams& c, const DwaParams& d, const int8_t* d_grid,
+                              const double* d_x0, const double* d_vb, const double* d_vref,
+                              const double* d_xt_ref, unsigned n_ref, double dt_ref, unsigned P,
+                              double* d_u_opt, int* d_found, hipStream_t s);
+
 // ======================================================================================
 // device helpers
 // ======================================================================================

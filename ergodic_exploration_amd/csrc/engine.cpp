@@ -863,4 +863,44 @@ eea_status eea_validate_control_batch(int device, const eea_collision_cfg* cfg, 
   return EEA_OK;
 }
 
+eea_status eea_dwa_control_batch(int device, const eea_collision_cfg* ccfg, const eea_dwa_cfg* dcfg,
+                                 const int8_t* d_grid, const double* d_x0, const double* d_vb,
+                                 const double* d_vref, const double* d_xt_ref, unsigned n_ref,
+                                 double dt_ref, unsigned P, double* d_u_opt, int* d_found, void* stream)
+{
+  eea::CollisionParams c;
+  eea_status st = make_collision_params(ccfg, c);
+  if (st != EEA_OK) return st;
+  if (dcfg == nullptr || d_grid == nullptr || d_x0 == nullptr || d_vb == nullptr || d_u_opt == nullptr ||
+      d_found == nullptr) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  }
+  if ((d_vref == nullptr) == (d_xt_ref == nullptr)) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "give either d_vref or d_xt_ref");
+  }
+  if (d_xt_ref != nullptr && n_ref == 0) return fail(EEA_ERR_INVALID_ARGUMENT, "empty reference trajectory");
+  eea::DwaParams d;
+  d.dt = dcfg->dt;
+  d.acc_dt = dcfg->acc_dt;
+  d.acc_lim[0] = dcfg->acc_lim_x;
+  d.acc_lim[1] = dcfg->acc_lim_y;
+  d.acc_lim[2] = dcfg->acc_lim_th;
+  d.vmax[0] = dcfg->max_vel_x;
+  d.vmax[1] = dcfg->max_vel_y;
+  d.vmax[2] = dcfg->max_rot_vel;
+  d.vmin[0] = dcfg->min_vel_x;
+  d.vmin[1] = dcfg->min_vel_y;
+  d.vmin[2] = dcfg->min_rot_vel;
+  // a sample count of 0 is raised to 1 (DynamicWindow::DynamicWindow, dynamic_window.cpp:71-90)
+  d.ns[0] = dcfg->vx_samples ? dcfg->vx_samples : 1;
+  d.ns[1] = dcfg->vy_samples ? dcfg->vy_samples : 1;
+  d.ns[2] = dcfg->vth_samples ? dcfg->vth_samples : 1;
+  d.steps = static_cast<unsigned>(std::abs(dcfg->horizon / dcfg->dt));
+  if (static_cast<size_t>(d.ns[0]) * d.ns[1] * d.ns[2] > 8192) return fail(EEA_ERR_UNSUPPORTED, "more than 8192 DWA samples");
+  EEA_HIP(hipSetDevice(device));
+  EEA_HIP(eea::launch_dwa_control(c, d, d_grid, d_x0, d_vb, d_vref, d_xt_ref, n_ref, dt_ref, P, d_u_opt,
+                                  d_found, static_cast<hipStream_t>(stream)));
+  return EEA_OK;
+}
+
 }  // extern "C"

@@ -196,6 +196,24 @@ eea_status eea_validate_control_batch(int device, const eea_collision_cfg* cfg, 
                                       const double* d_x0, const double* d_u, double dt,
                                       double horizon, unsigned P, int* d_valid, void* stream);
 
+/* DynamicWindow::control (dynamic_window.cpp:92-189), both overloads, for P robots on one grid:
+ * velocity window from the current twist d_vb (dynamic_window.cpp:191-235), vx x vy x vth sample
+ * grid built by repeated += (first strict minimum wins), constant-twist rollouts with a collision
+ * check per step (objective, :237-286).
+ *   mode "vref"  (d_xt_ref == NULL): cost = |vref - u|^2,            d_vref [P][3]
+ *   mode "traj"  (d_xt_ref != NULL): cost = distance to the reference trajectory
+ *                                     d_xt_ref [P][n_ref][3], time step dt_ref
+ * d_u_opt [P][3] out, d_found [P] out (0 = "DWA Failed! Not even 1 solution found"). */
+typedef struct {
+  double dt, horizon, acc_dt, acc_lim_x, acc_lim_y, acc_lim_th;
+  double max_vel_x, min_vel_x, max_vel_y, min_vel_y, max_rot_vel, min_rot_vel;
+  unsigned vx_samples, vy_samples, vth_samples;
+} eea_dwa_cfg;
+eea_status eea_dwa_control_batch(int device, const eea_collision_cfg* ccfg, const eea_dwa_cfg* dcfg,
+                                 const int8_t* d_grid, const double* d_x0, const double* d_vb,
+                                 const double* d_vref, const double* d_xt_ref, unsigned n_ref,
+                                 double dt_ref, unsigned P, double* d_u_opt, int* d_found, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -672,6 +672,107 @@ int eo_validate_control(const eo_collision* c, const eo_grid* g, const double x0
 }
 
 /* ======================================================================= */
+/* dynamic_window.cpp : DynamicWindow                                       */
+/* ======================================================================= */
+#include <float.h>
+
+/* dynamic_window.cpp:191-235 (window) */
+static void dwa_window(const eo_dwa* d, const double vb[3], double lower[3], double delta[3])
+{
+  double upper[3];
+  lower[0] = fmax(vb[0] - d->acc_lim_x * d->acc_dt, d->min_vel_x);
+  upper[0] = fmin(vb[0] + d->acc_lim_x * d->acc_dt, d->max_vel_x);
+  lower[1] = fmax(vb[1] - d->acc_lim_y * d->acc_dt, d->min_vel_y);
+  upper[1] = fmin(vb[1] + d->acc_lim_y * d->acc_dt, d->max_vel_y);
+  lower[2] = fmax(vb[2] - d->acc_lim_th * d->acc_dt, d->min_rot_vel);
+  upper[2] = fmin(vb[2] + d->acc_lim_th * d->acc_dt, d->max_rot_vel);
+  delta[0] = delta[1] = delta[2] = 0.0;
+  const unsigned nx = d->vx_samples ? d->vx_samples : 1, ny = d->vy_samples ? d->vy_samples : 1,
+                 nt = d->vth_samples ? d->vth_samples : 1; /* constructor :71-90 */
+  if (nx > 1) delta[0] = (upper[0] - lower[0]) / (double)(nx - 1);
+  if (ny > 1) delta[1] = (upper[1] - lower[1]) / (double)(ny - 1);
+  if (nt > 1) delta[2] = (upper[2] - lower[2]) / (double)(nt - 1);
+}
+
+/* dynamic_window.cpp:237-256 and :258-286 (objective); xt_ref == NULL selects the first */
+static double dwa_objective(const eo_dwa* d, const eo_collision* c, const eo_grid* g, const double x0[3],
+                            const double vref[3], const double u[3], const double* xt_ref,
+                            unsigned n_ref, double tf)
+{
+  const unsigned steps = eo_steps(d->horizon, d->dt);
+  double pose[3] = { x0[0], x0[1], x0[2] };
+  double t = 0.0, cost = 0.0;
+  for (unsigned i = 0; i < steps; i++) {
+    double pn[3];
+    eo_integrate_twist(pose, u, d->dt, pn);
+    pose[0] = pn[0];
+    pose[1] = pn[1];
+    pose[2] = eo_normalize_angle_PI(pn[2]);
+    if (eo_collision_check(c, g, pose, NULL, NULL, NULL)) return DBL_MAX;
+    if (xt_ref) {
+      const unsigned j = (unsigned)round((double)(n_ref - 1) * t / tf);
+      const double dx = xt_ref[3 * j + 0] - pose[0], dy = xt_ref[3 * j + 1] - pose[1];
+      cost += sqrt(dx * dx + dy * dy); /* arma::norm of a 2-vector */
+      cost += fabs(eo_normalize_angle_PI(eo_normalize_angle_PI(xt_ref[3 * j + 2]) - pose[2]));
+      t += d->dt;
+    }
+  }
+  if (xt_ref) return cost;
+  /* dot(e, e) as Armadillo's direct_dot pairs it: (e0^2 + e2^2) + e1^2 (unpinned, header) */
+  const double e0 = vref[0] - u[0], e1 = vref[1] - u[1], e2 = vref[2] - u[2];
+  return (e0 * e0 + e2 * e2) + e1 * e1;
+}
+
+/* dynamic_window.cpp:92-189: sample grid by repeated +=, first strict minimum wins */
+static int dwa_search(const eo_dwa* d, const eo_collision* c, const eo_grid* g, const double x0[3],
+                      const double vb[3], const double vref[3], const double* xt_ref, unsigned n_ref,
+                      double dt_ref, double u_opt[3], double* min_cost_out)
+{
+  double lower[3], delta[3];
+  dwa_window(d, vb, lower, delta);
+  const double tf = (double)n_ref * dt_ref;
+  const unsigned nx = d->vx_samples ? d->vx_samples : 1, ny = d->vy_samples ? d->vy_samples : 1,
+                 nt = d->vth_samples ? d->vth_samples : 1;
+  double min_cost = DBL_MAX;
+  u_opt[0] = u_opt[1] = u_opt[2] = 0.0;
+  double vx = lower[0];
+  for (unsigned i = 0; i < nx; i++) {
+    double vy = lower[1];
+    for (unsigned j = 0; j < ny; j++) {
+      double w = lower[2];
+      for (unsigned k = 0; k < nt; k++) {
+        const double u[3] = { vx, vy, w };
+        const double cost = dwa_objective(d, c, g, x0, vref, u, xt_ref, n_ref, tf);
+        if (cost < min_cost) {
+          min_cost = cost;
+          u_opt[0] = u[0];
+          u_opt[1] = u[1];
+          u_opt[2] = u[2];
+        }
+        w += delta[2];
+      }
+      vy += delta[1];
+    }
+    vx += delta[0];
+  }
+  if (min_cost_out) *min_cost_out = min_cost;
+  return eo_almost_equal(min_cost, DBL_MAX, 1.0e-12) ? 0 : 1;
+}
+
+int eo_dwa_control_vref(const eo_dwa* d, const eo_collision* c, const eo_grid* g, const double x0[3],
+                        const double vb[3], const double vref[3], double u_opt[3], double* min_cost)
+{
+  return dwa_search(d, c, g, x0, vb, vref, NULL, 0, 0.0, u_opt, min_cost);
+}
+
+int eo_dwa_control_traj(const eo_dwa* d, const eo_collision* c, const eo_grid* g, const double x0[3],
+                        const double vb[3], const double* xt_ref, unsigned n_ref, double dt_ref,
+                        double u_opt[3], double* min_cost)
+{
+  return dwa_search(d, c, g, x0, vb, NULL, xt_ref, n_ref, dt_ref, u_opt, min_cost);
+}
+
+/* ======================================================================= */
 /* ergodic_control.hpp : ErgodicControl<ModelT>                             */
 /* ======================================================================= */
 

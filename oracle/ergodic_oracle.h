@@ -119,6 +119,21 @@ int eo_collision_check(const eo_collision* c, const eo_grid* g, const double pos
 int eo_validate_control(const eo_collision* c, const eo_grid* g, const double x0[3],
                         const double u[3], double dt, double horizon);
 
+/* ---- dynamic_window.cpp (DynamicWindow) -------------------------------- */
+typedef struct {
+  double dt, horizon, acc_dt, acc_lim_x, acc_lim_y, acc_lim_th;
+  double max_vel_x, min_vel_x, max_vel_y, min_vel_y, max_rot_vel, min_rot_vel;
+  unsigned vx_samples, vy_samples, vth_samples;
+} eo_dwa;
+/* control(grid, x0, vb, vref): returns 1 if a collision-free twist was found; u_opt[3];
+ * min_cost (optional) receives the best cost */
+int eo_dwa_control_vref(const eo_dwa* d, const eo_collision* c, const eo_grid* g, const double x0[3],
+                        const double vb[3], const double vref[3], double u_opt[3], double* min_cost);
+/* control(grid, x0, vb, xt_ref, dt_ref): xt_ref 3 x n_ref column-major */
+int eo_dwa_control_traj(const eo_dwa* d, const eo_collision* c, const eo_grid* g, const double x0[3],
+                        const double vb[3], const double* xt_ref, unsigned n_ref, double dt_ref,
+                        double u_opt[3], double* min_cost);
+
 /* ---- ergodic_control.hpp (ErgodicControl<ModelT>) ---------------------- */
 typedef struct eo_control eo_control;
 

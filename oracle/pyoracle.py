@@ -51,6 +51,13 @@ class Collision(C.Structure):
                 ("obstacle_threshold", C.c_double), ("occupied_threshold", C.c_double)]
 
 
+class Dwa(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("dt", "horizon", "acc_dt", "acc_lim_x", "acc_lim_y", "acc_lim_th",
+                                          "max_vel_x", "min_vel_x", "max_vel_y", "min_vel_y",
+                                          "max_rot_vel", "min_rot_vel")] + \
+               [(n, C.c_uint) for n in ("vx_samples", "vy_samples", "vth_samples")]
+
+
 _lib = None
 
 
@@ -290,6 +297,24 @@ def validate_control(coll, grid, x0, u, dt, horizon):
     x0, u = _d(x0), _d(u)
     return bool(lib().eo_validate_control(C.byref(c), C.byref(grid.g), _p(x0), _p(u),
                                           C.c_double(dt), C.c_double(horizon)))
+
+
+def dwa_control(dwa, coll, grid, x0, vb, vref=None, xt_ref=None, dt_ref=0.0):
+    """DynamicWindow::control; dwa: tuple in Dwa field order. xt_ref (3, n). returns (found, u_opt, cost)"""
+    d = Dwa(*dwa)
+    c = Collision(*[float(v) for v in coll])
+    x0, vb = _d(x0), _d(vb)
+    u = np.empty(3)
+    cost = C.c_double()
+    if xt_ref is None:
+        vref = _d(vref)
+        ok = lib().eo_dwa_control_vref(C.byref(d), C.byref(c), C.byref(grid.g), _p(x0), _p(vb), _p(vref), _p(u),
+                                       C.byref(cost))
+    else:
+        xr = _d(np.asarray(xt_ref).T)
+        ok = lib().eo_dwa_control_traj(C.byref(d), C.byref(c), C.byref(grid.g), _p(x0), _p(vb), _p(xr),
+                                       C.c_uint(xr.shape[0]), C.c_double(dt_ref), _p(u), C.byref(cost))
+    return bool(ok), u, cost.value
 
 
 def make_config(model, dt, horizon, resolution, expl_weight, num_basis, Rinv, umin, umax):
