@@ -56,6 +56,13 @@ def cpu_baseline(args, T, seconds):
     cfg = po.make_config(model, args.dt, args.horizon, 0.1, 1.0, args.num_basis, Rinv, -lim, lim)
     rng = np.random.default_rng(12345)
     ncores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:  # a cgroup CPU quota (e.g. "1600000 100000" = 16 CPUs) caps the useful thread count
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            ncores = max(1, min(ncores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
 
     def poses(n):
         return np.stack([rng.uniform(-0.5, 10.5, n), rng.uniform(-0.5, 4.5, n), rng.uniform(-np.pi, np.pi, n)], 1)

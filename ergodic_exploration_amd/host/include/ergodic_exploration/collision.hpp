@@ -71,6 +71,8 @@ public:
   }
 
   double totalPadding() const { return boundary_radius_ + obstacle_threshold_; }
+  // geometry + thresholds in the C-ABI layout
+  eea_collision_cfg deviceConfig(const GridMap& grid) const { return config(grid); }
 
 private:
   static void check(hipError_t e)

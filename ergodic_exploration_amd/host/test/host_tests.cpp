@@ -9,6 +9,7 @@
 #include <cstring>
 #include <string>
 
+#include <ergodic_exploration/dynamic_window.hpp>
 #include <ergodic_exploration/ergodic_control.hpp>
 
 using namespace ergodic_exploration;
@@ -286,6 +287,33 @@ static void test_device_ops()
   CHECK(!col.collisionCheck(g, vec{ 3.5, 1.5, 0.0 }));    // far away
   CHECK(validate_control(col, g, vec{ 3.5, 1.5, 0.0 }, vec{ 0.2, 0.0, 0.1 }, 0.1, 0.5));
   CHECK(!validate_control(col, g, vec{ -0.2, -0.8, 0.0 }, vec{ 1.0, 0.0, 0.0 }, 0.1, 0.5));
+
+  // DynamicWindow: in free space the twist closest to the reference twist inside the window wins
+  const DynamicWindow dwa(col, 0.1, 1.0, 0.2, 1.0, 1.0, 1.0, 1.0, -1.0, 1.0, -1.0, 2.0, -2.0, 3, 8, 5);
+  {
+    const auto [ok, u] = dwa.control(g, vec{ 3.5, 1.5, 0.0 }, vec{ 0.0, 0.0, 0.0 }, vec{ 0.2, 0.2, 0.2 });
+    CHECK(ok);
+    CHECK_NEAR(u(0), 0.2, 1e-12);   // window [-0.2, 0.2] in every component: upper corner
+    CHECK_NEAR(u(1), 0.2, 1e-12);
+    CHECK_NEAR(u(2), 0.2, 1e-12);
+  }
+  {
+    // boxed in: robot right next to the obstacle block, every rollout collides
+    const auto [ok, u] = dwa.control(g, vec{ 1.3, -1.75, 0.0 }, vec{ 0.0, 0.0, 0.0 }, vec{ 0.2, 0.0, 0.0 });
+    CHECK(!ok);
+    CHECK_NEAR(u(0), 0.0, 0.0);
+  }
+  {
+    mat ref(3, 10);
+    for (int i = 0; i < 10; ++i) {
+      ref(0, i) = 3.5 + 0.02 * (i + 1);
+      ref(1, i) = 1.5;
+    }
+    const auto [ok, u] = dwa.control(g, vec{ 3.5, 1.5, 0.0 }, vec{ 0.2, 0.0, 0.0 }, ref, 0.1);
+    CHECK(ok);
+    CHECK(u(0) > 0.0);
+    CHECK_NEAR(u(2), 0.0, 1e-12);
+  }
 }
 
 // closed loop of SURVEY.md 8(c): free 12 x 6 m map at 0.05 m, origin (-1,-1), two yaml Gaussians,
