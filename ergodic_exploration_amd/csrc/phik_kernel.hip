@@ -11,6 +11,8 @@
 // wave-uniform (scalar loads), and each lane keeps K running sums.  Two passes, no atomics:
 // pass 1 writes K^2 partials per workgroup, pass 2 adds them in a fixed order, so results are
 // deterministic run to run.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace eea
@@ -144,54 +146,139 @@ __global__ __launch_bounds__(kBlock) void scale_by_inv_kernel(R* __restrict__ ph
   }
 }
 
-constexpr int kSpatialPad = kBlock + 1;  // LDS row stride of the per-column sums
-
-// pass 1: workgroup = 256 grid columns x `rows_per_tile` grid rows
-template <typename R, int KMAX>
+// pass 1: workgroup = (256 * CPT) grid columns x `rows_per_tile` grid rows.  Each lane owns CPT
+// adjacent columns (CPT = 2: one 16-byte load per row for fp64) and keeps K running sums per
+// column; four rows are in flight per iteration so that a wavefront has 4 KiB of loads outstanding.
+// EXACT: K == KMAX is known at compile time (no per-mode bounds tests in the streaming loop).
+template <typename R, int KMAX, int CPT, bool EXACT>
 __global__ __launch_bounds__(kBlock) void spatial_pass1_kernel(const R* __restrict__ phi, int nx, int ny,
-                                                               int K, int rows_per_tile,
+                                                               int K_rt, int rows_per_tile,
                                                                const R* __restrict__ cx,
                                                                const R* __restrict__ cy,
                                                                R* __restrict__ partials)
 {
+  constexpr int kCols = kBlock * CPT;
+  constexpr int kPad = kCols + 1;  // LDS row stride of the per-column sums
+  constexpr int kRowsInFlight = 4;
+  const int K = EXACT ? KMAX : K_rt;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  R* const s_S = reinterpret_cast<R*>(smem_raw);  // [K][kSpatialPad]
+  R* const s_S = reinterpret_cast<R*>(smem_raw);  // [K][kPad]
 
   const int tid = threadIdx.x;
-  const int ix0 = blockIdx.x * kBlock;
-  const int ix = ix0 + tid;
-  const bool valid = ix < nx;
+  const int ix0 = blockIdx.x * kCols;
+  const int ix = ix0 + tid * CPT;
   const int r0 = blockIdx.y * rows_per_tile;
   const int r1 = (r0 + rows_per_tile) < ny ? (r0 + rows_per_tile) : ny;
+  // vector loads need the whole CPT group in range and a 16-byte aligned row pitch
+  const bool vec_ok = (CPT == 1) || ((ix + CPT <= nx) && ((nx % CPT) == 0));
 
-  R acc[KMAX];
+  R acc[CPT][KMAX];
 #pragma unroll
-  for (int k = 0; k < KMAX; ++k) acc[k] = R(0);
+  for (int c = 0; c < CPT; ++c)
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) acc[c][k] = R(0);
 
-  for (int iy = r0; iy < r1; ++iy) {
-    const R v = valid ? phi[static_cast<size_t>(iy) * nx + ix] : R(0);
-    const R* const cyrow = cy + static_cast<size_t>(iy) * K;  // wave-uniform
+  auto load_row = [&](int iy, R (&v)[CPT]) {
+    const R* const row = phi + static_cast<size_t>(iy) * nx;
+    if (vec_ok) {
+      if (CPT == 2) {
+        typedef R vec2 __attribute__((ext_vector_type(2)));
+        const vec2 t = *reinterpret_cast<const vec2*>(row + ix);
+        v[0] = t.x;
+        v[CPT - 1] = t.y;
+      } else {
+        v[0] = (ix < nx) ? row[ix] : R(0);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) v[c] = (ix + c < nx) ? row[ix + c] : R(0);
+    }
+  };
+
+  int iy = r0;
+  for (; iy + kRowsInFlight <= r1; iy += kRowsInFlight) {
+    R v[kRowsInFlight][CPT];
+#pragma unroll
+    for (int u = 0; u < kRowsInFlight; ++u) load_row(iy + u, v[u]);
+#pragma unroll
+    for (int u = 0; u < kRowsInFlight; ++u) {
+      const R* const cyrow = cy + static_cast<size_t>(iy + u) * K;  // wave-uniform: scalar loads
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) {
+        if (EXACT || k < K) {
+          const R w = cyrow[k];
+#pragma unroll
+          for (int c = 0; c < CPT; ++c) acc[c][k] += v[u][c] * w;
+        }
+      }
+    }
+  }
+  for (; iy < r1; ++iy) {
+    R v[CPT];
+    load_row(iy, v);
+    const R* const cyrow = cy + static_cast<size_t>(iy) * K;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
-      if (k < K) acc[k] += v * cyrow[k];
+      if (EXACT || k < K) {
+        const R w = cyrow[k];
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) acc[c][k] += v[c] * w;
+      }
     }
   }
 #pragma unroll
   for (int k = 0; k < KMAX; ++k) {
-    if (k < K) s_S[k * kSpatialPad + tid] = acc[k];
+    if (EXACT || k < K) {
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) s_S[k * kPad + tid * CPT + c] = acc[c][k];
+    }
   }
   __syncthreads();
 
-  const int ncols = (nx - ix0) < kBlock ? (nx - ix0) : kBlock;
+  // epilogue: contract the column sums with the x table, K^2 modes over kCols columns.
+  // (mode, column-group) threads: G = 256 / K^2 groups split the columns, then one add per mode.
+  const int ncols = (nx - ix0) < kCols ? (nx - ix0) : kCols;
   const int K2 = K * K;
   R* const out = partials + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * K2;
-  for (int m = tid; m < K2; m += kBlock) {
-    const int k1 = m % K, k2 = m / K;  // col = k2*K + k1 (basis.cpp:58-66)
-    const R* const cxr = cx + static_cast<size_t>(k1) * nx + ix0;
-    const R* const sr = s_S + k2 * kSpatialPad;
-    R s = R(0);
-    for (int c = 0; c < ncols; ++c) s += cxr[c] * sr[c];
-    out[m] = s;
+  if (K2 <= kBlock / 2) {
+    const int G = kBlock / K2;
+    const int m = tid % K2, g = tid / K2;
+    R* const s_part = s_S + K * kPad;  // [G][K2], behind the column sums
+    if (g < G) {
+      const int k1 = m % K, k2 = m / K;  // col = k2*K + k1 (basis.cpp:58-66)
+      const int per = (ncols + G - 1) / G;
+      const int cb = g * per, ce = (cb + per) < ncols ? (cb + per) : ncols;
+      const R* const cxr = cx + static_cast<size_t>(k1) * nx + ix0;
+      const R* const sr = s_S + k2 * kPad;
+      R s0 = R(0), s1 = R(0);
+      int c = cb;
+      for (; c + 1 < ce; c += 2) {
+        s0 += cxr[c] * sr[c];
+        s1 += cxr[c + 1] * sr[c + 1];
+      }
+      if (c < ce) s0 += cxr[c] * sr[c];
+      s_part[g * K2 + m] = s0 + s1;
+    }
+    __syncthreads();
+    if (tid < K2) {
+      R s = R(0);
+      for (int gg = 0; gg < G; ++gg) s += s_part[gg * K2 + tid];
+      out[tid] = s;
+    }
+  } else {
+    for (int m = tid; m < K2; m += kBlock) {
+      const int k1 = m % K, k2 = m / K;
+      const R* const cxr = cx + static_cast<size_t>(k1) * nx + ix0;
+      const R* const sr = s_S + k2 * kPad;
+      R s0 = R(0), s1 = R(0);
+      int c = 0;
+      for (; c + 1 < ncols; c += 2) {
+        s0 += cxr[c] * sr[c];
+        s1 += cxr[c + 1] * sr[c + 1];
+      }
+      if (c < ncols) s0 += cxr[c] * sr[c];
+      out[m] = s0 + s1;
+    }
   }
 }
 
@@ -208,13 +295,28 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const R* __restric
   }
 }
 
-inline int spatial_rows_per_tile(int nx, int ny)
+// columns per lane: two (16-byte fp64 loads) while the K x 513 LDS tile stays small
+inline int spatial_cpt(int K) { return K <= 16 ? 2 : 1; }
+
+// rows per workgroup: tall tiles amortise the K^2 epilogue (>= 64 rows) while leaving a few
+// workgroups per CU on large grids
+inline int spatial_rows_per_tile(int nx, int ny, int K)
 {
-  const int col_tiles = (nx + kBlock - 1) / kBlock;
-  int row_tiles = 1024 / col_tiles;  // ~4 workgroups per CU on 256 CUs
+  const int cols = kBlock * spatial_cpt(K);
+  const int col_tiles = (nx + cols - 1) / cols;
+  // tuning knob for tools/phik_prof.sh: EEA_PHIK_ROWS fixes the rows per tile
+  static const int forced = [] {
+    const char* v = std::getenv("EEA_PHIK_ROWS");
+    return v ? std::atoi(v) : 0;
+  }();
+  if (forced > 0) return forced < ny ? forced : ny;
+  // measured on MI355X (profiles/r01_phik_rows_sweep.txt): the K^2 x columns epilogue, not the
+  // streaming loop, bounds the kernel, so tiles are as tall as ~2 workgroups per CU allow
+  int row_tiles = 512 / col_tiles;
   if (row_tiles < 1) row_tiles = 1;
   int rpt = (ny + row_tiles - 1) / row_tiles;
-  if (rpt < 16) rpt = 16;
+  if (rpt < 32) rpt = 32;
+  if (rpt > ny) rpt = ny;
   return rpt;
 }
 
@@ -359,8 +461,9 @@ hipError_t launch_scale_by_inv(R* d_phi, size_t n, const R* d_sum, hipStream_t s
 
 size_t spatial_work_elems(int nx, int ny, int K)
 {
-  const int col_tiles = (nx + kBlock - 1) / kBlock;
-  const int rpt = spatial_rows_per_tile(nx, ny);
+  const int cols = kBlock * spatial_cpt(K);
+  const int col_tiles = (nx + cols - 1) / cols;
+  const int rpt = spatial_rows_per_tile(nx, ny, K);
   const int row_tiles = (ny + rpt - 1) / rpt;
   return static_cast<size_t>(col_tiles) * row_tiles * K * K;
 }
@@ -369,16 +472,15 @@ template <typename R>
 hipError_t launch_spatial_coeff(const R* d_phi, int nx, int ny, int K, const R* d_cx, const R* d_cy,
                                 R* d_work, R* d_phik, hipStream_t s)
 {
-  const int col_tiles = (nx + kBlock - 1) / kBlock;
-  const int rpt = spatial_rows_per_tile(nx, ny);
+  const int cpt = spatial_cpt(K);
+  const int cols = kBlock * cpt;
+  const int col_tiles = (nx + cols - 1) / cols;
+  const int rpt = spatial_rows_per_tile(nx, ny, K);
   const int row_tiles = (ny + rpt - 1) / rpt;
-  const size_t lds = static_cast<size_t>(K) * kSpatialPad * sizeof(R);
+  // column sums [K][cols + 1] plus the epilogue's per-group partials (<= 256 reals)
+  const size_t lds = (static_cast<size_t>(K) * (cols + 1) + kBlock) * sizeof(R);
   const dim3 grid(col_tiles, row_tiles);
-  if (K <= 16) {
-    hipLaunchKernelGGL((spatial_pass1_kernel<R, 16>), grid, dim3(kBlock), lds, s, d_phi, nx, ny, K, rpt,
-                       d_cx, d_cy, d_work);
-  } else {
-    auto kern = spatial_pass1_kernel<R, 32>;
+  auto launch = [&](auto kern) -> hipError_t {
     if (lds > 64 * 1024) {
       const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                                hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -386,8 +488,15 @@ hipError_t launch_spatial_coeff(const R* d_phi, int nx, int ny, int K, const R* 
       if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, grid, dim3(kBlock), lds, s, d_phi, nx, ny, K, rpt, d_cx, d_cy, d_work);
-  }
-  hipError_t e = hipGetLastError();
+    return hipGetLastError();
+  };
+  hipError_t e;
+  if (K == 5) e = launch(spatial_pass1_kernel<R, 5, 2, true>);
+  else if (K == 10) e = launch(spatial_pass1_kernel<R, 10, 2, true>);
+  else if (K == 20) e = launch(spatial_pass1_kernel<R, 20, 1, true>);
+  else if (K == 30) e = launch(spatial_pass1_kernel<R, 30, 1, true>);
+  else if (K <= 16) e = launch(spatial_pass1_kernel<R, 16, 2, false>);
+  else e = launch(spatial_pass1_kernel<R, 32, 1, false>);
   if (e != hipSuccess) return e;
   const int K2 = K * K;
   hipLaunchKernelGGL(sum_partials_kernel<R>, dim3((K2 + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
