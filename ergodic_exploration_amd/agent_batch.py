@@ -52,3 +52,26 @@ def gather_ck_ragged(ck_local, n_agents, group=None):
 def consensus_ck(ck_all):
     """Mean of the agents' c_k: the shared statistic of decentralised ergodic control."""
     return ck_all.mean(dim=0)
+
+
+# ---- grid-tiled phi_k (BASELINE config 5): the target grid is sharded by rows ----------------
+def grid_row_tile(ny, rank, world):
+    """Rows [row0, row0 + nrows) of the target grid owned by `rank`."""
+    row0, row1 = shard_range(ny, rank, world)
+    return row0, row1 - row0
+
+
+def reduce_phik(phik_partial, group=None, total_mass=None):
+    """Sum of the per-rank K^2 partials (one all-reduce over RCCL/xGMI; 7.2 KB at K = 30).  If
+    `total_mass` (this rank's sum of un-normalised target values) is given it rides in the same
+    collective and phi_k is divided by the global mass (Target::fill's normalisation,
+    reference target.cpp:87)."""
+    import torch
+    import torch.distributed as dist
+    if total_mass is None:
+        buf = phik_partial.clone()
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+        return buf
+    buf = torch.cat([phik_partial.reshape(-1), total_mass.reshape(1).to(phik_partial.dtype)])
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf[:-1] / buf[-1]

@@ -102,6 +102,9 @@ def lib():
         L.eea_set_target_gaussians.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p]
         L.eea_set_target_grid.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_int,
                                           C.c_double, C.c_double, C.c_void_p]
+        L.eea_spatial_coeff_rows.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_void_p,
+                                             C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        L.eea_set_phik.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double]
         L.eea_config_domain.argtypes = [C.c_void_p] + [C.c_double] * 4 + [C.POINTER(C.c_int), C.c_void_p]
         L.eea_get_phik.argtypes = [C.c_void_p, C.c_void_p]
         L.eea_get_lamdak.argtypes = [C.c_void_p, C.c_void_p]
@@ -195,6 +198,15 @@ class Engine:
         on_device = 1 if (hasattr(phi_vals, "is_cuda") and phi_vals.is_cuda) else 0
         check(lib().eea_set_target_grid(self.h, nx, ny, _ptr(phi_vals), on_device, lx, ly,
                                         C.c_void_p(stream or 0)))
+
+    def spatial_coeff_rows(self, nx, ny_total, row0, nrows, phi_rows, lx, ly, out_partial, stream=None):
+        """partial phi_k of the grid rows [row0, row0+nrows) held in the device tensor phi_rows"""
+        check(lib().eea_spatial_coeff_rows(self.h, nx, ny_total, row0, nrows, _ptr(phi_rows), lx, ly,
+                                           _ptr(out_partial), C.c_void_p(stream or 0)))
+
+    def set_phik(self, phik, lx, ly):
+        on_device = 1 if (hasattr(phik, "is_cuda") and phik.is_cuda) else 0
+        check(lib().eea_set_phik(self.h, _ptr(phik), on_device, lx, ly))
 
     def config_domain(self, bounds, stream=None):
         rebuilt = C.c_int(0)

@@ -443,6 +443,52 @@ eea_status eea_set_target_grid(eea_engine* e, unsigned nx, unsigned ny, const vo
                 : set_target_grid_impl<double>(e, nx, ny, phi_vals, on_device, s);
 }
 
+eea_status eea_spatial_coeff_rows(eea_engine* e, unsigned nx, unsigned ny_total, unsigned row0,
+                                  unsigned nrows, const void* d_phi_rows, double lx, double ly,
+                                  void* d_phik_partial, void* stream)
+{
+  if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (d_phi_rows == nullptr || d_phik_partial == nullptr || nx == 0 || ny_total == 0 || nrows == 0 ||
+      row0 + nrows > ny_total || !(lx > 0.0) || !(ly > 0.0)) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "bad grid tile");
+  }
+  eea_status st = use_device(e);
+  if (st != EEA_OK) return st;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const double keep_lx = e->lx, keep_ly = e->ly;
+  e->lx = lx;  // the tables are built for the tile's domain; the engine's own domain is restored
+  e->ly = ly;
+  st = e->f32 ? upload_axes_and_tables<float>(e, nx, ny_total, s) : upload_axes_and_tables<double>(e, nx, ny_total, s);
+  e->lx = keep_lx;
+  e->ly = keep_ly;
+  if (st != EEA_OK) return st;
+  if (e->f32) {
+    EEA_HIP(eea::launch_spatial_coeff<float>(static_cast<const float*>(d_phi_rows), nx, nrows, e->K,
+                                             static_cast<const float*>(e->d_cx.p),
+                                             static_cast<const float*>(e->d_cy.p) + static_cast<size_t>(row0) * e->K,
+                                             static_cast<float*>(e->d_work.p), static_cast<float*>(d_phik_partial), s));
+  } else {
+    EEA_HIP(eea::launch_spatial_coeff<double>(static_cast<const double*>(d_phi_rows), nx, nrows, e->K,
+                                              static_cast<const double*>(e->d_cx.p),
+                                              static_cast<const double*>(e->d_cy.p) + static_cast<size_t>(row0) * e->K,
+                                              static_cast<double*>(e->d_work.p), static_cast<double*>(d_phik_partial), s));
+  }
+  return EEA_OK;
+}
+
+eea_status eea_set_phik(eea_engine* e, const void* phik, int on_device, double lx, double ly)
+{
+  if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (phik == nullptr || !(lx > 0.0) || !(ly > 0.0)) return fail(EEA_ERR_INVALID_ARGUMENT, "bad phi_k");
+  eea_status st = use_device(e);
+  if (st != EEA_OK) return st;
+  EEA_HIP(hipMemcpy(e->d_phik.p, phik, e->rs * e->K2, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  e->lx = lx;
+  e->ly = ly;
+  e->have_phik = true;
+  return EEA_OK;
+}
+
 eea_status eea_config_domain(eea_engine* e, double xmin, double xmax, double ymin, double ymax,
                              int* rebuilt, void* stream)
 {

@@ -93,6 +93,16 @@ eea_status eea_set_target_gaussians(eea_engine* e, unsigned n, const double* mu,
 eea_status eea_set_target_grid(eea_engine* e, unsigned nx, unsigned ny, const void* phi_vals,
                                int on_device, double lx, double ly, void* stream);
 
+/* Grid-tiled form of the same (multi-GPU target grids, BASELINE config 5): this rank holds rows
+ * [row0, row0 + nrows) of an nx x ny_total grid in d_phi_rows (device, x fastest) and gets its
+ * K^2 partial sums in d_phik_partial (device, real).  The caller adds the partials of all ranks
+ * (one all-reduce of K^2 reals over RCCL) and installs the result with eea_set_phik. */
+eea_status eea_spatial_coeff_rows(eea_engine* e, unsigned nx, unsigned ny_total, unsigned row0,
+                                  unsigned nrows, const void* d_phi_rows, double lx, double ly,
+                                  void* d_phik_partial, void* stream);
+/* installs phi_k (K^2 reals, device pointer if on_device != 0) for a domain lx x ly */
+eea_status eea_set_phik(eea_engine* e, const void* phik, int on_device, double lx, double ly);
+
 /* ErgodicControl::configTarget (ergodic_control.hpp:362-416): refreshes map_pos; rebuilds
  * phi_k (Target::fill target.cpp:78-89 + Basis::spatialCoeff) only when the extent changed
  * by >= 1e-12.  *rebuilt (optional) reports whether the rebuild ran. */

@@ -81,3 +81,52 @@ def test_gather_ck_world2_gloo(n_agents, ragged):
     ref = _ck_for(range(n_agents))
     assert np.array_equal(ck_all, ref)
     assert np.allclose(mean, ref.mean(0), atol=1e-15)
+
+
+def _phik_partial_cpu(phi, nx, ny, row0, nrows, K, res):
+    """oracle: partial phi_k of a row tile (sum over its points only)"""
+    from oracle import pyoracle as po
+    lx, ly = (nx - 1) * res, (ny - 1) * res
+    g = po.phi_grid(nx, ny, res)
+    sl = slice(row0 * nx, (row0 + nrows) * nx)
+    return po.spatial_coeff(lx, ly, K, phi[sl], g[:, sl])
+
+
+def _tile_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    nx, ny, K, res = 33, 21, 6, 0.1
+    phi = np.random.default_rng(4).random(nx * ny)          # un-normalised target values
+    row0, nrows = ab.grid_row_tile(ny, rank, world)
+    part = torch.as_tensor(_phik_partial_cpu(phi, nx, ny, row0, nrows, K, res))
+    mass = torch.as_tensor(phi[row0 * nx:(row0 + nrows) * nx].sum())
+    pk = ab.reduce_phik(part, total_mass=mass)
+    pk_raw = ab.reduce_phik(part)
+    if rank == 0:
+        q.put((pk.numpy(), pk_raw.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grid_tiled_phik_world2_gloo():
+    from oracle import pyoracle as po
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tile_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    pk, pk_raw = q.get(timeout=60)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    nx, ny, K, res = 33, 21, 6, 0.1
+    phi = np.random.default_rng(4).random(nx * ny)
+    g = po.phi_grid(nx, ny, res)
+    full = po.spatial_coeff((nx - 1) * res, (ny - 1) * res, K, phi, g)
+    assert np.abs(pk_raw - full).max() < 1e-12
+    assert np.abs(pk - full / phi.sum()).max() < 1e-13
+    rows = [ab.grid_row_tile(ny, r, 3) for r in range(3)]
+    assert rows[0][0] == 0 and sum(n for _, n in rows) == ny

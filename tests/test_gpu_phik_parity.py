@@ -149,3 +149,36 @@ def test_basis_free_functions():
     # single point == fourierBasis
     x = np.array([[3.3], [1.7]])
     assert np.abs(capi.basis_traj_coeff(lx, ly, 5, x) - po.fourier_basis(lx, ly, 5, x[:, 0])).max() < 1e-15
+
+
+def test_row_tiles_sum_to_full_grid():
+    """Grid-tiled phi_k (config 5 sharding): partials of row tiles add up to the full-grid result,
+    and installing the sum with eea_set_phik drives control like the single-GPU path."""
+    from ergodic_exploration_amd import agent_batch as ab
+    nx, ny, K, res = 300, 257, 12, 0.1
+    lx, ly = (nx - 1) * res, (ny - 1) * res
+    rng = np.random.default_rng(11)
+    phi = rng.random(nx * ny)
+    phi /= phi.sum()
+    d_phi = torch.as_tensor(phi).cuda()
+    eng = _engine(K, res)
+    eng.set_target_grid(nx, ny, d_phi, lx, ly)
+    full = eng.phik()
+    total = torch.zeros(K * K, dtype=torch.float64, device="cuda")
+    for world in (2, 3, 8):
+        total.zero_()
+        for rank in range(world):
+            row0, nrows = ab.grid_row_tile(ny, rank, world)
+            part = torch.empty(K * K, dtype=torch.float64, device="cuda")
+            eng.spatial_coeff_rows(nx, ny, row0, nrows, d_phi[row0 * nx:(row0 + nrows) * nx], lx, ly, part)
+            total += part
+        torch.cuda.synchronize()
+        assert np.abs(total.cpu().numpy() - full).max() < 1e-13
+    eng2 = _engine(K, res)
+    eng2.set_phik(total, lx, ly)
+    assert np.array_equal(eng2.phik(), total.cpu().numpy())
+    u1 = eng.control((0.0, lx, 0.0, ly), [3.0, 4.0, 0.5])
+    u2 = eng2.control((0.0, lx, 0.0, ly), [3.0, 4.0, 0.5])
+    assert np.abs(u1 - u2).max() < 1e-9
+    eng.close()
+    eng2.close()
