@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--n-mem", type=int, default=0)
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-gather", action="store_true", help="skip the c_k all-gather (N > 1)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="run the c_k all-gather even with one rank (exercises the RCCL path on 1 GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per leg; 0 = skip")
     ap.add_argument("--latency", action="store_true", help="also time the B = 1 dependent-call mode")
     return ap.parse_args()
@@ -100,8 +102,12 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_gather
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     f32 = args.precision == "f32"
@@ -133,7 +139,7 @@ def main():
                         rng.uniform(-np.pi, np.pi, B * args.n_mem)], 1).reshape(B, args.n_mem, 3)
         d_mem = torch.as_tensor(mem, dtype=tdt).cuda()
         d_nmem = torch.full((B,), args.n_mem, dtype=torch.int32, device="cuda")
-    gather = world > 1 and not args.no_gather
+    gather = (world > 1 or args.force_gather) and not args.no_gather
     d_all = [torch.empty((world * B, K2), dtype=tdt, device="cuda") for _ in range(2)] if gather else None
 
     compute = torch.cuda.Stream()
@@ -161,7 +167,7 @@ def main():
     for i in range(args.warmup):
         step(i)
     drain()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -171,13 +177,13 @@ def main():
         step(args.warmup + i)
     ev1.record(compute)
     drain()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the kernel's own stream
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -247,7 +253,7 @@ def main():
                                    "note": "B = 1, dependent eea_control calls incl. host round trip"}
         print(json.dumps(out), flush=True)
     eng.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
