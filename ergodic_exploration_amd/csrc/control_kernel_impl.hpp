@@ -32,6 +32,13 @@
 
 // Phase stamps: compiled in only by control_kernel_timing.hip (EEA_TIMING); each wavefront's
 // lane 0 records the shader clock at the phase boundaries into p.dbg.
+// EEA_ABLATE = n builds a variant with one phase removed (marginal-cost measurement only; results
+// are wrong by construction): 1 gradient FMAs, 2 c_k tables + MFMA, 3 sin/cos evaluations,
+// 4 cross-wavefront scan exchange, 5 HBM loads/stores of the controls
+#ifndef EEA_ABLATE
+#define EEA_ABLATE 0
+#endif
+
 // waves per SIMD the K <= 12 instances are compiled for (register budget 512 / waves)
 #ifndef EEA_WAVES_SMALL_K
 #define EEA_WAVES_SMALL_K 4
@@ -73,8 +80,9 @@ struct LdsLayout
                            // (memory points first, rollout last: buffer.cpp:78-108)
   int g0, g1;              // barrier gradient rows 0,1 carried from the forward to the backward half, [T]
   int D;                   // lambda_k * (c_k - phi_k), [K^2]
-  int sw;                  // scan scratch + flags
-  int E;                   // per-wavefront MFMA tiles, then the cross-wave reduction of c_k
+  int sw;                  // scan scratch (one slot set per scan) + flags
+  int red;                 // cross-wavefront reduction of c_k, [4][K^2]
+  int E;                   // per-wavefront MFMA tiles
   int total;
 };
 
@@ -94,18 +102,19 @@ __host__ __device__ inline LdsLayout lds_layout(int T, int Nmax, int K)
   L.g0 = o; o += up4(T);
   L.g1 = o; o += up4(T);
   L.D = o; o += up4(K * K);
-  L.sw = o; o += 16;
+  L.sw = o; o += 48;
+  L.red = o; o += up4(kWaves * K * K);
   L.E = o;
-  const int tab = kWaves * wave_tab_elems(K);
-  const int red = kWaves * K * K;
-  o += up4(tab > red ? tab : red);
+  o += up4(kWaves * wave_tab_elems(K));
   L.total = o;
   return L;
 }
 
 // ---- workgroup scans on top of the DPP wavefront scan -------------------------------------
+// `reuse`: the scratch slots will be written again before another barrier (multi-chunk
+// horizons); otherwise every scan owns its slots and the trailing barrier is not needed
 template <typename R>
-__device__ __forceinline__ R block_scan(R v, R* s_w, R& total)
+__device__ __forceinline__ R block_scan(R v, R* s_w, R& total, bool reuse)
 {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // provably wave-uniform
@@ -119,13 +128,13 @@ __device__ __forceinline__ R block_scan(R v, R* s_w, R& total)
     if (w < wave) off += ws;
     tot += ws;
   }
-  __syncthreads();
+  if (reuse) __syncthreads();
   total = tot;
   return s + off;
 }
 
 template <typename R>
-__device__ __forceinline__ void block_scan2(R& a, R& b, R* s_w, R& tot_a, R& tot_b)
+__device__ __forceinline__ void block_scan2(R& a, R& b, R* s_w, R& tot_a, R& tot_b, bool reuse)
 {
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -147,7 +156,7 @@ __device__ __forceinline__ void block_scan2(R& a, R& b, R* s_w, R& tot_a, R& tot
     ta += wa;
     tb += wb;
   }
-  __syncthreads();
+  if (reuse) __syncthreads();
   a = sa + oa;
   b = sb + ob;
   tot_a = ta;
@@ -251,7 +260,8 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
   R* const s_D = sm + L.D;
   R* const s_sw = sm + L.sw;
   R* const s_E = sm + L.E;
-  int& s_bad = *reinterpret_cast<int*>(s_sw + 12);
+  int* const s_bad = reinterpret_cast<int*>(s_sw + 40);  // one flag per wavefront
+  const bool multi_chunk = T > kBlock;
 
   EEA_STAMP(0);
   int nmem = 0;
@@ -272,9 +282,6 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
     phi_m = p.phik[tid];
   }
 
-  if (tid == 0) s_bad = 0;
-  __syncthreads();
-
   // ---- controls: shift left by one column, last column zero (ergodic_control.hpp:233-234)
   {
     bool bad = false;
@@ -292,10 +299,12 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
       // SimpleCart::operator() rejects a lateral velocity (cart.hpp:167-170)
       if (MODEL == kModelSimpleCart && !(fabs(vy) < R(1.0e-12))) bad = true;
     }
-    if (bad) s_bad = 1;
+    // every wavefront publishes its own flag: no initialisation pass, one barrier
+    const bool wave_bad = __any(bad);
+    if (lane == 0) s_bad[wave] = wave_bad ? 1 : 0;
   }
   __syncthreads();
-  if (s_bad) {
+  if (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) {
     // the reference throws out of rk4_.solve; nothing else of this agent is touched
     if (tid == 0 && p.status != nullptr) p.status[b] = 2;  // EEA_ERR_INVALID_TWIST
     return;
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
         d = dt6 * (((w + R(2) * w) + R(2) * w) + w);
       }
       R tot_th;
-      const R inc = block_scan(d, s_sw, tot_th);
+      const R inc = block_scan(d, s_sw, tot_th, multi_chunk);
       EEA_STAMP(2);
 
       // pre-step heading (own prefix minus own increment), mid stage theta + dt (0.5 w) shared
@@ -360,7 +369,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
         dy = dt6 * (((k1y + R(2) * k2y) + R(2) * k2y) + k4y);
       }
       R tx, ty;
-      block_scan2(dx, dy, s_sw, tx, ty);
+      block_scan2(dx, dy, s_sw + 4, tx, ty, multi_chunk);
       if (act) {
         const R X = carry_x + dx, Y = carry_y + dy;
         if (traj != nullptr) {
@@ -524,8 +533,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
 
     // cross-wavefront reduction: red[wave][mode], mode = k2*K + k1 (basis.cpp:58-66)
     EEA_STAMP(6);
-    __syncthreads();  // every wavefront is done with its tile before the region is reused
-    R* const s_red = s_E;
+    R* const s_red = sm + L.red;  // its own region: no barrier between the tiles and the reduction
     {
       const int j = lane & 15;
 #pragma unroll
@@ -654,7 +662,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
 
       R h0 = dt * g0, h1 = dt * g1;
       R t0, t1;
-      block_scan2(h0, h1, s_sw, t0, t1);
+      block_scan2(h0, h1, s_sw + 12, t0, t1, multi_chunk);
       const R rho0 = c0 + h0, rho1 = c1r + h1;  // inclusive suffix: rho after step i
       EEA_STAMP(9);
 
@@ -677,7 +685,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
         qv = dt * (sE + R(0.5) * dt * sG);
       }
       R tot2;
-      const R inc2 = block_scan(qv, s_sw, tot2);
+      const R inc2 = block_scan(qv, s_sw + 20, tot2, multi_chunk);
       const R rho2 = c2 + inc2;
       EEA_STAMP(10);
 
