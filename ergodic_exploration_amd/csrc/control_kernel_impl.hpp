@@ -34,7 +34,8 @@
 // lane 0 records the shader clock at the phase boundaries into p.dbg.
 // EEA_ABLATE = n builds a variant with one phase removed (marginal-cost measurement only; results
 // are wrong by construction): 1 gradient FMAs, 2 c_k tables + MFMA, 3 sin/cos evaluations,
-// 4 cross-wavefront scan exchange, 5 HBM loads/stores of the controls
+// 4 cross-wavefront scan exchange, 5 HBM loads/stores of the controls, 6 table staging writes,
+// 7 MFMA operand reads + matrix instructions, 8 table recurrence
 #ifndef EEA_ABLATE
 #define EEA_ABLATE 0
 #endif
@@ -59,6 +60,17 @@ namespace eea
 {
 namespace
 {
+template <typename R>
+__device__ __forceinline__ void sc_pi(R t, R* s, R* c)
+{
+#if EEA_ABLATE == 3
+  *s = t;
+  *c = R(1) - t;
+#else
+  sincospi_r(t, s, c);
+#endif
+}
+
 constexpr int kWaves = kBlock / kWave;
 constexpr int kSub = 16;     // points staged per wavefront per MFMA pass
 
@@ -119,6 +131,10 @@ __device__ __forceinline__ R block_scan(R v, R* s_w, R& total, bool reuse)
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // provably wave-uniform
   const R s = wave_inclusive_scan_dpp(v);
+#if EEA_ABLATE == 4
+  total = s;
+  return s;
+#endif
   if (lane == kWave - 1) s_w[wave] = s;
   __syncthreads();
   R off = R(0), tot = R(0);
@@ -140,6 +156,13 @@ __device__ __forceinline__ void block_scan2(R& a, R& b, R* s_w, R& tot_a, R& tot
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const R sa = wave_inclusive_scan_dpp(a);
   const R sb = wave_inclusive_scan_dpp(b);
+#if EEA_ABLATE == 4
+  a = sa;
+  b = sb;
+  tot_a = sa;
+  tot_b = sb;
+  return;
+#endif
   if (lane == kWave - 1) {
     s_w[wave] = sa;
     s_w[kWaves + wave] = sb;
@@ -288,10 +311,13 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
     for (int i = tid; i < T; i += kBlock) {
       const int src = rollout_only ? i : i + 1;
       R vx = R(0), vy = R(0), w = R(0);
-      if (src < T) {
+      if (src < T && EEA_ABLATE != 5) {
         vx = ut[3 * src + 0];
         vy = ut[3 * src + 1];
         w = ut[3 * src + 2];
+      } else if (EEA_ABLATE == 5) {
+        vx = R(0.001) * i;
+        w = R(0.002) * i;
       }
       s_vx[i] = vx;
       s_vy[i] = vy;
@@ -344,13 +370,13 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
         const R th_post = carry_th + inc;
         if (traj != nullptr) traj[3 * i + 2] = wrap_pi_fast(th_post);
         R s, c;
-        sincospi_r(th_pre * inv_pi, &s, &c);
+        sc_pi(th_pre * inv_pi, &s, &c);
         s_ct[i] = c;
         s_st[i] = s;
-        sincospi_r((th_pre + dt * (R(0.5) * w)) * inv_pi, &smid, &cm);
+        sc_pi((th_pre + dt * (R(0.5) * w)) * inv_pi, &smid, &cm);
         // the heading after the chunk's / horizon's last step has no later thread to produce it
         if (tid == kBlock - 1 || i == T - 1) {
-          sincospi_r(th_post * inv_pi, &s, &c);
+          sc_pi(th_post * inv_pi, &s, &c);
           s_ct[i + 1] = c;
           s_st[i + 1] = s;
         }
@@ -381,10 +407,10 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
           const R x = X - p.map_x, y = Y - p.map_y;
           // one sin/cos pair per axis: angle = pi x / lx (basis.cpp:85 with k = 1)
           R s, c;
-          sincospi_r(x * p.inv_lx, &s, &c);
+          sc_pi(x * p.inv_lx, &s, &c);
           s_c1x[nmem + i] = c;
           s_s1x[nmem + i] = s;
-          sincospi_r(y * p.inv_ly, &s, &c);
+          sc_pi(y * p.inv_ly, &s, &c);
           s_c1y[nmem + i] = c;
           s_s1y[nmem + i] = s;
           // barrier gradient (ergodic_control.hpp:453-474), carried to the backward half
@@ -411,10 +437,10 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
     const R* const mem = p.mem_cols + 3 * static_cast<size_t>(p.mem_stride) * b;
     for (int j = tid; j < nmem; j += kBlock) {
       R s, c;
-      sincospi_r((mem[3 * j + 0] - p.map_x) * p.inv_lx, &s, &c);
+      sc_pi((mem[3 * j + 0] - p.map_x) * p.inv_lx, &s, &c);
       s_c1x[j] = c;
       s_s1x[j] = s;
-      sincospi_r((mem[3 * j + 1] - p.map_y) * p.inv_ly, &s, &c);
+      sc_pi((mem[3 * j + 1] - p.map_y) * p.inv_ly, &s, &c);
       s_c1y[j] = c;
       s_s1y[j] = s;
     }
@@ -439,7 +465,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
     const int sub = lane >> 4;  // which 16-point pass stages this lane's point
     const int pl = lane & 15;
 
-    for (int c0 = 0; c0 < N; c0 += kBlock) {
+    for (int c0 = 0; c0 < (EEA_ABLATE == 2 ? 0 : N); c0 += kBlock) {
       const int q = c0 + wave * kWave + lane;
       int nvalid = N - (c0 + wave * kWave);
       nvalid = nvalid < 0 ? 0 : (nvalid > kWave ? kWave : nvalid);
@@ -449,7 +475,13 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
 
       constexpr int KA = KC > 0 ? KC : 1;
       R cxr[KA], cyr[KA];
-      if (KC > 0) {
+      if (KC > 0 && EEA_ABLATE == 8) {
+#pragma unroll
+        for (int k = 0; k < KA; ++k) {
+          cxr[k] = c1;
+          cyr[k] = d1;
+        }
+      } else if (KC > 0) {
         // cos(k a) for k < K by the angle-addition recurrence; zero rows for padding points
         R ck = have ? R(1) : R(0), sk = R(0), dk = have ? R(1) : R(0), ek = R(0);
 #pragma unroll
@@ -467,7 +499,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
 
       // stage one pass of 16 points (this lane's point if it belongs to pass s)
       auto stage = [&](int s) {
-        if (sub == s) {
+        if (sub == s && EEA_ABLATE != 6) {
           R* const tx = tabx + pl * KS;
           R* const ty = taby + pl * KS;
           if (KC > 0) {
@@ -493,6 +525,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
       };
       // four points per matrix instruction: operand of lane l = element (4g + l/16) * KS + l%16
       auto mma_group = [&](int g) {
+        if (EEA_ABLATE == 7) return;
         const int off = (4 * g + sub) * KS + pl;
         R av[NT], bv[NT];
 #pragma unroll
@@ -597,7 +630,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
             }
           }
           R dk = R(1), ek = R(0);
-          for (int k2 = 0; k2 < KA; ++k2) {
+          for (int k2 = 0; k2 < (EEA_ABLATE == 1 ? 1 : KA); ++k2) {
             const R* const Drow = s_D + k2 * KA;
             // two partial sums per row product keep four independent FMA chains in flight
             R t1a = R(0), t1b = R(0), t2a = R(0), t2b = R(0);
@@ -708,9 +741,11 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
           const R ur = (p.Rinv[r] * n0 + p.Rinv[r + 3] * n1) + p.Rinv[r + 6] * n2;
           u[r] = clamp_std(ur, p.umin[r], p.umax[r]);
         }
-        ut[3 * i + 0] = u[0];
-        ut[3 * i + 1] = u[1];
-        ut[3 * i + 2] = u[2];
+        if (EEA_ABLATE != 5 || u[0] == R(123456)) {
+          ut[3 * i + 0] = u[0];
+          ut[3 * i + 1] = u[1];
+          ut[3 * i + 2] = u[2];
+        }
         if (p.rhot != nullptr) {
           R* const o = p.rhot + 3 * (static_cast<size_t>(T) * b + i);
           o[0] = rho0;
