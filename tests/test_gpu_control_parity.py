@@ -240,3 +240,37 @@ def test_full_size_batch_properties():
     torch.cuda.synchronize()
     assert torch.equal(d_ut1[0], d_ut[7])
     eng.close()
+
+
+def test_ragged_memory_and_extreme_sizes():
+    """Edge cases: per-agent memory lengths 0 / 3 / full stride in one batch (d_n_mem), the shortest
+    legal horizon (T = 2), a single mode (K = 1) and the largest supported basis (K = 32)."""
+    from tests.gpu_util import MODELS
+    rng = np.random.default_rng(77)
+    # ragged memory: one launch, different n_mem per agent
+    eng, ors = make_pair("omni", 10, 5.0, n_oracles=4)
+    B, T, K2, stride = 4, eng.T, eng.K2, 100
+    n_mem = np.array([0, 3, 100, 41], dtype=np.int32)
+    poses = random_poses(rng, B)
+    mem = random_poses(rng, B * stride).reshape(B, stride, 3)
+    ut0 = rng.uniform(-0.4, 0.4, (B, T, 3))
+    d_ut, d_u0 = dev(ut0), torch.empty((B, 3), dtype=torch.float64, device="cuda")
+    d_ck = torch.empty((B, K2), dtype=torch.float64, device="cuda")
+    eng.control_batch(B, dev(poses), d_ut, d_u0, mem_cols=dev(mem), n_mem=torch.as_tensor(n_mem).cuda(),
+                      mem_stride=stride, ck=d_ck)
+    torch.cuda.synchronize()
+    for b in range(B):
+        ors[b].ut = ut0[b].T
+        u, st = ors[b].control(MAP_BOUNDS, poses[b], mem[b, :n_mem[b]].T if n_mem[b] else None, stages=True)
+        assert np.abs(d_ck[b].cpu().numpy() - st["ck"]).max() < TOL_CK
+        assert np.abs(d_u0[b].cpu().numpy() - u).max() < TOL
+        assert np.abs(d_ut[b].cpu().numpy().T - st["ut"]).max() < TOL
+    eng.close()
+    # shortest legal horizon, one mode, largest basis
+    run_batch_vs_oracle("simple_cart", 10, 0.2, 0.1, B=2, n_mem=0, calls=2, seed=1)   # T = 2
+    run_batch_vs_oracle("omni", 1, 1.0, 0.1, B=2, n_mem=2, calls=2, seed=2)           # K = 1
+    run_batch_vs_oracle("omni", 32, 3.0, 0.1, B=1, n_mem=0, calls=1, seed=4)          # K = 32
+    # truncating steps_: horizon 0.3 / dt 0.1 -> 2 steps (SURVEY.md section 8 notation)
+    eng2, _ = make_pair("omni", 5, 0.3, n_oracles=0)
+    assert eng2.T == 2
+    eng2.close()
