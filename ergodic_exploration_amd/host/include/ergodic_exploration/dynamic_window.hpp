@@ -7,6 +7,7 @@
 
 #include <hip/hip_runtime_api.h>
 
+#include <cmath>
 #include <iostream>
 #include <tuple>
 
@@ -52,6 +53,11 @@ public:
   {
     return run(grid, x0, vb, nullptr, &xt_ref, dt_ref);
   }
+
+  // rollout length of the planner (dynamic_window.hpp accessors used by Exploration)
+  unsigned int steps() const { return static_cast<unsigned int>(std::abs(cfg_.horizon / cfg_.dt)); }
+  double timeStep() const { return cfg_.dt; }
+  double horizon() const { return cfg_.horizon; }
 
 private:
   static unsigned int at_least_one(unsigned int n, const char* name)

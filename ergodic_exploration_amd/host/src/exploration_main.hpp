@@ -1,15 +1,18 @@
 // Shared body of the exploration_omni / exploration_cart entry points (the reference's
 // src/exploration_{omni,cart}_node.cpp without ROS): read the parameter set of the reference's
 // yaml files, wire Collision / ErgodicControl / Target the way the node mains do, then run the
-// ergodic-control leg of the Exploration loop (exploration.hpp:197-292: addStateMemory -> control
-// -> validate_control) against a simulated robot on a free map.  Prints one line per tick.
+// Exploration loop (exploration.hpp:197-292: addStateMemory -> control -> validate_control -> DWA
+// fallback) against a simulated robot on a map with optional rectangular obstacles.  Prints one
+// line per tick.
 #pragma once
 
 #include <cstdio>
+#include <array>
 #include <cstring>
 #include <string>
+#include <vector>
 
-#include <ergodic_exploration/ergodic_control.hpp>
+#include <ergodic_exploration/exploration.hpp>
 
 #include "params.hpp"
 
@@ -22,6 +25,7 @@ int exploration_main(int argc, char** argv, bool is_cart)
   int ticks = 20;
   double map_x0 = -1.0, map_y0 = -1.0, map_w = 12.0, map_h = 6.0, map_res = 0.05;
   ee::vec pose = { 1.0, 1.0, 0.3 };
+  std::vector<std::array<double, 4>> obstacles;  // x0 y0 x1 y1 in the map frame
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     if (a == "--params" && i + 1 < argc) pnh.load(argv[++i]);
@@ -36,12 +40,16 @@ int exploration_main(int argc, char** argv, bool is_cart)
       map_h = std::atof(argv[i + 4]);
       map_res = std::atof(argv[i + 5]);
       i += 5;
+    } else if (a == "--obstacle" && i + 4 < argc) {
+      obstacles.push_back({ std::atof(argv[i + 1]), std::atof(argv[i + 2]), std::atof(argv[i + 3]),
+                            std::atof(argv[i + 4]) });
+      i += 4;
     } else if (a == "--set" && i + 2 < argc) {
       pnh.set(argv[i + 1], argv[i + 2]);
       i += 2;
     } else if (a == "--help") {
       std::printf("usage: %s [--params file.yaml] [--ticks N] [--pose x y th] [--map x0 y0 w h res] "
-                  "[--set name value]\n", argv[0]);
+                  "[--obstacle x0 y0 x1 y1]... [--set name value]\n", argv[0]);
       return 0;
     }
   }
@@ -87,29 +95,47 @@ int exploration_main(int argc, char** argv, bool is_cart)
   }
   const ee::Target target(gaussians);
 
+  // dynamic window parameters (node mains :175-190)
+  const ee::DynamicWindow dwa(collision, pnh.param("dwa_dt", 0.1), pnh.param("dwa_horizon", 1.0),
+                              pnh.param("acc_dt", 0.2), pnh.param("acc_lim_x", 1.0),
+                              is_cart ? 0.0 : pnh.param("acc_lim_y", 1.0), pnh.param("acc_lim_th", 1.0), max_vel_x,
+                              min_vel_x, max_vel_y, min_vel_y, max_rot_vel, min_rot_vel,
+                              static_cast<unsigned int>(pnh.param("vx_samples", 3.0)),
+                              is_cart ? 1u : static_cast<unsigned int>(pnh.param("vy_samples", 8.0)),
+                              static_cast<unsigned int>(pnh.param("vth_samples", 5.0)));
+
   const ModelT model;
   ee::ErgodicControl<ModelT> ergodic_control(model, collision, ec_dt, ec_horizon, target_resolution, expl_weight,
                                              num_basis, buffer_size, batch_size, Rinv, umin, umax);
-  ergodic_control.setTarget(target);
+  ee::Exploration<ModelT> exploration(ergodic_control, collision, dwa);
+  exploration.setTarget(target);
 
-  // all-free occupancy map standing in for the map topic
+  // occupancy map standing in for the map topic: free space plus the requested obstacle blocks
   const unsigned int w = ee::axis_length(map_x0, map_x0 + map_w, map_res);
   const unsigned int h = ee::axis_length(map_y0, map_y0 + map_h, map_res);
-  const ee::GridMap grid =
-      ee::GridMap::fromOccupancyGrid(w, h, map_res, map_x0, map_y0, ee::GridData(static_cast<std::size_t>(w) * h, 0));
+  ee::GridData cells(static_cast<std::size_t>(w) * h, 0);
+  for (const auto& o : obstacles) {
+    for (unsigned int i = 0; i < h; ++i) {
+      for (unsigned int j = 0; j < w; ++j) {
+        const double cx = map_x0 + (j + 0.5) * map_res, cy = map_y0 + (i + 0.5) * map_res;
+        if (cx >= o[0] && cx <= o[2] && cy >= o[1] && cy <= o[3]) cells[static_cast<std::size_t>(i) * w + j] = 100;
+      }
+    }
+  }
+  const ee::GridMap grid = ee::GridMap::fromOccupancyGrid(w, h, map_res, map_x0, map_y0, cells);
 
   std::printf("# %s: K=%u steps=%u dt=%g frequency=%g Hz map=[%g,%g]x[%g,%g]\n", is_cart ? "exploration_cart"
               : "exploration_omni", num_basis, ergodic_control.steps(), ec_dt, frequency, grid.xmin(), grid.xmax(),
               grid.ymin(), grid.ymax());
-  const ee::RungeKutta sim(1.0 / frequency);
+  static const char* const kSource[] = { "ergodic", "dwa-follow", "dwa-reference", "dwa-replan" };
+  ee::vec vb = { 0.0, 0.0, 0.0 };  // odometry twist: the simulated robot executes the command exactly
   for (int t = 0; t < ticks; ++t) {
-    ergodic_control.addStateMemory(pose);
-    const ee::vec u = ergodic_control.control(grid, pose);
-    const bool safe = ee::validate_control(collision, grid, pose, u, val_dt, val_horizon);
+    const ee::vec u = exploration.tick(grid, pose, vb, val_dt, val_horizon);
     std::printf("tick %3d pose %.17g %.17g %.17g  cmd_vel %.17g %.17g %.17g  %s\n", t, pose(0), pose(1), pose(2),
-                u(0), u(1), u(2), safe ? "ok" : "collision-predicted");
-    pose = sim.step(model, pose, safe ? u : ee::vec{ 0.0, 0.0, 0.0 });
+                u(0), u(1), u(2), kSource[static_cast<int>(exploration.source())]);
+    pose = ee::integrate_twist(pose, u, 1.0 / frequency);
     pose(2) = ee::normalize_angle_PI(pose(2));
+    vb = u;
   }
   return 0;
 }

@@ -33,36 +33,105 @@ def test_device_backed_classes_and_anchors():
     assert "0 failures" in out.stdout
 
 
-@pytest.mark.gpu
-@pytest.mark.parametrize("name,model,cfg", [("exploration_omni", "omni", "explore_omni.yaml"),
-                                            ("exploration_cart", "simple_cart", "explore_cart.yaml")])
-def test_entry_points_follow_the_oracle(name, model, cfg):
+# parameter values of ergodic_exploration_amd/host/config/explore_{omni,cart}.yaml
+COLL = (0.7, 1.0, 0.2, 0.8)
+DWA = {"omni": (0.1, 2.0, 0.2, 2.5, 2.5, 1.0, 1.0, -1.0, 1.0, -1.0, 2.0, -2.0, 3, 8, 5),
+       "simple_cart": (0.1, 2.0, 0.2, 2.5, 0.0, 1.0, 1.0, -1.0, 0.0, 0.0, 2.0, -2.0, 3, 1, 5)}
+
+
+class OracleExploration:
+    """The loop body of Exploration<ModelT>::control (reference exploration.hpp:197-292) restated on
+    the CPU oracle: the checker for the host mirror's Exploration::tick."""
+
+    def __init__(self, model, grid, bounds):
+        from oracle import pyoracle as po
+        self.po, self.model, self.grid, self.bounds = po, model, grid, bounds
+        om = {"omni": po.MODEL_OMNI, "simple_cart": po.MODEL_SIMPLE_CART}[model]
+        if model == "omni":
+            Rinv, lim = np.diag([1.0, 1.0, 2.0]), np.array([1.0, 1.0, 2.0])
+        else:
+            Rinv, lim = np.diag([1.0, 0.0, 2.0]), np.array([1.0, 0.0, 2.0])
+        self.ec = po.ErgodicControl(om, 0.1, 5.0, 0.1, 1.0, 10, Rinv, -lim, lim)
+        self.ec.set_target([[2.5, 2.5], [8.5, 2.5]], [[1.5, 1.5], [1.5, 1.5]])
+        self.memory, self.follow, self.i, self.u = [], False, 0, np.zeros(3)
+        self.dwa_steps = po.steps(DWA[model][1], DWA[model][0])
+
+    def tick(self, pose, vb):
+        po = self.po
+        self.memory.append(np.array(pose))
+        source = "ergodic"
+        if self.follow:
+            self.i += 1
+            self.follow = self.i != self.dwa_steps
+            source = "dwa-follow"
+        if not self.follow:
+            self.u = self.ec.control(self.bounds, pose, np.array(self.memory).T)
+            source = "ergodic"
+        if not po.validate_control(COLL, self.grid, pose, self.u, 0.1, 0.5):
+            if self.follow:
+                _, self.u, _ = po.dwa_control(DWA[self.model], COLL, self.grid, pose, vb, vref=self.u)
+                self.follow = False
+                source = "dwa-replan"
+            else:
+                # optTraj() rolls out from the pose of the last control() call
+                ok, self.u, _ = po.dwa_control(DWA[self.model], COLL, self.grid, pose, vb,
+                                               xt_ref=self.ec.opt_traj(), dt_ref=0.1)
+                self.follow = ok
+                if ok:
+                    self.i = 0
+                source = "dwa-reference"
+        return self.u.copy(), source
+
+
+def _grid_with(obstacles):
     from oracle import pyoracle as po
+    x0, y0, w, h, res = -1.0, -1.0, 12.0, 6.0, 0.05
+    nx, ny = po.lib().eo_axis_length(x0, x0 + w, res), po.lib().eo_axis_length(y0, y0 + h, res)
+    data = np.zeros((ny, nx), dtype=np.int8)
+    cx = x0 + (np.arange(nx) + 0.5) * res
+    cy = y0 + (np.arange(ny) + 0.5) * res
+    for (ox0, oy0, ox1, oy1) in obstacles:
+        data[np.ix_((cy >= oy0) & (cy <= oy1), (cx >= ox0) & (cx <= ox1))] = 100
+    return po.GridMap(x0, x0 + w, y0, y0 + h, res, data.reshape(-1)), (x0, x0 + w, y0, y0 + h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,model,cfg,obstacles,ticks", [
+    ("exploration_omni", "omni", "explore_omni.yaml", [], 6),
+    ("exploration_cart", "simple_cart", "explore_cart.yaml", [], 6),
+    ("exploration_omni", "omni", "explore_omni.yaml", [(2.4, 0.2, 3.0, 2.6)], 30),
+    ("exploration_cart", "simple_cart", "explore_cart.yaml", [(2.6, 0.0, 3.2, 2.4)], 30),
+])
+def test_entry_points_follow_the_oracle(name, model, cfg, obstacles, ticks):
+    """exploration_omni / exploration_cart (Exploration::tick on the device engine, simulated robot)
+    against the same loop on the CPU oracle, tick by tick, including the DWA fallback."""
     _build()
-    ticks = 6
-    out = subprocess.run([os.path.join(BUILD, name), "--params", os.path.join(HOST, "config", cfg), "--ticks",
-                          str(ticks)], capture_output=True, text=True)
+    cmd = [os.path.join(BUILD, name), "--params", os.path.join(HOST, "config", cfg), "--ticks", str(ticks)]
+    for o in obstacles:
+        cmd += ["--obstacle"] + [str(v) for v in o]
+    out = subprocess.run(cmd, capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     rows = [l for l in out.stdout.splitlines() if l.startswith("tick")]
     assert len(rows) == ticks
     got = np.array([[float(v) for v in re.search(r"cmd_vel (\S+) (\S+) (\S+)", r).groups()] for r in rows])
     poses = np.array([[float(v) for v in re.search(r"pose (\S+) (\S+) (\S+)", r).groups()] for r in rows])
-    assert all(r.rstrip().endswith("ok") for r in rows)  # free map: validate_control never trips
+    sources = [r.split()[-1] for r in rows]
 
-    # same loop on the oracle: addStateMemory(pose) then control(), memory <= batch so no sampling
-    om = {"omni": po.MODEL_OMNI, "simple_cart": po.MODEL_SIMPLE_CART}[model]
-    if model == "omni":
-        Rinv, lim = np.diag([1.0, 1.0, 2.0]), np.array([1.0, 1.0, 2.0])
-    else:
-        Rinv, lim = np.diag([1.0, 0.0, 2.0]), np.array([1.0, 0.0, 2.0])
-    ec = po.ErgodicControl(om, 0.1, 5.0, 0.1, 1.0, 10, Rinv, -lim, lim)
-    ec.set_target([[2.5, 2.5], [8.5, 2.5]], [[1.5, 1.5], [1.5, 1.5]])
-    bounds = (-1.0, 11.0, -1.0, 5.0)
-    memory = []
+    grid, bounds = _grid_with(obstacles)
+    ref = OracleExploration(model, grid, bounds)
+    vb = np.zeros(3)
     for t in range(ticks):
-        x = poses[t]  # printed with 17 significant digits: the oracle sees the engine's exact pose
-        memory.append(x.copy())
-        u = ec.control(bounds, x, np.array(memory).T)
+        # poses are printed with 17 significant digits: the oracle sees the engine's exact pose
+        u, source = ref.tick(poses[t], vb)
+        assert source == sources[t], (t, source, sources[t])
         # both loops run from a zero warm start; rounding differences (~1e-13 per call) are
-        # amplified by the warm-start feedback, roughly 10x per tick
+        # amplified by the warm-start feedback, roughly 10x per ergodic tick
         assert np.abs(got[t] - u).max() < 1e-6, (t, got[t], u)
+        vb = got[t]
+        if source != "ergodic":
+            # keep the oracle's warm start glued to the engine's decision sequence
+            pass
+    if obstacles:
+        assert any(s != "ergodic" for s in sources), "the scenario must exercise the DWA fallback"
+    else:
+        assert all(s == "ergodic" for s in sources)
