@@ -241,6 +241,32 @@ __device__ __forceinline__ R wave_inclusive_scan(R v)
   return v;
 }
 
+// ---- matrix cores: D = A(16x4) B(4x16) + C, one operand element per lane -----------------------
+// A[i][k]: lane = 16 k + i;  B[k][j]: lane = 16 k + j.  C/D: col = lane % 16 and
+// row = lane/16 + 4 r (f64) or 4 (lane/16) + r (f32), r = accumulator register.
+template <typename R>
+struct Mfma;
+template <>
+struct Mfma<double>
+{
+  using acc_t = double __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t run(double a, double b, acc_t c)
+  {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <>
+struct Mfma<float>
+{
+  using acc_t = float __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t run(float a, float b, acc_t c)
+  {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+
 // ---- DPP scans: row shifts inside 16-lane rows, row broadcasts across rows; no LDS traffic
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_or_zero(double v)

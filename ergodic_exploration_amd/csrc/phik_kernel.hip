@@ -15,6 +15,11 @@
 
 #include "common.hpp"
 
+// grid rows whose loads are issued before the first is consumed (memory-level parallelism per lane)
+#ifndef EEA_PHIK_ROWS_IN_FLIGHT
+#define EEA_PHIK_ROWS_IN_FLIGHT 4
+#endif
+
 namespace eea
 {
 namespace
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(kBlock) void spatial_pass1_kernel(const R* __restri
 {
   constexpr int kCols = kBlock * CPT;
   constexpr int kPad = kCols + 1;  // LDS row stride of the per-column sums
-  constexpr int kRowsInFlight = 4;
+  constexpr int kRowsInFlight = EEA_PHIK_ROWS_IN_FLIGHT;
   const int K = EXACT ? KMAX : K_rt;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   R* const s_S = reinterpret_cast<R*>(smem_raw);  // [K][kPad]
@@ -195,11 +200,24 @@ __global__ __launch_bounds__(kBlock) void spatial_pass1_kernel(const R* __restri
     }
   };
 
+  // software pipeline: the loads of the next group of rows are issued before the current group is
+  // consumed, so HBM latency overlaps the K FMAs per element instead of preceding them
   int iy = r0;
-  for (; iy + kRowsInFlight <= r1; iy += kRowsInFlight) {
-    R v[kRowsInFlight][CPT];
+  R vcur[kRowsInFlight][CPT], vnxt[kRowsInFlight][CPT];
+  const bool have_first = iy + kRowsInFlight <= r1;
+  if (have_first) {
 #pragma unroll
-    for (int u = 0; u < kRowsInFlight; ++u) load_row(iy + u, v[u]);
+    for (int u = 0; u < kRowsInFlight; ++u) load_row(iy + u, vnxt[u]);
+  }
+  for (; iy + kRowsInFlight <= r1; iy += kRowsInFlight) {
+#pragma unroll
+    for (int u = 0; u < kRowsInFlight; ++u)
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) vcur[u][c] = vnxt[u][c];
+    if (iy + 2 * kRowsInFlight <= r1) {
+#pragma unroll
+      for (int u = 0; u < kRowsInFlight; ++u) load_row(iy + kRowsInFlight + u, vnxt[u]);
+    }
 #pragma unroll
     for (int u = 0; u < kRowsInFlight; ++u) {
       const R* const cyrow = cy + static_cast<size_t>(iy + u) * K;  // wave-uniform: scalar loads
@@ -208,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void spatial_pass1_kernel(const R* __restri
         if (EXACT || k < K) {
           const R w = cyrow[k];
 #pragma unroll
-          for (int c = 0; c < CPT; ++c) acc[c][k] += v[u][c] * w;
+          for (int c = 0; c < CPT; ++c) acc[c][k] += vcur[u][c] * w;
         }
       }
     }
@@ -235,50 +253,63 @@ __global__ __launch_bounds__(kBlock) void spatial_pass1_kernel(const R* __restri
   }
   __syncthreads();
 
-  // epilogue: contract the column sums with the x table, K^2 modes over kCols columns.
-  // (mode, column-group) threads: G = 256 / K^2 groups split the columns, then one add per mode.
-  const int ncols = (nx - ix0) < kCols ? (nx - ix0) : kCols;
+  // epilogue: out[k2][k1] = sum_c S[k2][c] cx[k1][ix0 + c] -- a (K x kCols)(kCols x K) product, on the
+  // matrix cores: A[i = k2][k = column] from the LDS column sums, B[k = column][j = k1] from the x
+  // table (L2-resident), four columns per v_mfma_*_16x16x4, each wavefront a quarter of the column
+  // groups, then one add per mode across the four wavefronts.  Rows / columns beyond K are clamped
+  // to K - 1 (their products land in ignored accumulator entries); out-of-range grid columns carry
+  // zero sums.
+  using M = Mfma<R>;
+  using acc_t = typename M::acc_t;
+  constexpr int NT = (KMAX + 15) / 16;
+  const int lane = tid & (kWave - 1), wave = tid / kWave;
+  const int li = lane & 15, lk = lane >> 4;
+  acc_t macc[NT][NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) macc[a][b] = acc_t{ R(0), R(0), R(0), R(0) };
+  int rowA[NT], rowB[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int r = 16 * t + li;
+    rowA[t] = (r < K ? r : K - 1) * kPad;                             // k2 row of the column sums
+    rowB[t] = r < K ? r : K - 1;                                      // k1 row of the x table
+  }
+  for (int cg = wave; cg < kCols / 4; cg += kBlock / kWave) {
+    const int c = 4 * cg + lk;                   // this lane's column within the tile
+    int gx = ix0 + c;
+    gx = gx < nx ? gx : nx - 1;                  // clamped: the matching column sum is zero
+    R av[NT], bv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      av[t] = s_S[rowA[t] + c];
+      bv[t] = cx[static_cast<size_t>(rowB[t]) * nx + gx];
+    }
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int b = 0; b < NT; ++b) macc[a][b] = M::run(av[a], bv[b], macc[a][b]);
+  }
+  __syncthreads();  // every wavefront is done reading the column sums
+  R* const s_red = s_S;  // [4 wavefronts][K^2], reuses the column-sum region (K^2 * 4 <= K * kPad)
   const int K2 = K * K;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k2 = 16 * a + M::row(lane, r), k1 = 16 * b + li;
+        if (k2 < K && k1 < K) s_red[wave * K2 + k2 * K + k1] = macc[a][b][r];  // col = k2*K + k1
+      }
+  __syncthreads();
   R* const out = partials + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * K2;
-  if (K2 <= kBlock / 2) {
-    const int G = kBlock / K2;
-    const int m = tid % K2, g = tid / K2;
-    R* const s_part = s_S + K * kPad;  // [G][K2], behind the column sums
-    if (g < G) {
-      const int k1 = m % K, k2 = m / K;  // col = k2*K + k1 (basis.cpp:58-66)
-      const int per = (ncols + G - 1) / G;
-      const int cb = g * per, ce = (cb + per) < ncols ? (cb + per) : ncols;
-      const R* const cxr = cx + static_cast<size_t>(k1) * nx + ix0;
-      const R* const sr = s_S + k2 * kPad;
-      R s0 = R(0), s1 = R(0);
-      int c = cb;
-      for (; c + 1 < ce; c += 2) {
-        s0 += cxr[c] * sr[c];
-        s1 += cxr[c + 1] * sr[c + 1];
-      }
-      if (c < ce) s0 += cxr[c] * sr[c];
-      s_part[g * K2 + m] = s0 + s1;
-    }
-    __syncthreads();
-    if (tid < K2) {
-      R s = R(0);
-      for (int gg = 0; gg < G; ++gg) s += s_part[gg * K2 + tid];
-      out[tid] = s;
-    }
-  } else {
-    for (int m = tid; m < K2; m += kBlock) {
-      const int k1 = m % K, k2 = m / K;
-      const R* const cxr = cx + static_cast<size_t>(k1) * nx + ix0;
-      const R* const sr = s_S + k2 * kPad;
-      R s0 = R(0), s1 = R(0);
-      int c = 0;
-      for (; c + 1 < ncols; c += 2) {
-        s0 += cxr[c] * sr[c];
-        s1 += cxr[c + 1] * sr[c + 1];
-      }
-      if (c < ncols) s0 += cxr[c] * sr[c];
-      out[m] = s0 + s1;
-    }
+  for (int m = tid; m < K2; m += kBlock) {
+    R t = R(0);
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) t += s_red[w * K2 + m];
+    out[m] = t;
   }
 }
 
@@ -310,9 +341,9 @@ inline int spatial_rows_per_tile(int nx, int ny, int K)
     return v ? std::atoi(v) : 0;
   }();
   if (forced > 0) return forced < ny ? forced : ny;
-  // measured on MI355X (profiles/r01_phik_rows_sweep.txt): the K^2 x columns epilogue, not the
-  // streaming loop, bounds the kernel, so tiles are as tall as ~2 workgroups per CU allow
-  int row_tiles = 512 / col_tiles;
+  // measured on MI355X (profiles/r01_phik_rows_sweep.txt): with the epilogue on the matrix cores
+  // ~8 workgroups per CU (64-row tiles at K = 10, 128-row tiles at K = 20/30 on 8192^2) are best
+  int row_tiles = 2048 / col_tiles;
   if (row_tiles < 1) row_tiles = 1;
   int rpt = (ny + row_tiles - 1) / row_tiles;
   if (rpt < 32) rpt = 32;
