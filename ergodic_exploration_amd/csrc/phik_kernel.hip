@@ -183,6 +183,18 @@ __global__ __launch_bounds__(kBlock) void spatial_pass1_kernel(const R* __restri
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) acc[c][k] = R(0);
 
+  // the y-table rows of this tile, staged once: [rows_per_tile][KY] behind the column sums (KY = K
+  // rounded up to an even count so that every row starts 16-byte aligned).  In the streaming loop
+  // they are read back as LDS broadcasts, which can be issued ahead of the FMAs (scalar loads
+  // return out of order and force a full wait in front of every row).
+  constexpr int KY = (KMAX + 1) & ~1;
+  R* const s_cy = s_S + ((K * kPad + kBlock + 3) & ~3);
+  for (int e = tid; e < (r1 - r0) * K; e += kBlock) {
+    const int rr = e / K, kk = e - rr * K;
+    s_cy[rr * KY + kk] = cy[static_cast<size_t>(r0 + rr) * K + kk];
+  }
+  __syncthreads();
+
   auto load_row = [&](int iy, R (&v)[CPT]) {
     const R* const row = phi + static_cast<size_t>(iy) * nx;
     if (vec_ok) {
@@ -220,7 +232,7 @@ __global__ __launch_bounds__(kBlock) void spatial_pass1_kernel(const R* __restri
     }
 #pragma unroll
     for (int u = 0; u < kRowsInFlight; ++u) {
-      const R* const cyrow = cy + static_cast<size_t>(iy + u) * K;  // wave-uniform: scalar loads
+      const R* const cyrow = s_cy + (iy + u - r0) * KY;  // same address in every lane: broadcast
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) {
         if (EXACT || k < K) {
@@ -234,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void spatial_pass1_kernel(const R* __restri
   for (; iy < r1; ++iy) {
     R v[CPT];
     load_row(iy, v);
-    const R* const cyrow = cy + static_cast<size_t>(iy) * K;
+    const R* const cyrow = s_cy + (iy - r0) * KY;
 #pragma unroll
     for (int k = 0; k < KMAX; ++k) {
       if (EXACT || k < K) {
@@ -327,7 +339,17 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const R* __restric
 }
 
 // columns per lane: two (16-byte fp64 loads) while the K x 513 LDS tile stays small
-inline int spatial_cpt(int K) { return K <= 16 ? 2 : 1; }
+inline int spatial_cpt(int K)
+{
+  static const int forced = [] {
+    const char* v = std::getenv("EEA_PHIK_CPT");
+    return v ? std::atoi(v) : 0;
+  }();
+  if (forced == 2 && K == 10) return 2;  // the two-column variant is built for K = 10 only (A/B knob)
+  // measured (profiles/r01_phik_rows_sweep.txt): one column per lane halves the LDS per workgroup
+  // (7 instead of 3 workgroups per CU) and wins over the wider 16-byte loads of two columns
+  return 1;
+}
 
 // rows per workgroup: tall tiles amortise the K^2 epilogue (>= 64 rows) while leaving a few
 // workgroups per CU on large grids
@@ -341,9 +363,9 @@ inline int spatial_rows_per_tile(int nx, int ny, int K)
     return v ? std::atoi(v) : 0;
   }();
   if (forced > 0) return forced < ny ? forced : ny;
-  // measured on MI355X (profiles/r01_phik_rows_sweep.txt): with the epilogue on the matrix cores
-  // ~8 workgroups per CU (64-row tiles at K = 10, 128-row tiles at K = 20/30 on 8192^2) are best
-  int row_tiles = 2048 / col_tiles;
+  // measured on MI355X (profiles/r01_phik_rows_sweep.txt): 128-row tiles for K <= 20 and 64-row
+  // tiles for larger K are best on 8192^2 grids (~8 / ~16 workgroups per CU in total)
+  int row_tiles = (K > 20 ? 4096 : 2048) / col_tiles;
   if (row_tiles < 1) row_tiles = 1;
   int rpt = (ny + row_tiles - 1) / row_tiles;
   if (rpt < 32) rpt = 32;
@@ -509,7 +531,8 @@ hipError_t launch_spatial_coeff(const R* d_phi, int nx, int ny, int K, const R* 
   const int rpt = spatial_rows_per_tile(nx, ny, K);
   const int row_tiles = (ny + rpt - 1) / rpt;
   // column sums [K][cols + 1] plus the epilogue's per-group partials (<= 256 reals)
-  const size_t lds = (static_cast<size_t>(K) * (cols + 1) + kBlock) * sizeof(R);
+  const int KYmax = ((K <= 16 ? (K == 5 ? 5 : (K == 10 ? 10 : 16)) : (K == 20 ? 20 : (K == 30 ? 30 : 32))) + 1) & ~1;
+  const size_t lds = (static_cast<size_t>(K) * (cols + 1) + kBlock + 4 + static_cast<size_t>(rpt) * KYmax) * sizeof(R);
   const dim3 grid(col_tiles, row_tiles);
   auto launch = [&](auto kern) -> hipError_t {
     if (lds > 64 * 1024) {
@@ -522,11 +545,12 @@ hipError_t launch_spatial_coeff(const R* d_phi, int nx, int ny, int K, const R* 
     return hipGetLastError();
   };
   hipError_t e;
-  if (K == 5) e = launch(spatial_pass1_kernel<R, 5, 2, true>);
-  else if (K == 10) e = launch(spatial_pass1_kernel<R, 10, 2, true>);
+  if (K == 5) e = launch(spatial_pass1_kernel<R, 5, 1, true>);
+  else if (K == 10 && cpt == 2) e = launch(spatial_pass1_kernel<R, 10, 2, true>);
+  else if (K == 10) e = launch(spatial_pass1_kernel<R, 10, 1, true>);
   else if (K == 20) e = launch(spatial_pass1_kernel<R, 20, 1, true>);
   else if (K == 30) e = launch(spatial_pass1_kernel<R, 30, 1, true>);
-  else if (K <= 16) e = launch(spatial_pass1_kernel<R, 16, 2, false>);
+  else if (K <= 16) e = launch(spatial_pass1_kernel<R, 16, 1, false>);
   else e = launch(spatial_pass1_kernel<R, 32, 1, false>);
   if (e != hipSuccess) return e;
   const int K2 = K * K;
