@@ -7,21 +7,49 @@ namespace eea
 {
 namespace
 {
-template <typename R, int MODEL>
+// Threads per agent: one lane per horizon step up to 256; horizons of at most 64 / 128 steps take one /
+// two wavefronts per agent (no cross-wavefront exchange at all for one).  EEA_BLOCK overrides
+// (A/B experiments: longer horizons then run several steps per lane through the chunk loop).
+int control_threads(int T)
+{
+  static const int forced = [] {
+    const char* v = std::getenv("EEA_BLOCK");
+    const int b = v ? std::atoi(v) : 0;
+    return (b == 64 || b == 128 || b == 256) ? b : 0;
+  }();
+  if (forced) return forced;
+  return T <= 64 ? 64 : (T <= 128 ? 128 : 256);
+}
+
+template <typename R, int MODEL, int BLK>
 hipError_t launch_model(const ControlParams<R>& p, unsigned B, int Nmax, bool rollout_only,
                         size_t lds, hipStream_t stream)
 {
   switch (p.K) {
     case 5:
-      return launch_one<R, MODEL, 5>(p, B, Nmax, rollout_only, lds, stream);
+      return launch_one<R, MODEL, 5, BLK>(p, B, Nmax, rollout_only, lds, stream);
     case 10:
-      return launch_one<R, MODEL, 10>(p, B, Nmax, rollout_only, lds, stream);
+      return launch_one<R, MODEL, 10, BLK>(p, B, Nmax, rollout_only, lds, stream);
     case 20:
-      return launch_one<R, MODEL, 20>(p, B, Nmax, rollout_only, lds, stream);
+      return launch_one<R, MODEL, 20, BLK>(p, B, Nmax, rollout_only, lds, stream);
     case 30:
-      return launch_one<R, MODEL, 30>(p, B, Nmax, rollout_only, lds, stream);
+      return launch_one<R, MODEL, 30, BLK>(p, B, Nmax, rollout_only, lds, stream);
     default:
-      return launch_one<R, MODEL, 0>(p, B, Nmax, rollout_only, lds, stream);
+      return launch_one<R, MODEL, 0, BLK>(p, B, Nmax, rollout_only, lds, stream);
+  }
+}
+
+template <typename R, int MODEL>
+hipError_t launch_block(const ControlParams<R>& p, unsigned B, int Nmax, bool rollout_only,
+                        size_t lds, hipStream_t stream)
+{
+  switch (control_threads(p.T)) {
+    case 64:
+      return launch_model<R, MODEL, 64>(p, B, Nmax, rollout_only, lds, stream);
+    case 128:
+      return launch_model<R, MODEL, 128>(p, B, Nmax, rollout_only, lds, stream);
+    default:
+      return launch_model<R, MODEL, 256>(p, B, Nmax, rollout_only, lds, stream);
   }
 }
 }  // namespace
@@ -29,7 +57,7 @@ hipError_t launch_model(const ControlParams<R>& p, unsigned B, int Nmax, bool ro
 template <typename R>
 size_t control_lds_bytes(int T, int K, int n_mem_max, int /*chunk*/)
 {
-  return static_cast<size_t>(lds_layout(T, T + n_mem_max, K).total) * sizeof(R);
+  return static_cast<size_t>(lds_layout(T, T + n_mem_max, K, control_threads(T) / kWave).total) * sizeof(R);
 }
 
 template <typename R>
@@ -45,8 +73,8 @@ hipError_t launch_control(const ControlParams<R>& p, unsigned B, int model, int 
     return v ? std::atoi(v) : 0;
   }();
   if (pad_kib > 0 && lds + static_cast<size_t>(pad_kib) * 1024 <= 160 * 1024) lds += static_cast<size_t>(pad_kib) * 1024;
-  if (model == kModelOmni) return launch_model<R, kModelOmni>(p, B, Nmax, rollout_only, lds, stream);
-  return launch_model<R, kModelSimpleCart>(p, B, Nmax, rollout_only, lds, stream);
+  if (model == kModelOmni) return launch_block<R, kModelOmni>(p, B, Nmax, rollout_only, lds, stream);
+  return launch_block<R, kModelSimpleCart>(p, B, Nmax, rollout_only, lds, stream);
 }
 
 template size_t control_lds_bytes<double>(int, int, int, int);

@@ -71,7 +71,6 @@ __device__ __forceinline__ void sc_pi(R t, R* s, R* c)
 #endif
 }
 
-constexpr int kWaves = kBlock / kWave;
 constexpr int kSub = 16;     // points staged per wavefront per MFMA pass
 
 __host__ __device__ inline int up4(int n) { return (n + 3) & ~3; }
@@ -98,7 +97,8 @@ struct LdsLayout
   int total;
 };
 
-__host__ __device__ inline LdsLayout lds_layout(int T, int Nmax, int K)
+// waves: wavefronts per agent (workgroup size / 64)
+__host__ __device__ inline LdsLayout lds_layout(int T, int Nmax, int K, int waves)
 {
   LdsLayout L;
   int o = 0;
@@ -115,9 +115,9 @@ __host__ __device__ inline LdsLayout lds_layout(int T, int Nmax, int K)
   L.g1 = o; o += up4(T);
   L.D = o; o += up4(K * K);
   L.sw = o; o += 48;
-  L.red = o; o += up4(kWaves * K * K);
+  L.red = o; o += up4(waves * K * K);
   L.E = o;
-  o += up4(kWaves * wave_tab_elems(K));
+  o += up4(waves * wave_tab_elems(K));
   L.total = o;
   return L;
 }
@@ -125,7 +125,7 @@ __host__ __device__ inline LdsLayout lds_layout(int T, int Nmax, int K)
 // ---- workgroup scans on top of the DPP wavefront scan -------------------------------------
 // `reuse`: the scratch slots will be written again before another barrier (multi-chunk
 // horizons); otherwise every scan owns its slots and the trailing barrier is not needed
-template <typename R>
+template <typename R, int WAVES>
 __device__ __forceinline__ R block_scan(R v, R* s_w, R& total, bool reuse)
 {
   const int lane = threadIdx.x & (kWave - 1);
@@ -139,7 +139,7 @@ __device__ __forceinline__ R block_scan(R v, R* s_w, R& total, bool reuse)
   __syncthreads();
   R off = R(0), tot = R(0);
 #pragma unroll
-  for (int w = 0; w < kWaves; ++w) {
+  for (int w = 0; w < WAVES; ++w) {
     const R ws = s_w[w];
     if (w < wave) off += ws;
     tot += ws;
@@ -149,7 +149,7 @@ __device__ __forceinline__ R block_scan(R v, R* s_w, R& total, bool reuse)
   return s + off;
 }
 
-template <typename R>
+template <typename R, int WAVES>
 __device__ __forceinline__ void block_scan2(R& a, R& b, R* s_w, R& tot_a, R& tot_b, bool reuse)
 {
   const int lane = threadIdx.x & (kWave - 1);
@@ -165,13 +165,13 @@ __device__ __forceinline__ void block_scan2(R& a, R& b, R* s_w, R& tot_a, R& tot
 #endif
   if (lane == kWave - 1) {
     s_w[wave] = sa;
-    s_w[kWaves + wave] = sb;
+    s_w[WAVES + wave] = sb;
   }
   __syncthreads();
   R oa = R(0), ob = R(0), ta = R(0), tb = R(0);
 #pragma unroll
-  for (int w = 0; w < kWaves; ++w) {
-    const R wa = s_w[w], wb = s_w[kWaves + w];
+  for (int w = 0; w < WAVES; ++w) {
+    const R wa = s_w[w], wb = s_w[WAVES + w];
     if (w < wave) {
       oa += wa;
       ob += wb;
@@ -226,8 +226,9 @@ __device__ __forceinline__ R wrap_pi_fast(R rad)
   return rad - pi;
 }
 
-template <typename R, int MODEL, int KC>
-__global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel(
+// BLK: threads per agent (64, 128 or 256): short horizons take fewer wavefronts per agent
+template <typename R, int MODEL, int KC, int BLK>
+__global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
     const ControlParams<R> p, const int Nmax, const int rollout_only)
 {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -241,7 +242,8 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
   const int K = (KC > 0) ? KC : p.K;
   const int K2 = K * K;
   const int KS = table_stride(K);
-  const LdsLayout L = lds_layout(T, Nmax, K);
+  constexpr int WAVES = BLK / kWave;
+  const LdsLayout L = lds_layout(T, Nmax, K, WAVES);
 
   R* const s_vx = sm + L.vx;
   R* const s_vy = sm + L.vy;
@@ -258,7 +260,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
   R* const s_sw = sm + L.sw;
   R* const s_E = sm + L.E;
   int* const s_bad = reinterpret_cast<int*>(s_sw + 40);  // one flag per wavefront
-  const bool multi_chunk = T > kBlock;
+  const bool multi_chunk = T > BLK;
 
   EEA_STAMP(0);
   int nmem = 0;
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
   // ---- controls: shift left by one column, last column zero (ergodic_control.hpp:233-234)
   {
     bool bad = false;
-    for (int i = tid; i < T; i += kBlock) {
+    for (int i = tid; i < T; i += BLK) {
       const int src = rollout_only ? i : i + 1;
       R vx = R(0), vy = R(0), w = R(0);
       if (src < T && EEA_ABLATE != 5) {
@@ -304,7 +306,10 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
     if (lane == 0) s_bad[wave] = wave_bad ? 1 : 0;
   }
   __syncthreads();
-  if (s_bad[0] | s_bad[1] | s_bad[2] | s_bad[3]) {
+  int any_bad = 0;
+#pragma unroll
+  for (int w = 0; w < WAVES; ++w) any_bad |= s_bad[w];
+  if (any_bad) {
     // the reference throws out of rk4_.solve; nothing else of this agent is touched
     if (tid == 0 && p.status != nullptr) p.status[b] = 2;  // EEA_ERR_INVALID_TWIST
     return;
@@ -323,7 +328,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
   // position: x_i = x_{i-1} + dt/6 (k1 + 2 k2 + 2 k3 + k4) with k2 == k3 (integrator.hpp:176-184)
   {
     R carry_th = wrap_pi_fast(th0), carry_x = x0, carry_y = y0;
-    for (int base = 0; base < T; base += kBlock) {
+    for (int base = 0; base < T; base += BLK) {
       const int i = base + tid;
       const bool act = i < T;
       R d = R(0), w = R(0);
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
         d = dt6 * (((w + R(2) * w) + R(2) * w) + w);
       }
       R tot_th;
-      const R inc = block_scan(d, s_sw, tot_th, multi_chunk);
+      const R inc = block_scan<R, WAVES>(d, s_sw, tot_th, multi_chunk);
       EEA_STAMP(2);
 
       // pre-step heading (own prefix minus own increment), mid stage theta + dt (0.5 w) shared
@@ -349,7 +354,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
         s_st[i] = s;
         sc_pi((th_pre + dt * (R(0.5) * w)) * inv_pi, &smid, &cm);
         // the heading after the chunk's / horizon's last step has no later thread to produce it
-        if (tid == kBlock - 1 || i == T - 1) {
+        if (tid == BLK - 1 || i == T - 1) {
           sc_pi(th_post * inv_pi, &s, &c);
           s_ct[i + 1] = c;
           s_st[i + 1] = s;
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
         dy = dt6 * (((k1y + R(2) * k2y) + R(2) * k2y) + k4y);
       }
       R tx, ty;
-      block_scan2(dx, dy, s_sw + 4, tx, ty, multi_chunk);
+      block_scan2<R, WAVES>(dx, dy, s_sw + 4, tx, ty, multi_chunk);
       if (act) {
         const R X = carry_x + dx, Y = carry_y + dy;
         if (traj != nullptr) {
@@ -409,7 +414,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
   // sampled past states are prepended (buffer.cpp:78-108) and shifted like the rollout
   if (nmem > 0) {
     const R* const mem = p.mem_cols + 3 * static_cast<size_t>(p.mem_stride) * b;
-    for (int j = tid; j < nmem; j += kBlock) {
+    for (int j = tid; j < nmem; j += BLK) {
       R s, c;
       sc_pi((mem[3 * j + 0] - p.map_x) * p.inv_lx, &s, &c);
       s_c1x[j] = c;
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
     const int sub = lane >> 4;  // which 16-point pass stages this lane's point
     const int pl = lane & 15;
 
-    for (int c0 = 0; c0 < (EEA_ABLATE == 2 ? 0 : N); c0 += kBlock) {
+    for (int c0 = 0; c0 < (EEA_ABLATE == 2 ? 0 : N); c0 += BLK) {
       const int q = c0 + wave * kWave + lane;
       int nvalid = N - (c0 + wave * kWave);
       nvalid = nvalid < 0 ? 0 : (nvalid > kWave ? kWave : nvalid);
@@ -556,10 +561,10 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
     }
     __syncthreads();
     const R invN = R(1) / static_cast<R>(N);
-    for (int m = tid; m < K2; m += kBlock) {
+    for (int m = tid; m < K2; m += BLK) {
       R s = R(0);
 #pragma unroll
-      for (int w = 0; w < kWaves; ++w) s += s_red[w * K2 + m];
+      for (int w = 0; w < WAVES; ++w) s += s_red[w * K2 + m];
       const R c = invN * s;
       if (p.ck != nullptr) p.ck[static_cast<size_t>(b) * K2 + m] = c;
       // fourier_diff = lamdak % (ck - phik)  (ergodic_control.hpp:422)
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
   //   A = fdx(x_i, u_i) (omni.hpp:194-197, cart.hpp:183-186); then u_i = clamp(-Rinv B^T rho_i)
   {
     R c0 = R(0), c1r = R(0), c2 = R(0);  // rhoT_ = 0 (ergodic_control.hpp:203)
-    for (int base = 0; base < T; base += kBlock) {
+    for (int base = 0; base < T; base += BLK) {
       const int i = T - 1 - (base + tid);
       const bool act = i >= 0;
       R g0 = R(0), g1 = R(0);
@@ -669,7 +674,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
 
       R h0 = dt * g0, h1 = dt * g1;
       R t0, t1;
-      block_scan2(h0, h1, s_sw + 12, t0, t1, multi_chunk);
+      block_scan2<R, WAVES>(h0, h1, s_sw + 12, t0, t1, multi_chunk);
       const R rho0 = c0 + h0, rho1 = c1r + h1;  // inclusive suffix: rho after step i
       EEA_STAMP(9);
 
@@ -692,7 +697,7 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
         qv = dt * (sE + R(0.5) * dt * sG);
       }
       R tot2;
-      const R inc2 = block_scan(qv, s_sw + 20, tot2, multi_chunk);
+      const R inc2 = block_scan<R, WAVES>(qv, s_sw + 20, tot2, multi_chunk);
       const R rho2 = c2 + inc2;
       EEA_STAMP(10);
 
@@ -741,18 +746,18 @@ __global__ __launch_bounds__(kBlock, min_waves_per_simd(KC)) void control_kernel
   EEA_STAMP(11);
 }
 
-template <typename R, int MODEL, int KC>
+template <typename R, int MODEL, int KC, int BLK>
 hipError_t launch_one(const ControlParams<R>& p, unsigned B, int Nmax, bool rollout_only,
                       size_t lds, hipStream_t stream)
 {
-  auto kern = control_kernel<R, MODEL, KC>;
+  auto kern = control_kernel<R, MODEL, KC, BLK>;
   if (lds > 64 * 1024) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize,
                                              static_cast<int>(lds));
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3(B), dim3(kBlock), lds, stream, p, Nmax, rollout_only ? 1 : 0);
+  hipLaunchKernelGGL(kern, dim3(B), dim3(BLK), lds, stream, p, Nmax, rollout_only ? 1 : 0);
   return hipGetLastError();
 }
 

@@ -11,8 +11,8 @@ hipError_t launch_control_timing(const ControlParams<double>& p, unsigned B, int
   if (B == 0) return hipSuccess;
   if (p.K != 10) return hipErrorInvalidValue;
   const int Nmax = p.T + n_mem_max;
-  const size_t lds = static_cast<size_t>(lds_layout(p.T, Nmax, p.K).total) * sizeof(double);
-  if (model == kModelOmni) return launch_one<double, kModelOmni, 10>(p, B, Nmax, false, lds, stream);
-  return launch_one<double, kModelSimpleCart, 10>(p, B, Nmax, false, lds, stream);
+  const size_t lds = static_cast<size_t>(lds_layout(p.T, Nmax, p.K, 4).total) * sizeof(double);
+  if (model == kModelOmni) return launch_one<double, kModelOmni, 10, 256>(p, B, Nmax, false, lds, stream);
+  return launch_one<double, kModelSimpleCart, 10, 256>(p, B, Nmax, false, lds, stream);
 }
 }  // namespace eea

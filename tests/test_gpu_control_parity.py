@@ -99,6 +99,31 @@ def test_generic_basis_count_and_long_horizon():
     run_batch_vs_oracle("simple_cart", 12, 3.0, 0.1, B=3, n_mem=0, calls=2, seed=6)
 
 
+@pytest.mark.parametrize("steps", [63, 64, 65, 100, 128, 129])
+def test_wavefronts_per_agent_boundaries(steps):
+    """Horizons of <= 64 / <= 128 steps run on one / two wavefronts per agent (control_kernel.hip
+    control_threads); dt = 0.125 keeps horizon / dt exact around the boundaries."""
+    run_batch_vs_oracle("omni", 10, steps * 0.125, 0.125, B=3, n_mem=9, calls=2, seed=21)
+    run_batch_vs_oracle("simple_cart", 6, steps * 0.125, 0.125, B=2, n_mem=0, calls=2, seed=22)
+
+
+@pytest.mark.parametrize("block", ["64", "128"])
+def test_forced_threads_per_agent_long_horizon(block):
+    """EEA_BLOCK forces fewer threads per agent than horizon steps: several steps per lane through
+    the chunk loop (the engine reads the knob once per process, hence the subprocess)."""
+    import os
+    import subprocess
+    import sys
+    code = ("from tests import test_gpu_control_parity as t; "
+            "t.run_batch_vs_oracle('simple_cart', 10, 20.0, 0.1, B=3, n_mem=40, calls=2, seed=31); "
+            "t.run_batch_vs_oracle('omni', 7, 30.0, 0.1, B=2, n_mem=0, calls=2, seed=32)")
+    env = dict(os.environ, EEA_BLOCK=block)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_config3_shape_f64_and_f32():
     # BASELINE config 3: Omni, K = 20, dt 0.02, horizon 5 (T = 250), 256 x 256 target grid
     bounds = (0.0, 25.5, 0.0, 25.5)
