@@ -46,6 +46,9 @@ def parse():
                     help="run the c_k all-gather even with one rank (exercises the RCCL path on 1 GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per leg; 0 = skip")
     ap.add_argument("--latency", action="store_true", help="also time the B = 1 dependent-call mode")
+    ap.add_argument("--agent-groups", type=int, default=1,
+                    help="split the rank's agents into this many groups, each launched on its own HIP stream: the "
+                         "drain of one group's launch overlaps the fill of another's (agents are independent)")
     return ap.parse_args()
 
 
@@ -150,23 +153,36 @@ def main():
     cstream = compute.cuda_stream
     works = [None, None]
     all_gather = dist.all_gather_into_tensor if gather else None
+    # agent groups: contiguous slices of the batch, group 0 on the compute stream
+    G = max(1, min(args.agent_groups, B))
+    bounds = [(g * B) // G for g in range(G + 1)]
+    gstreams = [compute] + [torch.cuda.Stream() for _ in range(G - 1)]
+    gevents = [torch.cuda.Event() for _ in range(G)]
+
+    def sl(t, g):
+        return None if t is None else t[bounds[g]:bounds[g + 1]]
 
     def step(i):
         slot = i & 1
         if gather and works[slot] is not None:
             works[slot].wait()  # the gather that read this slot two steps ago has finished
-        eng.control_batch(B, d_pose, d_ut, d_u0, mem_cols=d_mem, n_mem=d_nmem, mem_stride=args.n_mem,
-                          ck=d_ck[slot], stream=cstream)
+        for g in range(G):
+            eng.control_batch(bounds[g + 1] - bounds[g], sl(d_pose, g), sl(d_ut, g), sl(d_u0, g),
+                              mem_cols=sl(d_mem, g), n_mem=sl(d_nmem, g), mem_stride=args.n_mem,
+                              ck=sl(d_ck[slot], g), stream=gstreams[g].cuda_stream)
         if gather:
             # RCCL all-gather of the per-agent c_k over xGMI; runs on the process group's
             # stream and overlaps with the next step's kernel
+            for g in range(1, G):  # the gather reads every group's c_k
+                gevents[g].record(gstreams[g])
+                compute.wait_event(gevents[g])
             works[slot] = all_gather(d_all[slot], d_ck[slot], async_op=True)
 
     def drain():
         for w in works:
             if w is not None:
                 w.wait()
-        torch.cuda.synchronize()
+        torch.cuda.synchronize()  # all streams of the device
 
     for i in range(args.warmup):
         step(i)

@@ -165,36 +165,44 @@ __device__ __forceinline__ void sincospi_r(R t, R* s, R* c);
 // fp64: n = rint(2t), r = t - n/2 in [-1/4, 1/4] (exact), Taylor series of sin(pi r), cos(pi r)
 // in r^2 (8 and 9 terms: truncation < 5e-17), then the quadrant swap / sign from n mod 4.
 // Max abs error 1.6e-16 against a 40-digit reference on 2.2e6 arguments (tools check in
-// DESIGN.md); about half the instructions of the device library's sincospi.  Huge
-// arguments (|t| >= 2^30, never produced by headings or in-domain positions) take the library path.
+// DESIGN.md); about half the instructions of the device library's sincospi.
+//  - the rounding adds 1.5 * 2^52: the sum's low word is n mod 2^32 (no conversion) for |t| < 2^50;
+//    larger arguments (never produced by headings or in-domain positions) are first reduced
+//    modulo 2 with v_fract (exact)
+//  - Horner steps are written as v_fma_f64 with the coefficient in a scalar register pair: the
+//    compiler's own choice (v_fmac_f64 on a copy of a coefficient held in vector registers) costs
+//    a second instruction per step and 32 vector registers per kernel
+__device__ __forceinline__ double fma_sc(double a, double b, double coeff)
+{
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(coeff));
+  return d;
+}
 template <>
 __device__ __forceinline__ void sincospi_r<double>(double t, double* s, double* c)
 {
-  if (__builtin_expect(!(fabs(t) < 1073741824.0), 0)) {
-    sincospi(t, s, c);
-    return;
-  }
-  const double n = rint(2.0 * t);
+  if (__builtin_expect(!(fabs(t) < 0x1p50), 0)) t = 2.0 * __builtin_amdgcn_fract(0.5 * t);
+  const double magic = 0x1.8p52;
+  const double nb = fma(t, 2.0, magic);
+  const int q = __double2loint(nb);
+  const double n = nb - magic;
   const double r = fma(n, -0.5, t);
-  const int q = static_cast<int>(n);
   const double z = r * r;
-  double ps = -0x1.6fadb9f155744p-16;
-  ps = fma(ps, z, 0x1.e8f434d018d63p-12);
-  ps = fma(ps, z, -0x1.e3074fde8871fp-8);
-  ps = fma(ps, z, 0x1.50783487ee782p-4);
-  ps = fma(ps, z, -0x1.32d2cce62bd86p-1);
-  ps = fma(ps, z, 0x1.466bc6775aae2p+1);
-  ps = fma(ps, z, -0x1.4abbce625be53p+2);
-  ps = fma(ps, z, 0x1.921fb54442d18p+1);
+  double ps = fma(z, -0x1.6fadb9f155744p-16, 0x1.e8f434d018d63p-12);
+  ps = fma_sc(ps, z, -0x1.e3074fde8871fp-8);
+  ps = fma_sc(ps, z, 0x1.50783487ee782p-4);
+  ps = fma_sc(ps, z, -0x1.32d2cce62bd86p-1);
+  ps = fma_sc(ps, z, 0x1.466bc6775aae2p+1);
+  ps = fma_sc(ps, z, -0x1.4abbce625be53p+2);
+  ps = fma_sc(ps, z, 0x1.921fb54442d18p+1);
   const double sv = ps * r;
-  double pc = 4.3030695870329473e-06;
-  pc = fma(pc, z, -0.0001046381049248457);
-  pc = fma(pc, z, 0.0019295743094039231);
-  pc = fma(pc, z, -0.025806891390014061);
-  pc = fma(pc, z, 0.23533063035889321);
-  pc = fma(pc, z, -1.3352627688545895);
-  pc = fma(pc, z, 4.0587121264167685);
-  pc = fma(pc, z, -4.934802200544679);
+  double pc = fma(z, 4.3030695870329473e-06, -0.0001046381049248457);
+  pc = fma_sc(pc, z, 0.0019295743094039231);
+  pc = fma_sc(pc, z, -0.025806891390014061);
+  pc = fma_sc(pc, z, 0.23533063035889321);
+  pc = fma_sc(pc, z, -1.3352627688545895);
+  pc = fma_sc(pc, z, 4.0587121264167685);
+  pc = fma_sc(pc, z, -4.934802200544679);
   pc = fma(pc, z, 1.0);
   const bool odd = (q & 1) != 0;
   const double s1 = odd ? pc : sv;
@@ -268,18 +276,22 @@ struct Mfma<float>
 };
 
 // ---- DPP scans: row shifts inside 16-lane rows, row broadcasts across rows; no LDS traffic
+// full row mask: lanes without a source read 0 through bound_ctrl (no "old" register to clear);
+// partial row mask (row broadcasts): the unselected rows keep old = 0
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_or_zero(double v)
 {
+  constexpr bool kBound = ROW_MASK == 0xf;
   int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, kBound);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, kBound);
   return __hiloint2double(hi, lo);
 }
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_or_zero(float v)
 {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+  constexpr bool kBound = ROW_MASK == 0xf;
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, kBound));
 }
 
 // wave64 inclusive sum scan: row_shr 1,2,4,8 then row_bcast15 (rows 1,3) and row_bcast31

@@ -42,7 +42,7 @@
 
 // waves per SIMD the K <= 12 instances are compiled for (register budget 512 / waves)
 #ifndef EEA_WAVES_SMALL_K
-#define EEA_WAVES_SMALL_K 4
+#define EEA_WAVES_SMALL_K 5
 #endif
 
 #ifdef EEA_TIMING
@@ -71,6 +71,20 @@ __device__ __forceinline__ void sc_pi(R t, R* s, R* c)
 #endif
 }
 
+// acc + k * v for a small mode number k: fp64 takes the constant from a scalar register pair
+template <typename R>
+__device__ __forceinline__ R fma_mode(R v, int k, R acc)
+{
+  return acc + static_cast<R>(k) * v;
+}
+template <>
+__device__ __forceinline__ double fma_mode<double>(double v, int k, double acc)
+{
+  double d;
+  asm("v_fma_f64 %0, %1, %3, %2" : "=v"(d) : "v"(v), "v"(acc), "s"(static_cast<double>(k)));
+  return d;
+}
+
 constexpr int kSub = 16;     // points staged per wavefront per MFMA pass
 
 __host__ __device__ inline int up4(int n) { return (n + 3) & ~3; }
@@ -92,8 +106,7 @@ struct LdsLayout
   int g0, g1;              // barrier gradient rows 0,1 carried from the forward to the backward half, [T]
   int D;                   // lambda_k * (c_k - phi_k), [K^2]
   int sw;                  // scan scratch (one slot set per scan) + flags
-  int red;                 // cross-wavefront reduction of c_k, [4][K^2]
-  int E;                   // per-wavefront MFMA tiles
+  int E;                   // per-wavefront MFMA tiles; afterwards each wavefront's c_k partials [K^2]
   int total;
 };
 
@@ -115,7 +128,6 @@ __host__ __device__ inline LdsLayout lds_layout(int T, int Nmax, int K, int wave
   L.g1 = o; o += up4(T);
   L.D = o; o += up4(K * K);
   L.sw = o; o += 48;
-  L.red = o; o += up4(waves * K * K);
   L.E = o;
   o += up4(waves * wave_tab_elems(K));
   L.total = o;
@@ -209,8 +221,8 @@ __device__ __forceinline__ void model_xy(R vx, R vy, R c, R s, R& fx, R& fy)
 }
 
 // Register budget: waves per SIMD the kernel is compiled for (VGPR + AGPR <= 512 / waves).
-// K <= 12 keeps the basis rows of the gradient within 5 waves per SIMD (5 workgroups per CU,
-// matching the LDS footprint); larger K needs the wider budget.
+// K <= 12 fits 5 waves per SIMD = 5 workgroups per CU, matching the LDS footprint (29.6 KB at
+// T = 200, K = 10, fp64); larger K needs the wider budget.
 constexpr int min_waves_per_simd(int KC) { return (KC > 20) ? 2 : ((KC > 12) ? 3 : EEA_WAVES_SMALL_K); }
 
 // wrap to [-pi, pi) like normalize_angle_PI (numerics.hpp:78-90) with the quotient taken by a
@@ -545,7 +557,10 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
 
     // cross-wavefront reduction: red[wave][mode], mode = k2*K + k1 (basis.cpp:58-66)
     EEA_STAMP(6);
-    R* const s_red = sm + L.red;  // its own region: no barrier between the tiles and the reduction
+    // each wavefront's partial sums go into its own tile region (K^2 <= wave_tab_elems(K)), in
+    // program order after its last operand read: no barrier between the tiles and the reduction
+    const int red_stride = wave_tab_elems(K);
+    R* const s_red = s_E;
     {
       const int j = lane & 15;
 #pragma unroll
@@ -556,7 +571,7 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
           for (int r = 0; r < 4; ++r) {
             const int k1 = 16 * a + M::row(lane, r);
             const int k2 = 16 * c + j;
-            if (a < nt && c < nt && k1 < K && k2 < K) s_red[wave * K2 + k2 * K + k1] = acc[a][c][r];
+            if (a < nt && c < nt && k1 < K && k2 < K) s_red[wave * red_stride + k2 * K + k1] = acc[a][c][r];
           }
     }
     __syncthreads();
@@ -564,7 +579,7 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
     for (int m = tid; m < K2; m += BLK) {
       R s = R(0);
 #pragma unroll
-      for (int w = 0; w < WAVES; ++w) s += s_red[w * K2 + m];
+      for (int w = 0; w < WAVES; ++w) s += s_red[w * red_stride + m];
       const R c = invN * s;
       if (p.ck != nullptr) p.ck[static_cast<size_t>(b) * K2 + m] = c;
       // fourier_diff = lamdak % (ck - phik)  (ergodic_control.hpp:422)
@@ -595,43 +610,60 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
         const R d1 = s_c1y[q], e1 = s_s1y[q];
         R Ex = R(0), Ey = R(0);
         if (KC > 0) {
+          // edx_x = -pi/lx sum_k1 k1 sin(a_k1 x) G(k1),  G(k1) = sum_k2 D(k1,k2) cos(b_k2 y)
+          // edx_y = -pi/ly sum_k2 k2 sin(b_k2 y) H(k2),  H(k2) = sum_k1 D(k1,k2) cos(a_k1 x)
+          // one pass over D: K accumulators G (independent chains) and one H per row; the mode
+          // numbers multiply through scalar-register constants (no per-mode factors in registers)
           constexpr int KA = KC > 0 ? KC : 1;
-          R cxa[KA], sxa[KA];
+          R cxa[KA], G[KA];
           {
             R ck = R(1), sk = R(0);
 #pragma unroll
             for (int k = 0; k < KA; ++k) {
               cxa[k] = ck;
-              sxa[k] = -(static_cast<R>(k) * p.pi_lx) * sk;
+              G[k] = R(0);
               const R cn = ck * c1 - sk * s1;
               sk = sk * c1 + ck * s1;
               ck = cn;
             }
           }
-          R dk = R(1), ek = R(0);
+          R dk = R(1), ek = R(0), accy = R(0);
+          constexpr int kRowUnroll = (KA <= 12 && sizeof(R) == 8) ? KA : 1;
+#pragma unroll kRowUnroll
           for (int k2 = 0; k2 < (EEA_ABLATE == 1 ? 1 : KA); ++k2) {
             const R* const Drow = s_D + k2 * KA;
-            // two partial sums per row product keep four independent FMA chains in flight
-            R t1a = R(0), t1b = R(0), t2a = R(0), t2b = R(0);
+            R ha = R(0), hb = R(0);
 #pragma unroll
             for (int k1 = 0; k1 + 1 < KA; k1 += 2) {
               const R da = Drow[k1], db = Drow[k1 + 1];
-              t1a += da * sxa[k1];
-              t2a += da * cxa[k1];
-              t1b += db * sxa[k1 + 1];
-              t2b += db * cxa[k1 + 1];
+              G[k1] += da * dk;
+              ha += da * cxa[k1];
+              G[k1 + 1] += db * dk;
+              hb += db * cxa[k1 + 1];
             }
             if (KA & 1) {
               const R da = Drow[KA - 1];
-              t1a += da * sxa[KA - 1];
-              t2a += da * cxa[KA - 1];
+              G[KA - 1] += da * dk;
+              ha += da * cxa[KA - 1];
             }
-            Ex += dk * (t1a + t1b);
-            Ey += (-(static_cast<R>(k2) * p.pi_ly) * ek) * (t2a + t2b);
+            if (k2 > 0) accy = fma_mode(ek * (ha + hb), k2, accy);
             const R dn = dk * d1 - ek * e1;
             ek = ek * d1 + dk * e1;
             dk = dn;
           }
+          R accx = R(0);
+          {
+            R ck = c1, sk = s1;  // k1 = 1
+#pragma unroll
+            for (int k = 1; k < KA; ++k) {
+              accx = fma_mode(sk * G[k], k, accx);
+              const R cn = ck * c1 - sk * s1;
+              sk = sk * c1 + ck * s1;
+              ck = cn;
+            }
+          }
+          Ex = -p.pi_lx * accx;
+          Ey = -p.pi_ly * accy;
         } else {
           R dk = R(1), ek = R(0);
           for (int k2 = 0; k2 < K; ++k2) {
