@@ -27,6 +27,7 @@ struct ControlParams
   int chunk;          // points staged per contraction pass (multiple of 64)
   unsigned mem_stride;
   R dt, dt6, lx, ly, map_x, map_y, expl_weight;  // dt6 = dt / 6 (integrator.hpp:183,193)
+  R half_dt;                                     // dt / 2, formed on the host: stays in scalar registers
   R pi_lx, pi_ly;     // PI / lx, PI / ly (basis.cpp:85)
   R inv_lx, inv_ly;   // 1 / lx, 1 / ly (sin/cos(pi x / lx) evaluation)
   R Rinv[9];          // column-major

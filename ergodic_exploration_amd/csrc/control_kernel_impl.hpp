@@ -726,7 +726,7 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
         // rho_{i+1} = rho_i - dt g_i (rows 0,1): the exclusive suffix from this thread's own values
         const R sE = a02 * (rho0 - dt * g0) + a12 * (rho1 - dt * g1);
         const R sG = a02 * g0 + a12 * g1;
-        qv = dt * (sE + R(0.5) * dt * sG);
+        qv = dt * (sE + p.half_dt * sG);
       }
       R tot2;
       const R inc2 = block_scan<R, WAVES>(qv, s_sw + 20, tot2, multi_chunk);
@@ -742,7 +742,12 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
           v2 = rho2;
         } else {  // cart.hpp:194-203
           v0 = cth * rho0 + sth * rho1;
-          v1 = R(0);
+          // B^T rho has an exact zero in row 1; opaque to the compiler so that the three
+          // Rinv(r,1) * (-0) products are formed here instead of living in registers (or
+          // scratch) across the whole backward half
+          R zero = R(0);
+          asm volatile("" : "+v"(zero));
+          v1 = zero;
           v2 = rho2;
         }
         const R n0 = -v0, n1 = -v1, n2 = -v2;

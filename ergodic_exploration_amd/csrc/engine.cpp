@@ -261,6 +261,7 @@ void fill_params(const eea_engine* e, eea::ControlParams<R>& p)
   p.chunk = e->chunk;
   p.dt = static_cast<R>(e->cfg.dt);
   p.dt6 = static_cast<R>(e->cfg.dt / 6.0);
+  p.half_dt = static_cast<R>(0.5 * e->cfg.dt);
   p.lx = static_cast<R>(e->lx);
   p.ly = static_cast<R>(e->ly);
   p.map_x = static_cast<R>(e->map_x);
@@ -782,6 +783,7 @@ eea_status eea_rk4_rollout(int device, int model, double dt, double horizon, con
     p.chunk = 64;
     p.dt = dt;
     p.dt6 = dt / 6.0;
+    p.half_dt = 0.5 * dt;
     p.lx = p.ly = 1.0;
     p.inv_lx = p.inv_ly = 1.0;
     p.pose = static_cast<const double*>(dpose.p);
