@@ -162,14 +162,18 @@ def main():
     def sl(t, g):
         return None if t is None else t[bounds[g]:bounds[g + 1]]
 
+    # per-group argument tuples, built once (tensor slicing costs host time on every step otherwise)
+    gargs = [[dict(B=bounds[g + 1] - bounds[g], pose=sl(d_pose, g), ut=sl(d_ut, g), u0=sl(d_u0, g),
+                   mem_cols=sl(d_mem, g), n_mem=sl(d_nmem, g), ck=sl(d_ck[slot], g),
+                   stream=gstreams[g].cuda_stream) for g in range(G)] for slot in range(2)]
+
     def step(i):
         slot = i & 1
         if gather and works[slot] is not None:
             works[slot].wait()  # the gather that read this slot two steps ago has finished
-        for g in range(G):
-            eng.control_batch(bounds[g + 1] - bounds[g], sl(d_pose, g), sl(d_ut, g), sl(d_u0, g),
-                              mem_cols=sl(d_mem, g), n_mem=sl(d_nmem, g), mem_stride=args.n_mem,
-                              ck=sl(d_ck[slot], g), stream=gstreams[g].cuda_stream)
+        for a in gargs[slot]:
+            eng.control_batch(a["B"], a["pose"], a["ut"], a["u0"], mem_cols=a["mem_cols"], n_mem=a["n_mem"],
+                              mem_stride=args.n_mem, ck=a["ck"], stream=a["stream"])
         if gather:
             # RCCL all-gather of the per-agent c_k over xGMI; runs on the process group's
             # stream and overlaps with the next step's kernel
