@@ -75,3 +75,13 @@ def reduce_phik(phik_partial, group=None, total_mass=None):
     buf = torch.cat([phik_partial.reshape(-1), total_mass.reshape(1).to(phik_partial.dtype)])
     dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
     return buf[:-1] / buf[-1]
+
+
+def reduce_occupancy_sums(sums_partial, group=None):
+    """phi_k of an occupancy target tiled by rows (Engine.spatial_coeff_occupancy_rows): one
+    all-reduce of the K^2 un-normalised sums; element 0 (mode (0,0): cos 0 = 1) of the total is the
+    sum of the cell entropies, i.e. the normaliser of the reference's target.cpp:87."""
+    import torch.distributed as dist
+    buf = sums_partial.clone()
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf / buf.reshape(-1)[0]

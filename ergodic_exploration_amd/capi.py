@@ -104,6 +104,11 @@ def lib():
                                           C.c_double, C.c_double, C.c_void_p]
         L.eea_spatial_coeff_rows.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint, C.c_void_p,
                                              C.c_double, C.c_double, C.c_void_p, C.c_void_p]
+        L.eea_set_target_occupancy.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_void_p, C.c_int,
+                                               C.c_double, C.c_double, C.c_void_p]
+        L.eea_spatial_coeff_occupancy_rows.argtypes = [C.c_void_p, C.c_uint, C.c_uint, C.c_uint, C.c_uint,
+                                                       C.c_void_p, C.c_double, C.c_double, C.c_void_p,
+                                                       C.c_void_p]
         L.eea_set_phik.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double]
         L.eea_config_domain.argtypes = [C.c_void_p] + [C.c_double] * 4 + [C.POINTER(C.c_int), C.c_void_p]
         L.eea_get_phik.argtypes = [C.c_void_p, C.c_void_p]
@@ -203,6 +208,17 @@ class Engine:
         """partial phi_k of the grid rows [row0, row0+nrows) held in the device tensor phi_rows"""
         check(lib().eea_spatial_coeff_rows(self.h, nx, ny_total, row0, nrows, _ptr(phi_rows), lx, ly,
                                            _ptr(out_partial), C.c_void_p(stream or 0)))
+
+    def set_target_occupancy(self, nx, ny, occ, lx, ly, stream=None):
+        """int8 occupancy cells (OccupancyGrid.data layout) -> entropy target -> phi_k, fused on the device"""
+        on_device = 1 if (hasattr(occ, "is_cuda") and occ.is_cuda) else 0
+        check(lib().eea_set_target_occupancy(self.h, nx, ny, _ptr(occ), on_device, lx, ly,
+                                             C.c_void_p(stream or 0)))
+
+    def spatial_coeff_occupancy_rows(self, nx, ny_total, row0, nrows, occ_rows, lx, ly, out_sums, stream=None):
+        """un-normalised coefficient sums of the occupancy rows [row0, row0+nrows) (device int8 tensor)"""
+        check(lib().eea_spatial_coeff_occupancy_rows(self.h, nx, ny_total, row0, nrows, _ptr(occ_rows), lx, ly,
+                                                     _ptr(out_sums), C.c_void_p(stream or 0)))
 
     def set_phik(self, phik, lx, ly):
         on_device = 1 if (hasattr(phik, "is_cuda") and phik.is_cuda) else 0

@@ -108,6 +108,13 @@ size_t spatial_work_elems(int nx, int ny, int K);
 template <typename R>
 hipError_t launch_spatial_coeff(const R* d_phi, int nx, int ny, int K, const R* d_cx, const R* d_cy,
                                 R* d_work, R* d_phik, hipStream_t s);
+// occupancy cells (int8) decoded through d_lut[256] inside the streaming kernel; d_raw receives the
+// un-normalised sums, launch_normalise_by_first divides by element 0
+template <typename R>
+hipError_t launch_spatial_coeff_cells(const int8_t* d_occ, int nx, int ny, int K, const R* d_cx,
+                                      const R* d_cy, const R* d_lut, R* d_work, R* d_raw, hipStream_t s);
+template <typename R>
+hipError_t launch_normalise_by_first(const R* d_raw, int K2, R* d_out, hipStream_t s);
 
 // Weighted basis sum over an arbitrary point list (Basis::trajCoeff / spatialCoeff):
 // out[m] = scale * sum_p w_p f_m(x_p, y_p); d_w may be null (w = 1).

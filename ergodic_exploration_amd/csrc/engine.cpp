@@ -88,7 +88,9 @@ struct eea_engine
   DevBuf d_phik, d_lamdak;
   // phi grid of the last rebuild
   unsigned nx = 0, ny = 0;
+  bool have_fill_grid = false;  // d_phi holds the Target::fill output of the last rebuild
   DevBuf d_phi, d_xs, d_ys, d_cx, d_cy, d_work, d_gauss, d_sum;
+  DevBuf d_lut, d_raw, d_occ;  // occupancy targets: decode table, un-normalised sums, staged cells
 
   // single-agent path
   hipStream_t stream1 = nullptr;
@@ -225,6 +227,7 @@ eea_status rebuild_phik(eea_engine* e, hipStream_t s)
                                        static_cast<R*>(e->d_work.p), static_cast<R*>(e->d_phik.p), s));
   EEA_HIP(hipStreamSynchronize(s));
   e->have_phik = true;
+  e->have_fill_grid = true;
   return EEA_OK;
 }
 
@@ -235,6 +238,7 @@ eea_status set_target_grid_impl(eea_engine* e, unsigned nx, unsigned ny, const v
   const size_t P = static_cast<size_t>(nx) * ny;
   e->nx = nx;
   e->ny = ny;
+  e->have_fill_grid = false;
   eea_status st = upload_axes_and_tables<R>(e, nx, ny, s);
   if (st != EEA_OK) return st;
   const R* d_phi = static_cast<const R*>(phi_vals);
@@ -316,6 +320,48 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
   } else {
     EEA_HIP(eea::launch_control<R>(p, B, e->cfg.model, n_mem_max, rollout_only, s));
   }
+  return EEA_OK;
+}
+
+// numerics.hpp:164-179 of the reference: information entropy of one occupancy cell, p = cell / 100
+// (unknown cells, p < 0, count 0.7; p == 0 or 1 count 1e-3)
+double cell_entropy(double p)
+{
+  if (std::fabs(0.0 - p) < 1.0e-12 || std::fabs(1.0 - p) < 1.0e-12) return 1e-3;
+  if (p < 0.0) return 0.7;
+  return -p * std::log(p) - (1.0 - p) * std::log(1.0 - p);
+}
+
+// decode table of the occupancy path, indexed by the cell's byte (int8 two's complement)
+template <typename R>
+eea_status upload_entropy_table(eea_engine* e, hipStream_t s)
+{
+  std::vector<R> lut(256);
+  for (int b = 0; b < 256; ++b) {
+    const int cell = static_cast<int>(static_cast<int8_t>(static_cast<uint8_t>(b)));
+    lut[b] = static_cast<R>(cell_entropy(static_cast<double>(cell) / 100.0));  // getCell: grid.cpp:176-184
+  }
+  EEA_HIP(e->d_lut.reserve(sizeof(R) * 256));
+  EEA_HIP(e->d_raw.reserve(sizeof(R) * e->K2));
+  EEA_HIP(hipMemcpyAsync(e->d_lut.p, lut.data(), sizeof(R) * 256, hipMemcpyHostToDevice, s));
+  EEA_HIP(hipStreamSynchronize(s));
+  return EEA_OK;
+}
+
+// un-normalised coefficient sums of rows [row0, row0 + nrows) of an occupancy grid
+template <typename R>
+eea_status occupancy_rows_impl(eea_engine* e, unsigned nx, unsigned ny_total, unsigned row0, unsigned nrows,
+                               const int8_t* d_occ_rows, void* d_raw_out, hipStream_t s)
+{
+  eea_status st = upload_axes_and_tables<R>(e, nx, ny_total, s);
+  if (st != EEA_OK) return st;
+  st = upload_entropy_table<R>(e, s);
+  if (st != EEA_OK) return st;
+  // the work buffer was sized for the whole grid; a row tile needs no more
+  EEA_HIP(eea::launch_spatial_coeff_cells<R>(d_occ_rows, nx, nrows, e->K, static_cast<const R*>(e->d_cx.p),
+                                             static_cast<const R*>(e->d_cy.p) + static_cast<size_t>(row0) * e->K,
+                                             static_cast<const R*>(e->d_lut.p), static_cast<R*>(e->d_work.p),
+                                             static_cast<R*>(d_raw_out), s));
   return EEA_OK;
 }
 
@@ -406,7 +452,8 @@ void eea_destroy(eea_engine* e)
     (void)hipStreamDestroy(e->stream1);
   }
   DevBuf* bufs[] = { &e->d_phik, &e->d_lamdak, &e->d_phi, &e->d_xs, &e->d_ys, &e->d_cx, &e->d_cy,
-                     &e->d_work, &e->d_gauss, &e->d_sum, &e->d_ut1, &e->d_traj1, &e->d_mem1 };
+                     &e->d_work, &e->d_gauss, &e->d_sum, &e->d_ut1, &e->d_traj1, &e->d_mem1,
+                     &e->d_lut, &e->d_raw, &e->d_occ };
   for (DevBuf* b : bufs) b->release();
   if (e->h_mail) (void)hipHostFree(e->h_mail);
   if (e->h_stage) (void)hipHostFree(e->h_stage);
@@ -475,6 +522,67 @@ eea_status eea_spatial_coeff_rows(eea_engine* e, unsigned nx, unsigned ny_total,
                                               static_cast<double*>(e->d_work.p), static_cast<double*>(d_phik_partial), s));
   }
   return EEA_OK;
+}
+
+eea_status eea_set_target_occupancy(eea_engine* e, unsigned nx, unsigned ny, const int8_t* occ,
+                                    int on_device, double lx, double ly, void* stream)
+{
+  if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (occ == nullptr || nx == 0 || ny == 0 || !(lx > 0.0) || !(ly > 0.0)) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "bad occupancy grid");
+  }
+  eea_status st = use_device(e);
+  if (st != EEA_OK) return st;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t P = static_cast<size_t>(nx) * ny;
+  const int8_t* d_occ = occ;
+  if (!on_device) {
+    EEA_HIP(e->d_occ.reserve(P));
+    EEA_HIP(hipMemcpyAsync(e->d_occ.p, occ, P, hipMemcpyHostToDevice, s));
+    EEA_HIP(hipStreamSynchronize(s));
+    d_occ = static_cast<const int8_t*>(e->d_occ.p);
+  }
+  e->lx = lx;
+  e->ly = ly;
+  e->nx = nx;
+  e->ny = ny;
+  e->have_fill_grid = false;
+  EEA_HIP(e->d_raw.reserve(e->rs * e->K2));
+  st = e->f32 ? occupancy_rows_impl<float>(e, nx, ny, 0, ny, d_occ, e->d_raw.p, s)
+              : occupancy_rows_impl<double>(e, nx, ny, 0, ny, d_occ, e->d_raw.p, s);
+  if (st != EEA_OK) return st;
+  if (e->f32) {
+    EEA_HIP(eea::launch_normalise_by_first<float>(static_cast<const float*>(e->d_raw.p), e->K2,
+                                                  static_cast<float*>(e->d_phik.p), s));
+  } else {
+    EEA_HIP(eea::launch_normalise_by_first<double>(static_cast<const double*>(e->d_raw.p), e->K2,
+                                                   static_cast<double*>(e->d_phik.p), s));
+  }
+  EEA_HIP(hipStreamSynchronize(s));
+  e->have_phik = true;
+  return EEA_OK;
+}
+
+eea_status eea_spatial_coeff_occupancy_rows(eea_engine* e, unsigned nx, unsigned ny_total, unsigned row0,
+                                            unsigned nrows, const int8_t* d_occ_rows, double lx, double ly,
+                                            void* d_sums_partial, void* stream)
+{
+  if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (d_occ_rows == nullptr || d_sums_partial == nullptr || nx == 0 || ny_total == 0 || nrows == 0 ||
+      row0 + nrows > ny_total || !(lx > 0.0) || !(ly > 0.0)) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "bad occupancy tile");
+  }
+  eea_status st = use_device(e);
+  if (st != EEA_OK) return st;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const double keep_lx = e->lx, keep_ly = e->ly;
+  e->lx = lx;  // the tables are built for the tile's domain; the engine's own domain is restored
+  e->ly = ly;
+  st = e->f32 ? occupancy_rows_impl<float>(e, nx, ny_total, row0, nrows, d_occ_rows, d_sums_partial, s)
+              : occupancy_rows_impl<double>(e, nx, ny_total, row0, nrows, d_occ_rows, d_sums_partial, s);
+  e->lx = keep_lx;
+  e->ly = keep_ly;
+  return st;
 }
 
 eea_status eea_set_phik(eea_engine* e, const void* phik, int on_device, double lx, double ly)
@@ -549,7 +657,9 @@ eea_status eea_target_grid_size(const eea_engine* e, unsigned* nx, unsigned* ny)
 eea_status eea_get_target_grid(eea_engine* e, double* h_phi_vals)
 {
   if (check_engine(e) != EEA_OK || h_phi_vals == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
-  if (e->d_phi.p == nullptr || e->nx == 0) return fail(EEA_ERR_NO_TARGET, "no target grid on the device");
+  if (e->d_phi.p == nullptr || e->nx == 0 || !e->have_fill_grid) {
+    return fail(EEA_ERR_NO_TARGET, "no Target::fill grid on the device (explicit / occupancy targets are not kept)");
+  }
   return download_reals(e, e->d_phi.p, static_cast<size_t>(e->nx) * e->ny, h_phi_vals);
 }
 

@@ -11,7 +11,10 @@
 // wave-uniform (scalar loads), and each lane keeps K running sums.  Two passes, no atomics:
 // pass 1 writes K^2 partials per workgroup, pass 2 adds them in a fixed order, so results are
 // deterministic run to run.
+#include <cstdint>
 #include <cstdlib>
+#include <string>
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -152,18 +155,32 @@ __global__ __launch_bounds__(kBlock) void scale_by_inv_kernel(R* __restrict__ ph
 }
 
 // pass 1: workgroup = (256 * CPT) grid columns x `rows_per_tile` grid rows.  Each lane owns CPT
-// adjacent columns (CPT = 2: one 16-byte load per row for fp64) and keeps K running sums per
-// column; four rows are in flight per iteration so that a wavefront has 4 KiB of loads outstanding.
+// adjacent columns (one vector load per row: 16 bytes for two fp64 / four fp32 columns, one dword
+// for four occupancy cells) and keeps K running sums per column; four rows are in flight per
+// iteration plus the prefetch of the next four.  More columns per lane divide the LDS traffic of
+// the y-table rows (K broadcast reads per row and wavefront, the bound for K >= 20 and for byte
+// input) by CPT.
 // EXACT: K == KMAX is known at compile time (no per-mode bounds tests in the streaming loop).
-template <typename R, int KMAX, int CPT, bool EXACT>
-__global__ __launch_bounds__(kBlock) void spatial_pass1_kernel(const R* __restrict__ phi, int nx, int ny,
+// IN: element type of the grid in HBM.  IN = R: target values.  IN = int8_t: occupancy cells
+// (nav_msgs::OccupancyGrid::data, grid.cpp:63-94) decoded through a 256-entry table in LDS
+// (`lut`, indexed by the cell's byte: entropy(cell / 100), numerics.hpp:164-179) when a row is
+// consumed -- one byte per cell read from HBM instead of a materialised fp64 target grid.
+template <typename R, int KMAX, int CPT, bool EXACT, typename IN = R>
+__global__ __launch_bounds__(kBlock) void spatial_pass1_kernel(const IN* __restrict__ phi, int nx, int ny,
                                                                int K_rt, int rows_per_tile,
                                                                const R* __restrict__ cx,
                                                                const R* __restrict__ cy,
+                                                               const R* __restrict__ lut,
                                                                R* __restrict__ partials)
 {
+  constexpr bool kCells = !std::is_same<IN, R>::value;
+  static_assert(CPT == 1 || CPT == 2 || CPT == 4, "columns per lane");
+  static_assert(kCells || CPT * sizeof(R) <= 16, "one vector load per row");
+  // a lane's row data: CPT reals, or the CPT cells packed into one int
+  constexpr int RAWN = kCells ? 1 : CPT;
+  using raw_t = typename std::conditional<kCells, int, R>::type;
   constexpr int kCols = kBlock * CPT;
-  constexpr int kPad = kCols + 1;  // LDS row stride of the per-column sums
+  constexpr int kPad = kBlock + 1;  // LDS row stride of the per-column sums (one column pass)
   constexpr int kRowsInFlight = EEA_PHIK_ROWS_IN_FLIGHT;
   const int K = EXACT ? KMAX : K_rt;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -174,8 +191,11 @@ __global__ __launch_bounds__(kBlock) void spatial_pass1_kernel(const R* __restri
   const int ix = ix0 + tid * CPT;
   const int r0 = blockIdx.y * rows_per_tile;
   const int r1 = (r0 + rows_per_tile) < ny ? (r0 + rows_per_tile) : ny;
-  // vector loads need the whole CPT group in range and a 16-byte aligned row pitch
+  // vector loads need the whole CPT group in range and an aligned row pitch
   const bool vec_ok = (CPT == 1) || ((ix + CPT <= nx) && ((nx % CPT) == 0));
+  int okmask = 0;  // bit c: column ix + c is inside the grid
+#pragma unroll
+  for (int c = 0; c < CPT; ++c) okmask |= (ix + c < nx) ? (1 << c) : 0;
 
   R acc[CPT][KMAX];
 #pragma unroll
@@ -193,29 +213,66 @@ __global__ __launch_bounds__(kBlock) void spatial_pass1_kernel(const R* __restri
     const int rr = e / K, kk = e - rr * K;
     s_cy[rr * KY + kk] = cy[static_cast<size_t>(r0 + rr) * K + kk];
   }
+  R* const s_lut = s_cy + ((rows_per_tile * KY + 3) & ~3);
+  if (kCells) s_lut[tid] = lut[tid];  // kBlock == 256 entries
   __syncthreads();
 
-  auto load_row = [&](int iy, R (&v)[CPT]) {
-    const R* const row = phi + static_cast<size_t>(iy) * nx;
-    if (vec_ok) {
-      if (CPT == 2) {
-        typedef R vec2 __attribute__((ext_vector_type(2)));
-        const vec2 t = *reinterpret_cast<const vec2*>(row + ix);
-        v[0] = t.x;
-        v[CPT - 1] = t.y;
+  auto decode = [&](const raw_t (&raw)[RAWN], int c) -> R {
+    if constexpr (kCells) {
+      const R e = s_lut[(raw[0] >> (8 * c)) & 0xff];
+      return ((okmask >> c) & 1) ? e : R(0);
+    } else {
+      return raw[c];
+    }
+  };
+  auto load_row = [&](int iy, raw_t (&v)[RAWN]) {
+    const IN* const row = phi + static_cast<size_t>(iy) * nx;
+    if constexpr (kCells) {
+      if (vec_ok) {
+        if (CPT == 4) v[0] = *reinterpret_cast<const int*>(row + ix);
+        else if (CPT == 2) v[0] = *reinterpret_cast<const unsigned short*>(row + ix);
+        else v[0] = (ix < nx) ? static_cast<int>(static_cast<unsigned char>(row[ix])) : 0;
       } else {
+        int packed = 0;
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) {
+          if (ix + c < nx) packed |= static_cast<int>(static_cast<unsigned char>(row[ix + c])) << (8 * c);
+        }
+        v[0] = packed;
+      }
+    } else if (vec_ok) {
+      if (CPT == 1) {
         v[0] = (ix < nx) ? row[ix] : R(0);
+      } else {
+        typedef R vecn __attribute__((ext_vector_type(CPT)));
+        const vecn t = *reinterpret_cast<const vecn*>(row + ix);
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) v[c] = t[c];
       }
     } else {
 #pragma unroll
       for (int c = 0; c < CPT; ++c) v[c] = (ix + c < nx) ? row[ix + c] : R(0);
     }
   };
+  auto consume_row = [&](int iy, const raw_t (&raw)[RAWN]) {
+    const R* const cyrow = s_cy + (iy - r0) * KY;  // same address in every lane: broadcast
+    R val[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) val[c] = decode(raw, c);
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (EXACT || k < K) {
+        const R w = cyrow[k];
+#pragma unroll
+        for (int c = 0; c < CPT; ++c) acc[c][k] += val[c] * w;
+      }
+    }
+  };
 
   // software pipeline: the loads of the next group of rows are issued before the current group is
   // consumed, so HBM latency overlaps the K FMAs per element instead of preceding them
   int iy = r0;
-  R vcur[kRowsInFlight][CPT], vnxt[kRowsInFlight][CPT];
+  raw_t vcur[kRowsInFlight][RAWN], vnxt[kRowsInFlight][RAWN];
   const bool have_first = iy + kRowsInFlight <= r1;
   if (have_first) {
 #pragma unroll
@@ -225,52 +282,27 @@ __global__ __launch_bounds__(kBlock) void spatial_pass1_kernel(const R* __restri
 #pragma unroll
     for (int u = 0; u < kRowsInFlight; ++u)
 #pragma unroll
-      for (int c = 0; c < CPT; ++c) vcur[u][c] = vnxt[u][c];
+      for (int c = 0; c < RAWN; ++c) vcur[u][c] = vnxt[u][c];
     if (iy + 2 * kRowsInFlight <= r1) {
 #pragma unroll
       for (int u = 0; u < kRowsInFlight; ++u) load_row(iy + kRowsInFlight + u, vnxt[u]);
     }
 #pragma unroll
-    for (int u = 0; u < kRowsInFlight; ++u) {
-      const R* const cyrow = s_cy + (iy + u - r0) * KY;  // same address in every lane: broadcast
-#pragma unroll
-      for (int k = 0; k < KMAX; ++k) {
-        if (EXACT || k < K) {
-          const R w = cyrow[k];
-#pragma unroll
-          for (int c = 0; c < CPT; ++c) acc[c][k] += vcur[u][c] * w;
-        }
-      }
-    }
+    for (int u = 0; u < kRowsInFlight; ++u) consume_row(iy + u, vcur[u]);
   }
   for (; iy < r1; ++iy) {
-    R v[CPT];
-    load_row(iy, v);
-    const R* const cyrow = s_cy + (iy - r0) * KY;
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      if (EXACT || k < K) {
-        const R w = cyrow[k];
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) acc[c][k] += v[c] * w;
-      }
-    }
+    raw_t raw[RAWN];
+    load_row(iy, raw);
+    consume_row(iy, raw);
   }
-#pragma unroll
-  for (int k = 0; k < KMAX; ++k) {
-    if (EXACT || k < K) {
-#pragma unroll
-      for (int c = 0; c < CPT; ++c) s_S[k * kPad + tid * CPT + c] = acc[c][k];
-    }
-  }
-  __syncthreads();
 
   // epilogue: out[k2][k1] = sum_c S[k2][c] cx[k1][ix0 + c] -- a (K x kCols)(kCols x K) product, on the
   // matrix cores: A[i = k2][k = column] from the LDS column sums, B[k = column][j = k1] from the x
   // table (L2-resident), four columns per v_mfma_*_16x16x4, each wavefront a quarter of the column
-  // groups, then one add per mode across the four wavefronts.  Rows / columns beyond K are clamped
-  // to K - 1 (their products land in ignored accumulator entries); out-of-range grid columns carry
-  // zero sums.
+  // groups, then one add per mode across the four wavefronts.  One pass per column slot of the
+  // lanes (the LDS buffer holds 256 column sums per mode whatever CPT is).  Rows / columns beyond K
+  // are clamped to K - 1 (their products land in ignored accumulator entries); out-of-range grid
+  // columns carry zero sums.
   using M = Mfma<R>;
   using acc_t = typename M::acc_t;
   constexpr int NT = (KMAX + 15) / 16;
@@ -288,20 +320,29 @@ __global__ __launch_bounds__(kBlock) void spatial_pass1_kernel(const R* __restri
     rowA[t] = (r < K ? r : K - 1) * kPad;                             // k2 row of the column sums
     rowB[t] = r < K ? r : K - 1;                                      // k1 row of the x table
   }
-  for (int cg = wave; cg < kCols / 4; cg += kBlock / kWave) {
-    const int c = 4 * cg + lk;                   // this lane's column within the tile
-    int gx = ix0 + c;
-    gx = gx < nx ? gx : nx - 1;                  // clamped: the matching column sum is zero
-    R av[NT], bv[NT];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      av[t] = s_S[rowA[t] + c];
-      bv[t] = cx[static_cast<size_t>(rowB[t]) * nx + gx];
+  for (int cp = 0; cp < CPT; ++cp) {
+    if (cp > 0) __syncthreads();  // the previous pass's operand reads are done
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      if (EXACT || k < K) s_S[k * kPad + tid] = acc[cp][k];
     }
+    __syncthreads();
+    for (int cg = wave; cg < kBlock / 4; cg += kBlock / kWave) {
+      const int t = 4 * cg + lk;                 // owner lane of this operand column
+      int gx = ix0 + t * CPT + cp;
+      gx = gx < nx ? gx : nx - 1;                // clamped: the matching column sum is zero
+      R av[NT], bv[NT];
 #pragma unroll
-    for (int a = 0; a < NT; ++a)
+      for (int q = 0; q < NT; ++q) {
+        av[q] = s_S[rowA[q] + t];
+        bv[q] = cx[static_cast<size_t>(rowB[q]) * nx + gx];
+      }
 #pragma unroll
-      for (int b = 0; b < NT; ++b) macc[a][b] = M::run(av[a], bv[b], macc[a][b]);
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) macc[a][b] = M::run(av[a], bv[b], macc[a][b]);
+    }
   }
   __syncthreads();  // every wavefront is done reading the column sums
   R* const s_red = s_S;  // [4 wavefronts][K^2], reuses the column-sum region (K^2 * 4 <= K * kPad)
@@ -313,6 +354,244 @@ __global__ __launch_bounds__(kBlock) void spatial_pass1_kernel(const R* __restri
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int k2 = 16 * a + M::row(lane, r), k1 = 16 * b + li;
+        if (k2 < K && k1 < K) s_red[wave * K2 + k2 * K + k1] = macc[a][b][r];  // col = k2*K + k1
+      }
+  __syncthreads();
+  R* const out = partials + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * K2;
+  for (int m = tid; m < K2; m += kBlock) {
+    R t = R(0);
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) t += s_red[w * K2 + m];
+    out[m] = t;
+  }
+}
+
+// pass 1 on the matrix cores: S[k2][col] = sum_rows cy[row][k2] * phi[row][col] is a GEMM whose
+// B operand (4 rows x 16 columns per v_mfma_*_16x16x4) is exactly what a wavefront loads from the
+// row-major grid: lane (k, j) = 16 k + j holds phi[row + k][col + j].  The grid therefore goes from
+// HBM into the matrix instruction without a transpose or an LDS stage; the A operand (the y table,
+// 4 rows x 16 modes) comes from L2.  Per lane and 4-row step: LPS vector loads of SPL columns
+// (16 bytes of values, or one dword of occupancy cells) feeding U = LPS * SPL accumulator sets
+// (4 NT registers each) instead of K scalar accumulators per column and K LDS broadcasts per row
+// -- the kernel stays on the HBM roofline for every K <= 32.  Rows beyond the tile and columns
+// beyond the grid enter as zeros; table rows / modes beyond K are clamped (their products land in
+// output rows that are never read).
+// Epilogue per wavefront: each accumulator set (16 modes-tile x 16 columns) goes through a small
+// LDS buffer into A-operand layout and is multiplied with the x table (second GEMM,
+// out[k2][k1] = sum_col S[k2][col] cx[k1][col]); then one add per mode across the wavefronts.
+template <typename R, int NT, typename IN>
+__global__ __launch_bounds__(kBlock) void spatial_stream_kernel(const IN* __restrict__ phi, int nx, int ny,
+                                                                int K, int rows_per_tile,
+                                                                const R* __restrict__ cx,
+                                                                const R* __restrict__ cy,
+                                                                const R* __restrict__ lut,
+                                                                R* __restrict__ partials)
+{
+  constexpr bool kCells = !std::is_same<IN, R>::value;
+  // columns per lane and load: 16 bytes of values; 8 (one 8-byte load) or 4 occupancy cells
+  constexpr int SPL = kCells ? (NT == 1 ? 8 : 4) : static_cast<int>(16 / sizeof(R));
+  // loads per lane and row step; two mode tiles (K > 16) double the accumulators per column, so one
+  // load keeps the kernel at 3-4 wavefronts per SIMD (measured: profiles/r01_phik_rows_sweep.txt)
+  constexpr int LPS = (kCells || NT == 2) ? 1 : 2;
+  constexpr int U = SPL * LPS;               // accumulator sets per lane
+  constexpr int kWaveCols = 16 * U;
+  constexpr int kCols = (kBlock / kWave) * kWaveCols;
+  // row steps per pipeline stage: enough bytes in flight per CU for the HBM latency at the
+  // occupancy the accumulators allow (cells are 8x smaller than fp64 values)
+  constexpr int G = kCells ? 8 : (NT == 2 && sizeof(R) == 8 ? 4 : 2);
+  constexpr int kSetPad = 17;                // LDS row stride of one accumulator set
+  using M = Mfma<R>;
+  using acc_t = typename M::acc_t;
+  using raw_t = typename std::conditional<kCells, int, R>::type;
+  constexpr int RAWN = kCells ? SPL / 4 : SPL;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  R* const sm = reinterpret_cast<R*>(smem_raw);
+  const int tid = threadIdx.x;
+  const int lane = tid & (kWave - 1), wave = tid / kWave;
+  const int lj = lane & 15, lk = lane >> 4;
+  R* const s_set = sm + wave * (16 * NT * kSetPad);             // [16 NT modes][17]
+  R* const s_lut = sm + (kBlock / kWave) * (16 * NT * kSetPad);  // [256], occupancy input only
+  if (kCells) s_lut[tid] = lut[tid];
+
+  const int ix0 = blockIdx.x * kCols + wave * kWaveCols;  // first column of this wavefront
+  const int r0 = blockIdx.y * rows_per_tile;
+  const int r1 = (r0 + rows_per_tile) < ny ? (r0 + rows_per_tile) : ny;
+  const bool pitch_ok = (nx % SPL) == 0;  // vector loads need an aligned row pitch
+
+  acc_t acc[U][NT];
+#pragma unroll
+  for (int u = 0; u < U; ++u)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[u][t] = acc_t{ R(0), R(0), R(0), R(0) };
+
+  // first column of this lane's load l; accumulator set u = l * SPL + e <-> column col_of(l) + e
+  auto col_of = [&](int l) { return ix0 + l * (16 * SPL) + SPL * lj; };
+
+  struct Stage
+  {
+    raw_t b[LPS][RAWN];
+    R a[NT];
+  };
+  // interior wavefront: every vector load of every full row step is inside the grid (wave-uniform)
+  const bool interior = pitch_ok && (ix0 + kWaveCols <= nx);
+  // fast form: no bounds tests, no divergence -- the loads of a whole pipeline stage issue back to back
+  auto load_step_fast = [&](int row_base, Stage& st) {
+    const int row = row_base + lk;
+    const IN* const prow = phi + static_cast<size_t>(row) * nx;
+#pragma unroll
+    for (int l = 0; l < LPS; ++l) {
+      const int c = col_of(l);
+      if constexpr (kCells) {
+        if constexpr (RAWN == 2) {
+          typedef int int2v __attribute__((ext_vector_type(2)));
+          const int2v v = *reinterpret_cast<const int2v*>(prow + c);
+          st.b[l][0] = v.x;
+          st.b[l][RAWN - 1] = v.y;
+        } else {
+          st.b[l][0] = *reinterpret_cast<const int*>(prow + c);
+        }
+      } else {
+        typedef R vecn __attribute__((ext_vector_type(SPL)));
+        const vecn v = *reinterpret_cast<const vecn*>(prow + c);
+#pragma unroll
+        for (int e = 0; e < SPL; ++e) st.b[l][e] = v[e];
+      }
+    }
+    const R* const crow = cy + static_cast<size_t>(row) * K;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int m = 16 * t + lj;
+      st.a[t] = crow[m < K ? m : K - 1];
+    }
+  };
+  // masked form (tile edges): rows beyond the tile and columns beyond the grid enter as zeros
+  auto load_step_edge = [&](int row_base, Stage& st) {
+    const int row = row_base + lk;
+    const bool row_ok = row < r1;
+    const int rowc = row_ok ? row : r1 - 1;
+    const IN* const prow = phi + static_cast<size_t>(rowc) * nx;
+#pragma unroll
+    for (int l = 0; l < LPS; ++l) {
+      const int c = col_of(l);
+      if constexpr (kCells) {
+#pragma unroll
+        for (int w = 0; w < RAWN; ++w) st.b[l][w] = 0;
+        if (row_ok) {
+#pragma unroll
+          for (int e = 0; e < SPL; ++e) {
+            if (c + e < nx) {
+              st.b[l][e / 4] |= static_cast<int>(static_cast<unsigned char>(prow[c + e])) << (8 * (e % 4));
+            }
+          }
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < SPL; ++e) st.b[l][e] = (row_ok && c + e < nx) ? prow[c + e] : R(0);
+      }
+    }
+    // A operand: lane (k, i) = cy[row + k][16 t + i]
+    const R* const crow = cy + static_cast<size_t>(rowc) * K;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int m = 16 * t + lj;
+      st.a[t] = crow[m < K ? m : K - 1];
+    }
+  };
+  auto load_group = [&](int row, Stage (&st)[G]) {
+    if (interior && row + 4 * G <= r1) {  // wave-uniform
+#pragma unroll
+      for (int g = 0; g < G; ++g) load_step_fast(row + 4 * g, st[g]);
+    } else {
+#pragma unroll
+      for (int g = 0; g < G; ++g) load_step_edge(row + 4 * g, st[g]);
+    }
+  };
+  if (kCells) __syncthreads();  // decode table staged
+  auto mma_step = [&](int row_base, const Stage& st) {
+    const bool row_ok = row_base + lk < r1;
+#pragma unroll
+    for (int l = 0; l < LPS; ++l) {
+#pragma unroll
+      for (int e = 0; e < SPL; ++e) {
+        R bv;
+        if constexpr (kCells) {
+          // columns beyond the grid / rows beyond the tile decode to 0
+          const R d = s_lut[(st.b[l][e / 4] >> (8 * (e % 4))) & 0xff];
+          bv = (row_ok && col_of(l) + e < nx) ? d : R(0);
+        } else {
+          bv = st.b[l][e];
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[l * SPL + e][t] = M::run(st.a[t], bv, acc[l * SPL + e][t]);
+      }
+    }
+  };
+
+  // software pipeline over groups of G row steps: the next group's loads are in flight while the
+  // current group feeds the matrix cores
+  Stage cur[G], nxt[G];
+  int row = r0;
+  load_group(row, nxt);
+  for (; row < r1; row += 4 * G) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) cur[g] = nxt[g];
+    if (row + 4 * G < r1) load_group(row + 4 * G, nxt);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (row + 4 * g < r1) mma_step(row + 4 * g, cur[g]);  // wave-uniform
+    }
+  }
+
+  // ---- epilogue: out[k2][k1] += sum over this wavefront's columns of S[k2][col] cx[k1][col]
+  acc_t macc[NT][NT];
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b) macc[a][b] = acc_t{ R(0), R(0), R(0), R(0) };
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    // accumulator set -> LDS, [mode][column]
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) s_set[(16 * t + M::row(lane, r)) * kSetPad + lj] = acc[u][t][r];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int l = u / SPL, e = u % SPL;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      // A[i = k2][k = column 4 g4 + k], B[k = column][j = k1]
+      const int cset = 4 * g4 + lk;                               // column index inside the set
+      int gx = ix0 + l * (16 * SPL) + SPL * cset + e;             // its grid column
+      gx = gx < nx ? gx : nx - 1;                                 // clamped: that column's sums are zero
+      R av[NT], bv[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        av[t] = s_set[(16 * t + lj) * kSetPad + cset];
+        const int k1 = 16 * t + lj;
+        bv[t] = cx[static_cast<size_t>(k1 < K ? k1 : K - 1) * nx + gx];
+      }
+#pragma unroll
+      for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) macc[a][b] = M::run(av[a], bv[b], macc[a][b]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  __syncthreads();  // all wavefronts are done with their set buffers
+  R* const s_red = sm;  // [4 wavefronts][K^2] <= 4 * (16 NT)^2 reals, fits the set buffers + table
+  const int K2 = K * K;
+#pragma unroll
+  for (int a = 0; a < NT; ++a)
+#pragma unroll
+    for (int b = 0; b < NT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k2 = 16 * a + M::row(lane, r), k1 = 16 * b + lj;
         if (k2 < K && k1 < K) s_red[wave * K2 + k2 * K + k1] = macc[a][b][r];  // col = k2*K + k1
       }
   __syncthreads();
@@ -338,24 +617,35 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const R* __restric
   }
 }
 
-// columns per lane: two (16-byte fp64 loads) while the K x 513 LDS tile stays small
-inline int spatial_cpt(int K)
+// columns per lane.  kind: 0 = fp64 values, 1 = fp32 values, 2 = occupancy cells (bytes).
+// More columns per lane divide the y-table LDS reads per element; the accumulators (CPT * K reals
+// per lane) bound it.  EEA_PHIK_CPT overrides within what is built (tools/phik_prof.sh sweeps).
+constexpr int kKindF64 = 0, kKindF32 = 1, kKindCells = 2;
+inline int spatial_cpt_max(int K, int kind)
+{
+  if (!(K == 5 || K == 10 || K == 20 || K == 30)) return 1;  // run-time K instances: one column
+  if (kind == kKindF64) return 2;
+  return K <= 10 ? 4 : 2;
+}
+inline int spatial_cpt(int K, int kind)
 {
   static const int forced = [] {
     const char* v = std::getenv("EEA_PHIK_CPT");
     return v ? std::atoi(v) : 0;
   }();
-  if (forced == 2 && K == 10) return 2;  // the two-column variant is built for K = 10 only (A/B knob)
-  // measured (profiles/r01_phik_rows_sweep.txt): one column per lane halves the LDS per workgroup
-  // (7 instead of 3 workgroups per CU) and wins over the wider 16-byte loads of two columns
-  return 1;
+  const int cmax = spatial_cpt_max(K, kind);
+  if (forced == 1 || forced == 2 || forced == 4) return forced < cmax ? forced : cmax;
+  // measured on MI355X (profiles/r01_phik_rows_sweep.txt)
+  if (kind == kKindCells) return cmax;
+  if (kind == kKindF32) return K >= 20 ? 2 : 1;
+  return K >= 20 ? 2 : 1;
 }
 
-// rows per workgroup: tall tiles amortise the K^2 epilogue (>= 64 rows) while leaving a few
-// workgroups per CU on large grids
-inline int spatial_rows_per_tile(int nx, int ny, int K)
+// rows per workgroup: tall tiles amortise the K^2 epilogue while leaving a few workgroups per CU
+// on large grids; the tile's y-table rows live in LDS, which caps the height
+inline int spatial_rows_per_tile(int nx, int ny, int K, int cpt)
 {
-  const int cols = kBlock * spatial_cpt(K);
+  const int cols = kBlock * cpt;
   const int col_tiles = (nx + cols - 1) / cols;
   // tuning knob for tools/phik_prof.sh: EEA_PHIK_ROWS fixes the rows per tile
   static const int forced = [] {
@@ -364,10 +654,12 @@ inline int spatial_rows_per_tile(int nx, int ny, int K)
   }();
   if (forced > 0) return forced < ny ? forced : ny;
   // measured on MI355X (profiles/r01_phik_rows_sweep.txt): 128-row tiles for K <= 20 and 64-row
-  // tiles for larger K are best on 8192^2 grids (~8 / ~16 workgroups per CU in total)
+  // tiles for larger K are best on 8192^2 grids
   int row_tiles = (K > 20 ? 4096 : 2048) / col_tiles;
   if (row_tiles < 1) row_tiles = 1;
   int rpt = (ny + row_tiles - 1) / row_tiles;
+  const int cap = K > 20 ? 64 : 128;
+  if (rpt > cap) rpt = cap;
   if (rpt < 32) rpt = 32;
   if (rpt > ny) rpt = ny;
   return rpt;
@@ -512,27 +804,111 @@ hipError_t launch_scale_by_inv(R* d_phi, size_t n, const R* d_sum, hipStream_t s
   return hipGetLastError();
 }
 
-size_t spatial_work_elems(int nx, int ny, int K)
+// ---- geometry of the matrix-core streaming kernel -------------------------------------------
+inline bool spatial_use_mfma()
 {
-  const int cols = kBlock * spatial_cpt(K);
+  static const bool valu = [] {
+    const char* v = std::getenv("EEA_PHIK_IMPL");
+    return v != nullptr && std::string(v) == "valu";
+  }();
+  return !valu;  // EEA_PHIK_IMPL=valu selects the per-column accumulator kernel (A/B baseline)
+}
+// columns per workgroup: 4 wavefronts x 16 x (columns per lane)
+inline int stream_cols(int kind, int NT)
+{
+  const int spl = kind == kKindF64 ? 2 : (kind == kKindF32 ? 4 : (NT == 1 ? 8 : 4));
+  const int lps = (kind == kKindCells || NT == 2) ? 1 : 2;
+  return (kBlock / kWave) * 16 * spl * lps;
+}
+inline int stream_rows_per_tile(int nx, int ny, int kind, int NT)
+{
+  static const int forced = [] {
+    const char* v = std::getenv("EEA_PHIK_ROWS");
+    return v ? std::atoi(v) : 0;
+  }();
+  const int cols = stream_cols(kind, NT);
   const int col_tiles = (nx + cols - 1) / cols;
-  const int rpt = spatial_rows_per_tile(nx, ny, K);
-  const int row_tiles = (ny + rpt - 1) / rpt;
-  return static_cast<size_t>(col_tiles) * row_tiles * K * K;
+  int rpt;
+  if (forced > 0) {
+    rpt = forced;
+  } else {
+    // ~6 workgroups per CU in total; at least 64 rows so that the epilogue (16 NT^2 matrix
+    // instructions per accumulator set) stays a small part of the tile
+    int row_tiles = 1536 / col_tiles;
+    if (row_tiles < 1) row_tiles = 1;
+    rpt = (ny + row_tiles - 1) / row_tiles;
+    if (rpt < 64) rpt = 64;
+  }
+  rpt = (rpt + 31) & ~31;  // whole pipeline stages (4 G rows, G <= 8)
+  if (rpt > ny) rpt = ny;
+  return rpt;
 }
 
-template <typename R>
-hipError_t launch_spatial_coeff(const R* d_phi, int nx, int ny, int K, const R* d_cx, const R* d_cy,
-                                R* d_work, R* d_phik, hipStream_t s)
+size_t spatial_work_elems(int nx, int ny, int K)
 {
-  const int cpt = spatial_cpt(K);
+  // the largest tile count over the column-per-lane choices of any input kind
+  size_t tiles = 0;
+  for (int cpt = 1; cpt <= 4; cpt *= 2) {
+    const int cols = kBlock * cpt;
+    const int col_tiles = (nx + cols - 1) / cols;
+    const int rpt = spatial_rows_per_tile(nx, ny, K, cpt);
+    const int row_tiles = (ny + rpt - 1) / rpt;
+    const size_t t = static_cast<size_t>(col_tiles) * row_tiles;
+    tiles = t > tiles ? t : tiles;
+  }
+  const int NT = K <= 16 ? 1 : 2;
+  for (int kind = 0; kind < 3; ++kind) {
+    const int cols = stream_cols(kind, NT);
+    const int rpt = stream_rows_per_tile(nx, ny, kind, NT);
+    const size_t t = static_cast<size_t>((nx + cols - 1) / cols) * ((ny + rpt - 1) / rpt);
+    tiles = t > tiles ? t : tiles;
+  }
+  return tiles * K * K;
+}
+
+namespace
+{
+template <typename R, typename IN>
+hipError_t launch_spatial_generic(const IN* d_in, int nx, int ny, int K, const R* d_cx, const R* d_cy,
+                                  const R* d_lut, R* d_work, R* d_phik, hipStream_t s)
+{
+  constexpr bool kCells = !std::is_same<IN, R>::value;
+  constexpr int kind = kCells ? kKindCells : (sizeof(R) == 8 ? kKindF64 : kKindF32);
+  const int K2 = K * K;
+  if (spatial_use_mfma()) {
+    const int NT = K <= 16 ? 1 : 2;
+    const int cols = stream_cols(kind, NT);
+    const int col_tiles = (nx + cols - 1) / cols;
+    const int rpt = stream_rows_per_tile(nx, ny, kind, NT);
+    const int row_tiles = (ny + rpt - 1) / rpt;
+    // per-wavefront accumulator-set buffers (+ decode table), reused for the K^2 reduction
+    size_t elems = static_cast<size_t>(kBlock / kWave) * 16 * NT * 17 + (kCells ? 256 : 0);
+    if (elems < static_cast<size_t>(4) * K2) elems = static_cast<size_t>(4) * K2;
+    const size_t lds = elems * sizeof(R);
+    const dim3 grid(col_tiles, row_tiles);
+    if (NT == 1) {
+      hipLaunchKernelGGL((spatial_stream_kernel<R, 1, IN>), grid, dim3(kBlock), lds, s, d_in, nx, ny, K, rpt,
+                         d_cx, d_cy, d_lut, d_work);
+    } else {
+      hipLaunchKernelGGL((spatial_stream_kernel<R, 2, IN>), grid, dim3(kBlock), lds, s, d_in, nx, ny, K, rpt,
+                         d_cx, d_cy, d_lut, d_work);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(sum_partials_kernel<R>, dim3((K2 + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+                       d_work, col_tiles * row_tiles, K2, R(1), d_phik);
+    return hipGetLastError();
+  }
+  const int cpt = spatial_cpt(K, kind);
   const int cols = kBlock * cpt;
   const int col_tiles = (nx + cols - 1) / cols;
-  const int rpt = spatial_rows_per_tile(nx, ny, K);
+  const int rpt = spatial_rows_per_tile(nx, ny, K, cpt);
   const int row_tiles = (ny + rpt - 1) / rpt;
-  // column sums [K][cols + 1] plus the epilogue's per-group partials (<= 256 reals)
+  // column sums [K][257] plus the epilogue's per-group partials (<= 256 reals), the tile's
+  // y-table rows and (occupancy input) the 256-entry decode table
   const int KYmax = ((K <= 16 ? (K == 5 ? 5 : (K == 10 ? 10 : 16)) : (K == 20 ? 20 : (K == 30 ? 30 : 32))) + 1) & ~1;
-  const size_t lds = (static_cast<size_t>(K) * (cols + 1) + kBlock + 4 + static_cast<size_t>(rpt) * KYmax) * sizeof(R);
+  const size_t lds = (static_cast<size_t>(K) * (kBlock + 1) + kBlock + 4 + static_cast<size_t>(rpt) * KYmax + 4 +
+                      (kCells ? 256 : 0)) * sizeof(R);
   const dim3 grid(col_tiles, row_tiles);
   auto launch = [&](auto kern) -> hipError_t {
     if (lds > 64 * 1024) {
@@ -541,21 +917,63 @@ hipError_t launch_spatial_coeff(const R* d_phi, int nx, int ny, int K, const R* 
                                                static_cast<int>(lds));
       if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kern, grid, dim3(kBlock), lds, s, d_phi, nx, ny, K, rpt, d_cx, d_cy, d_work);
+    hipLaunchKernelGGL(kern, grid, dim3(kBlock), lds, s, d_in, nx, ny, K, rpt, d_cx, d_cy, d_lut, d_work);
     return hipGetLastError();
   };
-  hipError_t e;
-  if (K == 5) e = launch(spatial_pass1_kernel<R, 5, 1, true>);
-  else if (K == 10 && cpt == 2) e = launch(spatial_pass1_kernel<R, 10, 2, true>);
-  else if (K == 10) e = launch(spatial_pass1_kernel<R, 10, 1, true>);
-  else if (K == 20) e = launch(spatial_pass1_kernel<R, 20, 1, true>);
-  else if (K == 30) e = launch(spatial_pass1_kernel<R, 30, 1, true>);
-  else if (K <= 16) e = launch(spatial_pass1_kernel<R, 16, 1, false>);
-  else e = launch(spatial_pass1_kernel<R, 32, 1, false>);
+  // exact-K instances for the BASELINE basis sizes x the columns-per-lane choices of this input kind
+  constexpr bool kWide = kind != kKindF64;  // four columns per lane: 16-byte fp32 loads / one dword of cells
+  hipError_t e = hipErrorInvalidValue;
+  auto pick = [&](auto k_tag) -> hipError_t {
+    constexpr int KX = decltype(k_tag)::value;
+    if (cpt == 1) return launch(spatial_pass1_kernel<R, KX, 1, true, IN>);
+    if (cpt == 2) return launch(spatial_pass1_kernel<R, KX, 2, true, IN>);
+    if constexpr (kWide && KX <= 10) {
+      if (cpt == 4) return launch(spatial_pass1_kernel<R, KX, 4, true, IN>);
+    }
+    return hipErrorInvalidValue;
+  };
+  if (K == 5) e = pick(std::integral_constant<int, 5>{});
+  else if (K == 10) e = pick(std::integral_constant<int, 10>{});
+  else if (K == 20) e = pick(std::integral_constant<int, 20>{});
+  else if (K == 30) e = pick(std::integral_constant<int, 30>{});
+  else if (K <= 16) e = launch(spatial_pass1_kernel<R, 16, 1, false, IN>);
+  else e = launch(spatial_pass1_kernel<R, 32, 1, false, IN>);
   if (e != hipSuccess) return e;
-  const int K2 = K * K;
   hipLaunchKernelGGL(sum_partials_kernel<R>, dim3((K2 + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
                      d_work, col_tiles * row_tiles, K2, R(1), d_phik);
+  return hipGetLastError();
+}
+
+// out[m] = raw[m] / raw[0]: the (0,0) mode of the un-normalised sums is the sum of the target
+// values (cos 0 = 1), i.e. the normaliser of target.cpp:87
+template <typename R>
+__global__ __launch_bounds__(kBlock) void normalise_by_first_kernel(const R* __restrict__ raw, int K2,
+                                                                    R* __restrict__ out)
+{
+  const R s = raw[0];
+  for (int m = blockIdx.x * kBlock + threadIdx.x; m < K2; m += gridDim.x * kBlock) out[m] = raw[m] / s;
+}
+}  // namespace
+
+template <typename R>
+hipError_t launch_spatial_coeff(const R* d_phi, int nx, int ny, int K, const R* d_cx, const R* d_cy,
+                                R* d_work, R* d_phik, hipStream_t s)
+{
+  return launch_spatial_generic<R, R>(d_phi, nx, ny, K, d_cx, d_cy, nullptr, d_work, d_phik, s);
+}
+
+template <typename R>
+hipError_t launch_spatial_coeff_cells(const int8_t* d_occ, int nx, int ny, int K, const R* d_cx,
+                                      const R* d_cy, const R* d_lut, R* d_work, R* d_raw, hipStream_t s)
+{
+  return launch_spatial_generic<R, int8_t>(d_occ, nx, ny, K, d_cx, d_cy, d_lut, d_work, d_raw, s);
+}
+
+template <typename R>
+hipError_t launch_normalise_by_first(const R* d_raw, int K2, R* d_out, hipStream_t s)
+{
+  hipLaunchKernelGGL(normalise_by_first_kernel<R>, dim3((K2 + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+                     d_raw, K2, d_out);
   return hipGetLastError();
 }
 
@@ -593,6 +1011,9 @@ hipError_t launch_point_coeff(const R* d_x, const R* d_y, const R* d_w, unsigned
   template hipError_t launch_scale_by_inv<R>(R*, size_t, const R*, hipStream_t);                    \
   template hipError_t launch_spatial_coeff<R>(const R*, int, int, int, const R*, const R*, R*, R*,  \
                                               hipStream_t);                                         \
+  template hipError_t launch_spatial_coeff_cells<R>(const int8_t*, int, int, int, const R*,         \
+                                                    const R*, const R*, R*, R*, hipStream_t);       \
+  template hipError_t launch_normalise_by_first<R>(const R*, int, R*, hipStream_t);                 \
   template hipError_t launch_point_coeff<R>(const R*, const R*, const R*, unsigned, int, R, R, R,   \
                                             R*, R*, hipStream_t);
 EEA_INSTANTIATE(double)

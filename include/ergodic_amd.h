@@ -100,6 +100,23 @@ eea_status eea_set_target_grid(eea_engine* e, unsigned nx, unsigned ny, const vo
 eea_status eea_spatial_coeff_rows(eea_engine* e, unsigned nx, unsigned ny_total, unsigned row0,
                                   unsigned nrows, const void* d_phi_rows, double lx, double ly,
                                   void* d_phik_partial, void* stream);
+/* Target from an occupancy grid (BASELINE config 5: the in-tree surrogate of the mutual-information
+ * map): phi(cell) = entropy(cell / 100.0) (numerics.hpp:164-179 with GridMap::getCell, grid.cpp:176-184),
+ * normalised to sum 1 (the idiom of Target::fill, target.cpp:87), then Basis::spatialCoeff
+ * (basis.cpp:122-133).  occ is the nav_msgs::OccupancyGrid::data buffer as GridMap holds it
+ * (grid.cpp:63-94): int8, row-major, x fastest, nx*ny cells on the grid configTarget builds for a
+ * domain lx x ly.  The entropy is applied inside the streaming kernel (one byte per cell read from
+ * HBM, no fp64 target grid is materialised) and the normaliser is the (0,0) coefficient of the
+ * un-normalised sums.  Sets lx, ly and phi_k.  occ is a device pointer if on_device != 0. */
+eea_status eea_set_target_occupancy(eea_engine* e, unsigned nx, unsigned ny, const int8_t* occ,
+                                    int on_device, double lx, double ly, void* stream);
+/* Grid-tiled form (rows tiled across GPUs): this rank holds rows [row0, row0 + nrows) in d_occ_rows
+ * (device) and gets its K^2 UN-normalised partial sums in d_sums_partial (device, real).  The caller
+ * adds the partials of all ranks (one all-reduce of K^2 reals), divides by element 0 (the sum of the
+ * entropies) and installs the result with eea_set_phik. */
+eea_status eea_spatial_coeff_occupancy_rows(eea_engine* e, unsigned nx, unsigned ny_total, unsigned row0,
+                                            unsigned nrows, const int8_t* d_occ_rows, double lx, double ly,
+                                            void* d_sums_partial, void* stream);
 /* installs phi_k (K^2 reals, device pointer if on_device != 0) for a domain lx x ly */
 eea_status eea_set_phik(eea_engine* e, const void* phik, int on_device, double lx, double ly);
 

@@ -130,3 +130,43 @@ def test_grid_tiled_phik_world2_gloo():
     assert np.abs(pk - full / phi.sum()).max() < 1e-13
     rows = [ab.grid_row_tile(ny, r, 3) for r in range(3)]
     assert rows[0][0] == 0 and sum(n for _, n in rows) == ny
+
+
+def _occ_tile_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import pyoracle as po
+    nx, ny, K, res = 40, 27, 5, 0.1
+    occ = np.random.default_rng(9).choice(np.array([0, 100, -1, 37], dtype=np.int8), size=nx * ny)
+    ent = np.array([po.lib().eo_entropy(float(v) / 100.0) for v in occ])   # un-normalised target
+    row0, nrows = ab.grid_row_tile(ny, rank, world)
+    part = torch.as_tensor(_phik_partial_cpu(ent, nx, ny, row0, nrows, K, res))
+    pk = ab.reduce_occupancy_sums(part)
+    if rank == 0:
+        q.put(pk.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_occupancy_tiled_phik_world2_gloo():
+    """row-tiled occupancy target (BASELINE config 5 sharding): the all-reduced un-normalised sums
+    divided by their (0,0) element equal spatialCoeff of the normalised entropy target"""
+    from oracle import pyoracle as po
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_occ_tile_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    pk = q.get(timeout=60)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    nx, ny, K, res = 40, 27, 5, 0.1
+    occ = np.random.default_rng(9).choice(np.array([0, 100, -1, 37], dtype=np.int8), size=nx * ny)
+    ent = np.array([po.lib().eo_entropy(float(v) / 100.0) for v in occ])
+    full = po.spatial_coeff((nx - 1) * res, (ny - 1) * res, K, ent / ent.sum(), po.phi_grid(nx, ny, res))
+    assert np.abs(pk - full).max() < 1e-13
+    assert abs(pk[0] - 1.0) < 1e-15

@@ -182,3 +182,83 @@ def test_row_tiles_sum_to_full_grid():
     assert np.abs(u1 - u2).max() < 1e-9
     eng.close()
     eng2.close()
+
+
+def _occupancy(nx, ny, seed=2024, block=32):
+    """BASELINE config 5 occupancy: 70 % free (0), 10 % occupied (100), 20 % unknown (-1) in blocks"""
+    rng = np.random.default_rng(seed)
+    blocks = rng.choice(np.array([0, 100, -1], dtype=np.int8), size=(ny // block + 1, nx // block + 1),
+                        p=[0.7, 0.1, 0.2])
+    return np.ascontiguousarray(np.kron(blocks, np.ones((block, block), dtype=np.int8))[:ny, :nx])
+
+
+def _entropy_target(occ):
+    lut = np.array([po.lib().eo_entropy(float(np.int8(np.uint8(b))) / 100.0) for b in range(256)])
+    ent = lut[occ.reshape(-1).view(np.uint8)]
+    return ent / ent.sum()
+
+
+@pytest.mark.parametrize("nx,ny,K", [(129, 129, 12), (300, 77, 10), (257, 513, 30), (64, 40, 5)])
+def test_occupancy_target_fused(nx, ny, K):
+    """eea_set_target_occupancy (int8 cells -> entropy -> normalise -> spatialCoeff in one streaming
+    pass) against the oracle's spatialCoeff on the materialised entropy target."""
+    res = 0.1
+    lx, ly = (nx - 1) * res, (ny - 1) * res
+    occ = _occupancy(nx, ny, block=16)
+    # a few raw probabilities as well (cells strictly between 0 and 100)
+    occ[3, 5:9] = [17, 50, 83, 99]
+    ref = po.spatial_coeff(lx, ly, K, _entropy_target(occ), po.phi_grid(nx, ny, res))
+    eng = _engine(K, res)
+    eng.set_target_occupancy(nx, ny, torch.as_tensor(occ).cuda(), lx, ly)
+    assert np.abs(eng.phik() - ref).max() < 1e-11
+    assert abs(eng.phik()[0] - 1.0) < 1e-14  # normalised: mode (0,0) is the total mass
+    eng.set_target_occupancy(nx, ny, occ, lx, ly)  # host-pointer form
+    assert np.abs(eng.phik() - ref).max() < 1e-11
+    with pytest.raises(capi.EngineError):  # the fp64 target grid is never materialised
+        eng.target_grid()
+    eng.close()
+
+
+def test_occupancy_row_tiles():
+    """config 5 sharding: un-normalised sums of row tiles add up; total / total[0] == fused result"""
+    from ergodic_exploration_amd import agent_batch as ab
+    nx, ny, K, res = 200, 131, 10, 0.1
+    lx, ly = (nx - 1) * res, (ny - 1) * res
+    occ = _occupancy(nx, ny, block=8)
+    d_occ = torch.as_tensor(occ).cuda()
+    eng = _engine(K, res)
+    eng.set_target_occupancy(nx, ny, d_occ, lx, ly)
+    full = eng.phik()
+    for world in (2, 3, 8):
+        total = torch.zeros(K * K, dtype=torch.float64, device="cuda")
+        for rank in range(world):
+            row0, nrows = ab.grid_row_tile(ny, rank, world)
+            part = torch.empty(K * K, dtype=torch.float64, device="cuda")
+            eng.spatial_coeff_occupancy_rows(nx, ny, row0, nrows, d_occ[row0:row0 + nrows], lx, ly, part)
+            total += part
+        torch.cuda.synchronize()
+        assert np.abs((total / total[0]).cpu().numpy() - full).max() < 1e-13
+    eng.close()
+
+
+def test_occupancy_target_f32_and_config5_size():
+    """fp32 engine on the full BASELINE config 5 grid (1024 x 1024, K = 30) against the fp64 engine"""
+    nx = ny = 1024
+    res = 0.1
+    lx = ly = 102.4
+    occ = torch.as_tensor(_occupancy(nx, ny)).cuda()
+    e64 = _engine(30, res)
+    e64.set_target_occupancy(nx, ny, occ, lx, ly)
+    e32 = _engine(30, res, precision=capi.PREC_F32)
+    e32.set_target_occupancy(nx, ny, occ, lx, ly)
+    assert np.abs(e32.phik() - e64.phik()).max() < 2e-5
+    # the fp64 result against numpy on the same entropy target (separable form, fp64)
+    phi = _entropy_target(occ.cpu().numpy()).reshape(ny, nx)
+    xs = np.concatenate([[0.0], np.cumsum(np.full(nx - 1, res))])  # coordinates by accumulation
+    ys = np.concatenate([[0.0], np.cumsum(np.full(ny - 1, res))])
+    cx = np.cos(np.outer(np.arange(30) * (np.pi / lx), xs))
+    cy = np.cos(np.outer(np.arange(30) * (np.pi / ly), ys))
+    ref = (cy @ phi @ cx.T).reshape(-1)  # [k2][k1] -> col = k2*K + k1
+    assert np.abs(e64.phik() - ref).max() < 1e-11
+    e64.close()
+    e32.close()
