@@ -2,10 +2,14 @@
 // src/exploration_{omni,cart}_node.cpp without ROS): read the parameter set of the reference's
 // yaml files, wire Collision / ErgodicControl / Target the way the node mains do, then run the
 // Exploration loop (exploration.hpp:197-292: addStateMemory -> control -> validate_control -> DWA
-// fallback) against a simulated robot on a map with optional rectangular obstacles.  Prints one
-// line per tick.
+// fallback) against a simulated robot on a map with optional rectangular obstacles, or on a
+// map_server map (--map-yaml, the format of the reference's maps/maze.yaml).  Prints one line per
+// tick.  --record writes the loop's inputs and outputs as a replay log; --replay feeds a log (a
+// recorded run, or poses / twists / maps logged on a robot) through the same state machine and
+// compares the twists tick by tick (map_io.hpp describes both file formats).
 #pragma once
 
+#include <cmath>
 #include <cstdio>
 #include <array>
 #include <cstring>
@@ -14,6 +18,7 @@
 
 #include <ergodic_exploration/exploration.hpp>
 
+#include "map_io.hpp"
 #include "params.hpp"
 
 namespace ee = ergodic_exploration;
@@ -26,6 +31,9 @@ int exploration_main(int argc, char** argv, bool is_cart)
   double map_x0 = -1.0, map_y0 = -1.0, map_w = 12.0, map_h = 6.0, map_res = 0.05;
   ee::vec pose = { 1.0, 1.0, 0.3 };
   std::vector<std::array<double, 4>> obstacles;  // x0 y0 x1 y1 in the map frame
+  std::string map_yaml, record_path, replay_path;
+  bool dump_map = false;
+  double replay_tol = 1e-9;
   for (int i = 1; i < argc; ++i) {
     const std::string a = argv[i];
     if (a == "--params" && i + 1 < argc) pnh.load(argv[++i]);
@@ -44,12 +52,23 @@ int exploration_main(int argc, char** argv, bool is_cart)
       obstacles.push_back({ std::atof(argv[i + 1]), std::atof(argv[i + 2]), std::atof(argv[i + 3]),
                             std::atof(argv[i + 4]) });
       i += 4;
+    } else if (a == "--map-yaml" && i + 1 < argc) {
+      map_yaml = argv[++i];
+    } else if (a == "--dump-map") {
+      dump_map = true;
+    } else if (a == "--record" && i + 1 < argc) {
+      record_path = argv[++i];
+    } else if (a == "--replay" && i + 1 < argc) {
+      replay_path = argv[++i];
+    } else if (a == "--replay-tol" && i + 1 < argc) {
+      replay_tol = std::atof(argv[++i]);
     } else if (a == "--set" && i + 2 < argc) {
       pnh.set(argv[i + 1], argv[i + 2]);
       i += 2;
     } else if (a == "--help") {
       std::printf("usage: %s [--params file.yaml] [--ticks N] [--pose x y th] [--map x0 y0 w h res] "
-                  "[--obstacle x0 y0 x1 y1]... [--set name value]\n", argv[0]);
+                  "[--obstacle x0 y0 x1 y1]... [--map-yaml map.yaml] [--dump-map] [--record log] [--replay log] "
+                  "[--replay-tol eps] [--set name value]\n", argv[0]);
       return 0;
     }
   }
@@ -104,38 +123,125 @@ int exploration_main(int argc, char** argv, bool is_cart)
                               is_cart ? 1u : static_cast<unsigned int>(pnh.param("vy_samples", 8.0)),
                               static_cast<unsigned int>(pnh.param("vth_samples", 5.0)));
 
+  // occupancy map standing in for the map topic: a map_server map, or free space plus the
+  // requested obstacle blocks
+  map_io::Occupancy occ;
+  if (!map_yaml.empty()) {
+    occ = map_io::load_map_yaml(map_yaml);
+  } else {
+    occ.width = ee::axis_length(map_x0, map_x0 + map_w, map_res);
+    occ.height = ee::axis_length(map_y0, map_y0 + map_h, map_res);
+    occ.resolution = map_res;
+    occ.origin_x = map_x0;
+    occ.origin_y = map_y0;
+    occ.data.assign(static_cast<std::size_t>(occ.width) * occ.height, 0);
+  }
+  for (const auto& o : obstacles) {
+    for (unsigned int i = 0; i < occ.height; ++i) {
+      for (unsigned int j = 0; j < occ.width; ++j) {
+        const double cx = occ.origin_x + (j + 0.5) * occ.resolution, cy = occ.origin_y + (i + 0.5) * occ.resolution;
+        if (cx >= o[0] && cx <= o[2] && cy >= o[1] && cy <= o[3]) occ.data[static_cast<std::size_t>(i) * occ.width + j] = 100;
+      }
+    }
+  }
+  ee::GridMap grid = occ.grid();
+
+  if (dump_map) {
+    // summary of the occupancy cells (no engine, no GPU needed): counts and an FNV-1a checksum
+    std::size_t n_free = 0, n_occ = 0, n_unknown = 0;
+    unsigned long long hash = 1469598103934665603ull;
+    for (const int8_t v : occ.data) {
+      n_free += v == 0;
+      n_occ += v == 100;
+      n_unknown += v == -1;
+      hash = (hash ^ static_cast<unsigned char>(v)) * 1099511628211ull;
+    }
+    std::printf("map width %u height %u resolution %.17g origin %.17g %.17g free %zu occupied %zu unknown %zu "
+                "fnv1a %llu\n", occ.width, occ.height, occ.resolution, occ.origin_x, occ.origin_y, n_free, n_occ,
+                n_unknown, hash);
+    std::printf("bounds x [%.17g, %.17g] y [%.17g, %.17g]\n", grid.xmin(), grid.xmax(), grid.ymin(), grid.ymax());
+    return 0;
+  }
+
   const ModelT model;
   ee::ErgodicControl<ModelT> ergodic_control(model, collision, ec_dt, ec_horizon, target_resolution, expl_weight,
                                              num_basis, buffer_size, batch_size, Rinv, umin, umax);
   ee::Exploration<ModelT> exploration(ergodic_control, collision, dwa);
   exploration.setTarget(target);
 
-  // occupancy map standing in for the map topic: free space plus the requested obstacle blocks
-  const unsigned int w = ee::axis_length(map_x0, map_x0 + map_w, map_res);
-  const unsigned int h = ee::axis_length(map_y0, map_y0 + map_h, map_res);
-  ee::GridData cells(static_cast<std::size_t>(w) * h, 0);
-  for (const auto& o : obstacles) {
-    for (unsigned int i = 0; i < h; ++i) {
-      for (unsigned int j = 0; j < w; ++j) {
-        const double cx = map_x0 + (j + 0.5) * map_res, cy = map_y0 + (i + 0.5) * map_res;
-        if (cx >= o[0] && cx <= o[2] && cy >= o[1] && cy <= o[3]) cells[static_cast<std::size_t>(i) * w + j] = 100;
-      }
-    }
-  }
-  const ee::GridMap grid = ee::GridMap::fromOccupancyGrid(w, h, map_res, map_x0, map_y0, cells);
-
   std::printf("# %s: K=%u steps=%u dt=%g frequency=%g Hz map=[%g,%g]x[%g,%g]\n", is_cart ? "exploration_cart"
               : "exploration_omni", num_basis, ergodic_control.steps(), ec_dt, frequency, grid.xmin(), grid.xmax(),
               grid.ymin(), grid.ymax());
   static const char* const kSource[] = { "ergodic", "dwa-follow", "dwa-reference", "dwa-replan" };
+  auto print_tick = [&](int t, const ee::vec& p, const ee::vec& u) {
+    std::printf("tick %3d pose %.17g %.17g %.17g  cmd_vel %.17g %.17g %.17g  %s\n", t, p(0), p(1), p(2), u(0), u(1),
+                u(2), kSource[static_cast<int>(exploration.source())]);
+  };
+
+  if (!replay_path.empty()) {
+    // replay: maps, poses and body twists come from the log; the twists are compared with the logged ones
+    const std::vector<map_io::Record> records = map_io::read_replay(replay_path);
+    bool have_map = false;
+    int n_ticks = 0, n_compared = 0, n_source_mismatch = 0;
+    double worst = 0.0;
+    for (const map_io::Record& r : records) {
+      if (r.is_map) {
+        grid = r.map.grid();
+        have_map = true;
+        continue;
+      }
+      if (!have_map) {
+        std::fprintf(stderr, "replay: tick before the first map record; using the command-line map\n");
+        have_map = true;
+      }
+      const ee::vec p = { r.tick.pose[0], r.tick.pose[1], r.tick.pose[2] };
+      const ee::vec v = { r.tick.vb[0], r.tick.vb[1], r.tick.vb[2] };
+      const ee::vec u = exploration.tick(grid, p, v, val_dt, val_horizon);
+      print_tick(r.tick.t, p, u);
+      ++n_ticks;
+      if (r.tick.source != "?") {
+        ++n_compared;
+        for (int c = 0; c < 3; ++c) {
+          const double d = std::fabs(u(c) - r.tick.u[c]);
+          worst = d > worst ? d : worst;
+        }
+        n_source_mismatch += r.tick.source != kSource[static_cast<int>(exploration.source())];
+      }
+    }
+    std::printf("# replay: %d ticks, %d compared, max |cmd_vel - logged| = %.3g, source mismatches = %d\n", n_ticks,
+                n_compared, worst, n_source_mismatch);
+    return (n_compared > 0 && (worst > replay_tol || n_source_mismatch > 0)) ? 1 : 0;
+  }
+
+  std::FILE* rec = nullptr;
+  if (!record_path.empty()) {
+    rec = std::fopen(record_path.c_str(), "w");
+    if (rec == nullptr) {
+      std::fprintf(stderr, "cannot open %s for writing\n", record_path.c_str());
+      return 2;
+    }
+    std::fprintf(rec, "# ergodic exploration replay log v1 (%s)\n", is_cart ? "exploration_cart" : "exploration_omni");
+    map_io::write_map(rec, occ);
+  }
   ee::vec vb = { 0.0, 0.0, 0.0 };  // odometry twist: the simulated robot executes the command exactly
   for (int t = 0; t < ticks; ++t) {
     const ee::vec u = exploration.tick(grid, pose, vb, val_dt, val_horizon);
-    std::printf("tick %3d pose %.17g %.17g %.17g  cmd_vel %.17g %.17g %.17g  %s\n", t, pose(0), pose(1), pose(2),
-                u(0), u(1), u(2), kSource[static_cast<int>(exploration.source())]);
+    print_tick(t, pose, u);
+    if (rec != nullptr) {
+      map_io::Tick k;
+      k.t = t;
+      for (int c = 0; c < 3; ++c) {
+        k.pose[c] = pose(c);
+        k.vb[c] = vb(c);
+        k.u[c] = u(c);
+      }
+      k.source = kSource[static_cast<int>(exploration.source())];
+      map_io::write_tick(rec, k);
+    }
     pose = ee::integrate_twist(pose, u, 1.0 / frequency);
     pose(2) = ee::normalize_angle_PI(pose(2));
     vb = u;
   }
+  if (rec != nullptr) std::fclose(rec);
   return 0;
 }

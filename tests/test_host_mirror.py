@@ -135,3 +135,93 @@ def test_entry_points_follow_the_oracle(name, model, cfg, obstacles, ticks):
         assert any(s != "ergodic" for s in sources), "the scenario must exercise the DWA fallback"
     else:
         assert all(s == "ergodic" for s in sources)
+
+
+def _map_server_cells(pix, negate, occ_th, free_th):
+    """the published map_server rule (trinary mode), image row 0 = top of the map"""
+    p = pix.astype(np.float64) / 255.0 if negate else (255 - pix.astype(np.int64)) / 255.0
+    cells = np.where(p > occ_th, 100, np.where(p < free_th, 0, -1)).astype(np.int8)
+    return cells[::-1]  # OccupancyGrid row 0 = lowest y
+
+
+def _fnv1a(cells):
+    h = 1469598103934665603
+    for b in cells.reshape(-1).view(np.uint8):
+        h = ((h ^ int(b)) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return h
+
+
+@pytest.mark.parametrize("kind,negate", [("P5", 0), ("P2", 0), ("P5", 1)])
+def test_map_server_yaml_and_pgm_loader(tmp_path, kind, negate):
+    """--map-yaml reads the reference's map format (maps/maze.yaml: map_server yaml + PGM) into the
+    OccupancyGrid layout GridMap consumes (grid.cpp:63-94); checked without a GPU via --dump-map."""
+    _build()
+    rng = np.random.default_rng(5)
+    w, h = 37, 23
+    pix = rng.choice(np.array([0, 100, 205, 254, 255, 128, 60], dtype=np.uint8), size=(h, w))
+    pgm = tmp_path / "m.pgm"
+    if kind == "P5":
+        pgm.write_bytes(b"P5\n# CREATOR: test 0.100 m/pix\n%d %d\n255\n" % (w, h) + pix.tobytes())
+    else:
+        pgm.write_text("P2\n%d %d\n255\n" % (w, h) + "\n".join(" ".join(str(v) for v in row) for row in pix) + "\n")
+    (tmp_path / "m.yaml").write_text("image: m.pgm\nresolution: 0.100000\norigin: [-8.350015, -13.950030, 0.000000]\n"
+                                     "negate: %d\noccupied_thresh: 0.65\nfree_thresh: 0.196\n" % negate)
+    out = subprocess.run([os.path.join(BUILD, "exploration_omni"), "--map-yaml", str(tmp_path / "m.yaml"), "--dump-map"],
+                         capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    f = out.stdout.split()
+    got = {f[i]: f[i + 1] for i in range(1, 6, 2)}
+    cells = _map_server_cells(pix, negate, 0.65, 0.196)
+    assert int(got["width"]) == w and int(got["height"]) == h and float(got["resolution"]) == 0.1
+    assert float(f[f.index("origin") + 1]) == -8.350015 and float(f[f.index("origin") + 2]) == -13.95003
+    assert int(f[f.index("free") + 1]) == int((cells == 0).sum())
+    assert int(f[f.index("occupied") + 1]) == int((cells == 100).sum())
+    assert int(f[f.index("unknown") + 1]) == int((cells == -1).sum())
+    assert int(f[f.index("fnv1a") + 1]) == _fnv1a(cells)
+    # bounds as GridMap derives them from the message fields (grid.hpp:66-76)
+    from oracle import pyoracle as po
+    b = out.stdout.splitlines()[1].replace("[", " ").replace("]", " ").replace(",", " ").split()
+    assert float(b[3]) == po.lib().eo_axis_upper(-8.350015, 0.1, w)
+    assert float(b[6]) == po.lib().eo_axis_upper(-13.95003, 0.1, h)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,cfg,obstacle", [
+    ("exploration_omni", "explore_omni.yaml", (2.4, 0.2, 3.0, 2.6)),
+    ("exploration_cart", "explore_cart.yaml", (2.6, 0.0, 3.2, 2.4)),
+])
+def test_record_then_replay(tmp_path, name, cfg, obstacle):
+    """--record writes the loop's inputs (map, pose, body twist) and outputs; --replay feeds them
+    through a fresh Exploration state machine: same twists, same EC / DWA decisions, tick by tick."""
+    _build()
+    log = str(tmp_path / "run.log")
+    base = [os.path.join(BUILD, name), "--params", os.path.join(HOST, "config", cfg)]
+    rec = subprocess.run(base + ["--ticks", "30", "--obstacle"] + [str(v) for v in obstacle] + ["--record", log],
+                         capture_output=True, text=True)
+    assert rec.returncode == 0, rec.stdout + rec.stderr
+    lines = open(log).read().splitlines()
+    assert lines[1].startswith("map ") and sum(l.startswith("tick ") for l in lines) == 30
+    assert any(l.split()[-1] != "ergodic" for l in lines if l.startswith("tick "))  # the DWA fallback ran
+    rep = subprocess.run(base + ["--replay", log], capture_output=True, text=True)
+    assert rep.returncode == 0, rep.stdout + rep.stderr
+    summary = [l for l in rep.stdout.splitlines() if l.startswith("# replay")][0]
+    assert "30 ticks, 30 compared" in summary and "source mismatches = 0" in summary
+    # identical engine, identical inputs: bit-identical twists
+    assert "max |cmd_vel - logged| = 0," in summary
+    # a log of the inputs alone (no published twist) replays without comparison
+    stripped = str(tmp_path / "inputs.log")
+    with open(stripped, "w") as f:
+        for l in lines:
+            f.write((" ".join(l.split()[:8]) if l.startswith("tick ") else l) + "\n")
+    rep2 = subprocess.run(base + ["--replay", stripped], capture_output=True, text=True)
+    assert rep2.returncode == 0 and "30 ticks, 0 compared" in rep2.stdout
+    # a corrupted twist is reported
+    bad = str(tmp_path / "bad.log")
+    with open(bad, "w") as f:
+        for l in lines:
+            p = l.split()
+            if l.startswith("tick 7 "):
+                p[8] = repr(float(p[8]) + 1e-3)
+            f.write(" ".join(p) + "\n")
+    rep3 = subprocess.run(base + ["--replay", bad], capture_output=True, text=True)
+    assert rep3.returncode == 1
