@@ -604,18 +604,24 @@ __global__ __launch_bounds__(kBlock) void spatial_stream_kernel(const IN* __rest
   }
 }
 
-// pass 2: add the partials of all workgroups in a fixed order
+// pass 2: add the partials of all workgroups in a fixed order (run-to-run deterministic): one
+// wavefront per mode, lanes stride over the partials, then a fixed shuffle tree.  (One thread per
+// mode walking all partials took 3x as long as the streaming pass on a grid with 1400 tiles.)
 template <typename R>
 __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const R* __restrict__ partials,
                                                               int n_parts, int K2, R scale,
                                                               R* __restrict__ out)
 {
-  for (int m = blockIdx.x * kBlock + threadIdx.x; m < K2; m += gridDim.x * kBlock) {
-    R s = R(0);
-    for (int b = 0; b < n_parts; ++b) s += partials[static_cast<size_t>(b) * K2 + m];
-    out[m] = scale * s;
-  }
+  const int lane = threadIdx.x & (kWave - 1);
+  const int m = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  if (m >= K2) return;  // whole wavefront
+  R s = R(0);
+  for (int b = lane; b < n_parts; b += kWave) s += partials[static_cast<size_t>(b) * K2 + m];
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) s += __shfl_down(s, o, kWave);
+  if (lane == 0) out[m] = scale * s;
 }
+constexpr int kModesPerSumBlock = kBlock / kWave;
 
 // columns per lane.  kind: 0 = fp64 values, 1 = fp32 values, 2 = occupancy cells (bytes).
 // More columns per lane divide the y-table LDS reads per element; the accumulators (CPT * K reals
@@ -895,7 +901,7 @@ hipError_t launch_spatial_generic(const IN* d_in, int nx, int ny, int K, const R
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sum_partials_kernel<R>, dim3((K2 + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+    hipLaunchKernelGGL(sum_partials_kernel<R>, dim3((K2 + kModesPerSumBlock - 1) / kModesPerSumBlock), dim3(kBlock), 0, s,
                        d_work, col_tiles * row_tiles, K2, R(1), d_phik);
     return hipGetLastError();
   }
@@ -939,7 +945,7 @@ hipError_t launch_spatial_generic(const IN* d_in, int nx, int ny, int K, const R
   else if (K <= 16) e = launch(spatial_pass1_kernel<R, 16, 1, false, IN>);
   else e = launch(spatial_pass1_kernel<R, 32, 1, false, IN>);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(sum_partials_kernel<R>, dim3((K2 + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+  hipLaunchKernelGGL(sum_partials_kernel<R>, dim3((K2 + kModesPerSumBlock - 1) / kModesPerSumBlock), dim3(kBlock), 0, s,
                      d_work, col_tiles * row_tiles, K2, R(1), d_phik);
   return hipGetLastError();
 }
@@ -995,7 +1001,7 @@ hipError_t launch_point_coeff(const R* d_x, const R* d_y, const R* d_w, unsigned
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(sum_partials_kernel<R>, dim3((K2 + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
+  hipLaunchKernelGGL(sum_partials_kernel<R>, dim3((K2 + kModesPerSumBlock - 1) / kModesPerSumBlock), dim3(kBlock), 0, s,
                      d_work, static_cast<int>(blocks), K2, scale, d_out);
   return hipGetLastError();
 }
