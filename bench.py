@@ -226,15 +226,17 @@ def main():
         bytes_per_opt = rs * (3 + 3 * T + 3 * T + 3 + K2 + 3 * args.n_mem)
         flops_per_opt = 2 * K * K * N + 4 * K * K * T + (4 * K + 140) * T  # SURVEY.md 8(d) "W"
         launch_s = kernel_ms * 1e-3
-        hbm_gbs = bytes_per_opt * B / launch_s / 1e9
-        tflops = flops_per_opt * B / launch_s / 1e12
+        # per launch: with agent groups, the launches of group 0 (timed by the events on its stream)
+        Bl = bounds[1] - bounds[0]
+        hbm_gbs = bytes_per_opt * Bl / launch_s / 1e9
+        tflops = flops_per_opt * Bl / launch_s / 1e12
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_control_pmc.json")
         if os.path.exists(pmc):
             try:
                 with open(pmc) as f:
                     rec = json.load(f)
-                if rec.get("agents") == B and rec.get("T") == T and rec.get("K") == K and rec.get("precision") == args.precision:
+                if rec.get("agents") == Bl and rec.get("T") == T and rec.get("K") == K and rec.get("precision") == args.precision:
                     traffic = rec.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -249,17 +251,19 @@ def main():
                                    "K=%dx%d, T=%d steps (dt %.3g, horizon %.3g), n_mem=%d, c_k all-gather %s"
                                    % (B, args.model, K, K, T, args.dt, args.horizon, args.n_mem,
                                       "on" if gather else "off (1 GPU)"),
-                       "agents_per_gpu": B, "num_basis": K, "steps_T": T, "model": args.model,
+                       "agents_per_gpu": B, "num_basis": K, "horizon_steps": T, "kinematics": args.model,
+                       "agent_groups": G,
                        "parallelism": "agent-batch x%d" % world},
             "host_enqueue_us_per_step": host_us,
             "roofline": {"bound": "hbm", "kernel": "control_kernel", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_launch": bytes_per_opt * B, "launch_ms": kernel_ms},
+                         "bytes_per_launch": bytes_per_opt * Bl, "launch_ms": kernel_ms,
+                         "agents_per_launch": Bl, "concurrent_launches": G},
             "roofline_valu": {"bound": "valu-%s" % args.precision, "kernel": "control_kernel",
                               "achieved": tflops, "peak": VALU_F32_PEAK_TF if f32 else VALU_F64_PEAK_TF,
                               "unit": "TFLOP/s",
                               "frac": tflops / (VALU_F32_PEAK_TF if f32 else VALU_F64_PEAK_TF),
-                              "flops_per_launch": flops_per_opt * B,
+                              "flops_per_launch": flops_per_opt * Bl,
                               "note": "the control kernel is vector-ALU/transcendental bound, not HBM bound "
                                       "(SURVEY.md 8(d)); W = 2K^2N + 4K^2T + (4K+140)T flop per optimisation"},
         }
