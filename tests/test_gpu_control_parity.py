@@ -299,3 +299,19 @@ def test_ragged_memory_and_extreme_sizes():
     eng2, _ = make_pair("omni", 5, 0.3, n_oracles=0)
     assert eng2.T == 2
     eng2.close()
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_shapes_against_oracle(seed):
+    """Randomised shapes: basis size 1..32 (exact-K and run-time-K kernels), horizons of 2..420 steps
+    (one, two and four wavefronts per agent, chunked scans beyond 256), ragged replay memory,
+    both kinematic models; dt = 1/16 keeps horizon / dt exact."""
+    rng = np.random.default_rng(1000 + seed)
+    model = ["omni", "simple_cart"][seed % 2]
+    K = int(rng.choice([1, 2, 3, 5, 6, 9, 10, 11, 13, 16, 17, 20, 24, 30, 32]))
+    steps = int(rng.choice([2, 3, 7, 31, 64, 65, 97, 128, 160, 200, 257, 420]))
+    n_mem = int(rng.choice([0, 0, 1, 5, 33, 100]))
+    dt = 0.0625
+    # the oracle costs O(K^2 (T + n_mem)) trig calls per agent and call: bound the batch
+    B = 2 if K * K * (steps + n_mem) > 60000 else 4
+    run_batch_vs_oracle(model, K, steps * dt, dt, B=B, n_mem=n_mem, calls=2, seed=seed)

@@ -262,3 +262,28 @@ def test_occupancy_target_f32_and_config5_size():
     assert np.abs(e64.phik() - ref).max() < 1e-11
     e64.close()
     e32.close()
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_random_grid_shapes(seed):
+    """Randomised grid shapes through both inputs of the streaming kernel (fp64 values, int8 cells):
+    widths that break the 16-byte / 8-byte vector loads, grids narrower than one 16-column operand
+    and shorter than one 4-row step, heights that leave a partial pipeline stage."""
+    rng = np.random.default_rng(500 + seed)
+    nx = int(rng.choice([1, 2, 3, 5, 15, 16, 17, 63, 66, 127, 130, 257]))
+    ny = int(rng.choice([1, 2, 3, 4, 5, 31, 33, 64, 70, 129]))
+    K = int(rng.choice([1, 2, 5, 7, 10, 16, 17, 20, 30, 32]))
+    res = 0.1
+    lx, ly = max(nx - 1, 1) * res, max(ny - 1, 1) * res
+    g = po.phi_grid(nx, ny, res)
+    phi = rng.random(nx * ny)
+    ref = po.spatial_coeff(lx, ly, K, phi, g)
+    eng = _engine(K, res)
+    eng.set_target_grid(nx, ny, torch.as_tensor(phi).cuda(), lx, ly)
+    assert np.abs(eng.phik() - ref).max() < 1e-11 * max(1.0, phi.sum())
+    occ = rng.choice(np.array([0, 100, -1, 25, 77], dtype=np.int8), size=(ny, nx))
+    tgt = _entropy_target(occ)
+    ref_o = po.spatial_coeff(lx, ly, K, tgt, g)
+    eng.set_target_occupancy(nx, ny, torch.as_tensor(occ).cuda(), lx, ly)
+    assert np.abs(eng.phik() - ref_o).max() < 1e-11
+    eng.close()
