@@ -2,6 +2,21 @@
 // collision.cpp:126-243) on a GridMap (grid.cpp:96-184) and validate_control
 // (numerics.hpp:273-330).  Integer work, one pose per lane; results are bit-exact with the
 // reference's x86-64 build, including the wrap of negative world coordinates in world2Grid.
+//
+// Large batches go through an inflated map: the boolean result of the ring search does not depend on
+// the visiting order (the search only stops at a hit), so it equals "some occupied cell lies at one
+// of the offsets the Bresenham rings r_bnd..r_max visit and within r_col" -- a dilation of the
+// occupied cells by a fixed offset set.  That set is enumerated on the host by the same ring walk,
+// the occupied cells scatter a 1 to every centre that would see them, and a collision check becomes
+// one byte lookup (a robot centred inside a small obstacle still reports no collision: cells closer
+// than r_bnd are not in the set, as in the reference).
+#include <algorithm>
+#include <cstdint>
+#include <cstdlib>
+#include <mutex>
+#include <utility>
+#include <vector>
+
 #include "common.hpp"
 
 namespace eea
@@ -79,6 +94,62 @@ __device__ __forceinline__ bool collision_check(const CollisionParams& c,
   return false;
 }
 
+// ---- inflated map ----------------------------------------------------------------------------
+// hit map over the centres [-R, xsize + R) x [-R, ysize + R), R = r_col, row-major
+struct HitMap
+{
+  const uint8_t* cells;
+  int R, w, h;  // w = xsize + 2R, h = ysize + 2R
+};
+
+// grid cell of a world point as collisionCheck derives it (grid.cpp:143-159), as signed ints
+__device__ __forceinline__ void centre_of(const CollisionParams& c, double px, double py, int& cx, int& cy)
+{
+  unsigned j = cast_u32_x86(floor((px - c.xmin) / c.resolution));
+  unsigned i = cast_u32_x86(floor((py - c.ymin) / c.resolution));
+  if (j == c.xsize) j--;
+  if (i == c.ysize) i--;
+  cx = static_cast<int>(j);
+  cy = static_cast<int>(i);
+}
+
+__device__ __forceinline__ bool hit_lookup(const HitMap& m, int cx, int cy)
+{
+  const int hx = cx + m.R, hy = cy + m.R;
+  // centres further than R outside the grid see no cell at all (the unsigned cell indices of
+  // collision.cpp:216-243 fall outside gridBounds)
+  if (hx < 0 || hy < 0 || hx >= m.w || hy >= m.h) return false;
+  return m.cells[static_cast<size_t>(hy) * m.w + hx] != 0;
+}
+
+// occupied cells mark every centre that reaches them through one of the ring offsets
+__global__ __launch_bounds__(kBlock) void inflate_kernel(const CollisionParams c, const int8_t* __restrict__ grid,
+                                                         const short2* __restrict__ offsets, int n_off,
+                                                         uint8_t* __restrict__ cells, int R, int w)
+{
+  const size_t q = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
+  const size_t n = static_cast<size_t>(c.xsize) * c.ysize;
+  if (q >= n) return;
+  const double cell = static_cast<double>(grid[q]) / 100.0;  // GridMap::getCell, grid.cpp:177-184
+  if (cell < c.occupied_threshold) return;                   // checkCell tests !(cell < threshold)
+  const int i = static_cast<int>(q / c.xsize), j = static_cast<int>(q - static_cast<size_t>(i) * c.xsize);
+  for (int o = 0; o < n_off; ++o) {
+    const short2 d = offsets[o];  // cell = centre + d
+    cells[static_cast<size_t>(i - d.y + R) * w + (j - d.x + R)] = 1;  // same value from every writer
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void collision_check_map_kernel(const CollisionParams c, const HitMap m,
+                                                                     const double* __restrict__ pose,
+                                                                     unsigned P, int* __restrict__ hit)
+{
+  const unsigned q = blockIdx.x * kBlock + threadIdx.x;
+  if (q >= P) return;
+  int cx, cy;
+  centre_of(c, pose[3 * static_cast<size_t>(q)], pose[3 * static_cast<size_t>(q) + 1], cx, cy);
+  hit[q] = hit_lookup(m, cx, cy) ? 1 : 0;
+}
+
 __global__ __launch_bounds__(kBlock) void collision_check_kernel(const CollisionParams c,
                                                                  const int8_t* __restrict__ grid,
                                                                  const double* __restrict__ pose,
@@ -91,8 +162,22 @@ __global__ __launch_bounds__(kBlock) void collision_check_kernel(const Collision
 
 __device__ __forceinline__ double wrap_pi_d(double rad) { return wrap_pi<double>(rad); }
 
+// one collision test through the inflated map (MAP) or by the ring search
+template <bool MAP>
+__device__ __forceinline__ bool pose_collides(const CollisionParams& c, const int8_t* __restrict__ grid,
+                                              const HitMap& m, double px, double py)
+{
+  if (MAP) {
+    int cx, cy;
+    centre_of(c, px, py, cx, cy);
+    return hit_lookup(m, cx, cy);
+  }
+  return collision_check(c, grid, px, py);
+}
+
 // numerics.hpp:273-330
-__global__ __launch_bounds__(kBlock) void validate_control_kernel(const CollisionParams c,
+template <bool MAP>
+__global__ __launch_bounds__(kBlock) void validate_control_kernel(const CollisionParams c, const HitMap m,
                                                                   const int8_t* __restrict__ grid,
                                                                   const double* __restrict__ x0,
                                                                   const double* __restrict__ u,
@@ -126,7 +211,7 @@ __global__ __launch_bounds__(kBlock) void validate_control_kernel(const Collisio
     x = x + (cc * d0 + (-s) * d1);
     y = y + (s * d0 + cc * d1);
     th = wrap_pi_d(th + d2);
-    if (collision_check(c, grid, x, y)) {
+    if (pose_collides<MAP>(c, grid, m, x, y)) {
       ok = 0;
       break;
     }
@@ -136,7 +221,9 @@ __global__ __launch_bounds__(kBlock) void validate_control_kernel(const Collisio
 // DynamicWindow::control (dynamic_window.cpp:92-286): one workgroup per robot, one lane per
 // velocity sample; lane 0 then takes the first strict minimum in the reference's loop order.
 constexpr int kDwaBlock = 128;
+template <bool MAP>
 __global__ __launch_bounds__(kDwaBlock) void dwa_control_kernel(const CollisionParams c, const DwaParams d,
+                                                               const HitMap m,
                                                                const int8_t* __restrict__ grid,
                                                                const double* __restrict__ x0s,
                                                                const double* __restrict__ vbs,
@@ -165,7 +252,7 @@ __global__ __launch_bounds__(kDwaBlock) void dwa_control_kernel(const CollisionP
   const double tf = static_cast<double>(n_ref) * dt_ref;
   const double* const xr = (xt_refs != nullptr) ? xt_refs + 3 * static_cast<size_t>(n_ref) * r : nullptr;
 
-  for (unsigned sidx = threadIdx.x; sidx < nsamp; sidx += kDwaBlock) {
+  for (unsigned sidx = threadIdx.x; sidx < nsamp; sidx += blockDim.x) {
     // sample (i, j, k) in the reference's loop order; values by repeated += like the reference
     const unsigned k = sidx % d.ns[2], j = (sidx / d.ns[2]) % d.ns[1], i = sidx / (d.ns[2] * d.ns[1]);
     double u0 = lower[0], u1 = lower[1], u2 = lower[2];
@@ -196,7 +283,7 @@ __global__ __launch_bounds__(kDwaBlock) void dwa_control_kernel(const CollisionP
       x = x + (cs * d0 + (-sn) * d1);
       y = y + (sn * d0 + cs * d1);
       th = wrap_pi<double>(th + d2);
-      if (collision_check(c, grid, x, y)) {
+      if (pose_collides<MAP>(c, grid, m, x, y)) {
         hit = true;
         break;
       }
@@ -246,16 +333,159 @@ __global__ __launch_bounds__(kDwaBlock) void dwa_control_kernel(const CollisionP
 }
 }  // namespace
 
+namespace
+{
+// offsets (cell - centre) the ring search r_bnd..r_max can report a collision at: the walk of
+// collision.cpp:166-214, keeping the cells within r_col (collision.cpp:239)
+std::vector<short2> ring_offsets(const CollisionParams& c)
+{
+  std::vector<std::pair<int, int>> pts;
+  for (int r0 = c.r_bnd; r0 <= c.r_max; ++r0) {
+    int r = r0, x = -r0, y = 0, err = 2 - 2 * r0;
+    while (x < 0) {
+      pts.emplace_back(-x, y);
+      pts.emplace_back(-y, -x);
+      pts.emplace_back(x, -y);
+      pts.emplace_back(y, x);
+      r = err;
+      if (r <= y) {
+        y++;
+        err += 2 * y + 1;
+      }
+      if (r > x || err > y) {
+        x++;
+        err += 2 * x + 1;
+      }
+    }
+  }
+  std::sort(pts.begin(), pts.end());
+  pts.erase(std::unique(pts.begin(), pts.end()), pts.end());
+  std::vector<short2> out;
+  for (const auto& p : pts) {
+    if (p.first * p.first + p.second * p.second <= c.r_col * c.r_col) {
+      short2 o;
+      o.x = static_cast<short>(p.first);
+      o.y = static_cast<short>(p.second);
+      out.push_back(o);
+    }
+  }
+  return out;
+}
+
+// The offset list depends on three small integers only: built once per (device, radii) and kept for
+// the life of the process (a few KB), so that building a map needs no host synchronisation.
+struct OffsetEntry
+{
+  int device, r_bnd, r_col, r_max, n;
+  short2* d_offsets;
+};
+std::mutex g_offsets_mutex;
+std::vector<OffsetEntry> g_offsets;
+
+hipError_t device_offsets(const CollisionParams& c, const short2** d_out, int* n_out)
+{
+  int device = 0;
+  hipError_t e = hipGetDevice(&device);
+  if (e != hipSuccess) return e;
+  std::lock_guard<std::mutex> lock(g_offsets_mutex);
+  for (const OffsetEntry& o : g_offsets) {
+    if (o.device == device && o.r_bnd == c.r_bnd && o.r_col == c.r_col && o.r_max == c.r_max) {
+      *d_out = o.d_offsets;
+      *n_out = o.n;
+      return hipSuccess;
+    }
+  }
+  const std::vector<short2> off = ring_offsets(c);
+  OffsetEntry ent{ device, c.r_bnd, c.r_col, c.r_max, static_cast<int>(off.size()), nullptr };
+  if (!off.empty()) {
+    e = hipMalloc(reinterpret_cast<void**>(&ent.d_offsets), off.size() * sizeof(short2));
+    if (e != hipSuccess) return e;
+    e = hipMemcpy(ent.d_offsets, off.data(), off.size() * sizeof(short2), hipMemcpyHostToDevice);
+    if (e != hipSuccess) return e;
+  }
+  g_offsets.push_back(ent);
+  *d_out = ent.d_offsets;
+  *n_out = ent.n;
+  return hipSuccess;
+}
+
+// stream-ordered scratch for one call: the inflated map
+struct MapScratch
+{
+  void* cells = nullptr;
+  HitMap map{ nullptr, 0, 0, 0 };
+};
+
+hipError_t build_hit_map(const CollisionParams& c, const int8_t* d_grid, MapScratch& sc, hipStream_t s)
+{
+  if (c.r_col < 0 || c.r_col > 8192 || c.r_max < c.r_bnd) return hipErrorInvalidValue;
+  const short2* d_off = nullptr;
+  int n_off = 0;
+  hipError_t e = device_offsets(c, &d_off, &n_off);
+  if (e != hipSuccess) return e;
+  const int R = c.r_col;
+  const int w = static_cast<int>(c.xsize) + 2 * R, h = static_cast<int>(c.ysize) + 2 * R;
+  const size_t bytes = static_cast<size_t>(w) * h;
+  e = hipMallocAsync(&sc.cells, bytes, s);
+  if (e != hipSuccess) return e;
+  e = hipMemsetAsync(sc.cells, 0, bytes, s);
+  if (e != hipSuccess) return e;
+  if (n_off > 0) {
+    const size_t n = static_cast<size_t>(c.xsize) * c.ysize;
+    hipLaunchKernelGGL(inflate_kernel, dim3(static_cast<unsigned>((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, c,
+                       d_grid, d_off, n_off, static_cast<uint8_t*>(sc.cells), R, w);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  sc.map.cells = static_cast<const uint8_t*>(sc.cells);
+  sc.map.R = R;
+  sc.map.w = w;
+  sc.map.h = h;
+  return hipSuccess;
+}
+
+void release_hit_map(MapScratch& sc, hipStream_t s)
+{
+  if (sc.cells) (void)hipFreeAsync(sc.cells, s);
+  sc.cells = nullptr;
+}
+
+// the inflated map pays off once a call tests a few thousand poses (EEA_COLLISION_MAP=0/1 forces)
+bool use_hit_map(size_t poses)
+{
+  static const int forced = [] {
+    const char* v = std::getenv("EEA_COLLISION_MAP");
+    return v ? (std::atoi(v) != 0 ? 1 : 0) : -1;
+  }();
+  if (forced >= 0) return forced == 1;
+  return poses >= 4096;
+}
+}  // namespace
+
 hipError_t launch_dwa_control(const CollisionParams& c, const DwaParams& d, const int8_t* d_grid,
                               const double* d_x0, const double* d_vb, const double* d_vref,
                               const double* d_xt_ref, unsigned n_ref, double dt_ref, unsigned P,
                               double* d_u_opt, int* d_found, hipStream_t s)
 {
   if (P == 0) return hipSuccess;
-  const size_t lds = sizeof(double) * static_cast<size_t>(d.ns[0]) * d.ns[1] * d.ns[2];
+  const size_t nsamp = static_cast<size_t>(d.ns[0]) * d.ns[1] * d.ns[2];
+  const size_t lds = sizeof(double) * nsamp;
   if (lds > 64 * 1024) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(dwa_control_kernel, dim3(P), dim3(kDwaBlock), lds, s, c, d, d_grid, d_x0, d_vb, d_vref,
-                     d_xt_ref, n_ref, dt_ref, d_u_opt, d_found);
+  // one lane per velocity sample: a single wavefront when the window has at most 64 samples
+  const unsigned block = nsamp <= 64 ? 64 : kDwaBlock;
+  if (use_hit_map(static_cast<size_t>(P) * nsamp * d.steps)) {
+    MapScratch sc;
+    hipError_t e = build_hit_map(c, d_grid, sc, s);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(dwa_control_kernel<true>, dim3(P), dim3(block), lds, s, c, d, sc.map, d_grid, d_x0, d_vb,
+                         d_vref, d_xt_ref, n_ref, dt_ref, d_u_opt, d_found);
+      e = hipGetLastError();
+    }
+    release_hit_map(sc, s);
+    return e;
+  }
+  hipLaunchKernelGGL(dwa_control_kernel<false>, dim3(P), dim3(block), lds, s, c, d, HitMap{ nullptr, 0, 0, 0 }, d_grid,
+                     d_x0, d_vb, d_vref, d_xt_ref, n_ref, dt_ref, d_u_opt, d_found);
   return hipGetLastError();
 }
 
@@ -263,8 +493,18 @@ hipError_t launch_collision_check(const CollisionParams& c, const int8_t* d_grid
                                   const double* d_pose, unsigned P, int* d_hit, hipStream_t s)
 {
   if (P == 0) return hipSuccess;
-  hipLaunchKernelGGL(collision_check_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, c,
-                     d_grid, d_pose, P, d_hit);
+  const dim3 grid((P + kBlock - 1) / kBlock);
+  if (use_hit_map(P)) {
+    MapScratch sc;
+    hipError_t e = build_hit_map(c, d_grid, sc, s);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(collision_check_map_kernel, grid, dim3(kBlock), 0, s, c, sc.map, d_pose, P, d_hit);
+      e = hipGetLastError();
+    }
+    release_hit_map(sc, s);
+    return e;
+  }
+  hipLaunchKernelGGL(collision_check_kernel, grid, dim3(kBlock), 0, s, c, d_grid, d_pose, P, d_hit);
   return hipGetLastError();
 }
 
@@ -273,8 +513,20 @@ hipError_t launch_validate_control(const CollisionParams& c, const int8_t* d_gri
                                    unsigned P, int* d_valid, hipStream_t s)
 {
   if (P == 0) return hipSuccess;
-  hipLaunchKernelGGL(validate_control_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, c,
-                     d_grid, d_x0, d_u, dt, steps, P, d_valid);
+  const dim3 grid((P + kBlock - 1) / kBlock);
+  if (use_hit_map(static_cast<size_t>(P) * steps)) {
+    MapScratch sc;
+    hipError_t e = build_hit_map(c, d_grid, sc, s);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(validate_control_kernel<true>, grid, dim3(kBlock), 0, s, c, sc.map, d_grid, d_x0, d_u, dt,
+                         steps, P, d_valid);
+      e = hipGetLastError();
+    }
+    release_hit_map(sc, s);
+    return e;
+  }
+  hipLaunchKernelGGL(validate_control_kernel<false>, grid, dim3(kBlock), 0, s, c, HitMap{ nullptr, 0, 0, 0 }, d_grid,
+                     d_x0, d_u, dt, steps, P, d_valid);
   return hipGetLastError();
 }
 }  // namespace eea

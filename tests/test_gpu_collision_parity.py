@@ -74,3 +74,42 @@ def test_validate_control_matches_oracle():
     # of a cell edge may legitimately land in the neighbouring cell: allow none in practice
     assert (got != ref).sum() == 0, np.nonzero(got != ref)[0][:10]
     assert 0 < ref.sum() < P
+
+
+@pytest.mark.parametrize("res,coll", [
+    (0.05, (0.7, 1.0, 0.2, 0.8)),    # yaml radii on a fine map: rings 14..20, collision within 18 cells
+    (0.25, (0.7, 1.0, 0.2, 0.8)),    # coarse map: rings 2..4
+    (0.1, (0.3, 0.6, 0.1, 0.5)),     # other radii and occupancy threshold
+    (0.1, (0.0, 0.5, 0.3, 0.8)),     # r_bnd = 0: the ring of radius 0 is empty, the centre cell is never tested
+    (0.1, (0.4, 0.4, 0.5, 0.8)),     # r_col beyond r_max: only the visited rings count
+])
+def test_inflated_map_and_ring_search_agree_with_oracle(res, coll):
+    """Large calls answer from the inflated map (occupied cells dilated by the ring offsets), small
+    calls walk the rings; both must reproduce the oracle bit for bit, also for poses outside the map."""
+    rng = np.random.default_rng(int(res * 1000) + int(coll[0] * 10))
+    xs, ys = 90, 70
+    xmin, ymin = -2.0, -1.5
+    data = np.zeros((ys, xs), dtype=np.int8)
+    for _ in range(12):
+        i, j = rng.integers(0, ys - 6), rng.integers(0, xs - 6)
+        data[i:i + rng.integers(1, 6), j:j + rng.integers(1, 6)] = rng.choice([100, 80, 79, 55, 50, 49])
+    data[rng.integers(0, ys, 30), rng.integers(0, xs, 30)] = 100
+    data[0, :] = 100      # obstacles on the border rows / columns: centres outside the map see them
+    data[:, xs - 1] = 100
+    g = po.GridMap(xmin, xmin + xs * res, ymin, ymin + ys * res, res, data.reshape(-1))
+    cfg = capi.make_collision_cfg(xmin, ymin, res, xs, ys, *coll)
+    P = 6000
+    poses = np.empty((P, 3))
+    poses[:, 0] = rng.uniform(xmin - 30 * res, xmin + (xs + 30) * res, P)
+    poses[:, 1] = rng.uniform(ymin - 30 * res, ymin + (ys + 30) * res, P)
+    poses[:, 2] = 0.0
+    ref = np.array([po.collision_check(coll, g, p)[0] for p in poses], dtype=np.int32)
+    d_grid, d_pose = torch.as_tensor(data).cuda(), torch.as_tensor(poses).cuda()
+    d_hit = torch.full((P,), -1, dtype=torch.int32, device="cuda")
+    capi.collision_check_batch(cfg, d_grid, d_pose, d_hit)            # >= 4096 poses: inflated map
+    d_small = torch.full((500,), -1, dtype=torch.int32, device="cuda")
+    capi.collision_check_batch(cfg, d_grid, d_pose[:500], d_small)    # ring search
+    torch.cuda.synchronize()
+    assert np.array_equal(d_hit.cpu().numpy(), ref), np.nonzero(d_hit.cpu().numpy() != ref)[0][:10]
+    assert np.array_equal(d_small.cpu().numpy(), ref[:500])
+    assert 0 < ref.sum() < P
