@@ -450,15 +450,21 @@ void release_hit_map(MapScratch& sc, hipStream_t s)
   sc.cells = nullptr;
 }
 
-// the inflated map pays off once a call tests a few thousand poses (EEA_COLLISION_MAP=0/1 forces)
-bool use_hit_map(size_t poses)
+// Inflated map or ring search?  A ring search is a chain of ~200 dependent byte loads per pose
+// (~40 us on MI355X, and the steps of one rollout follow each other in one lane), the map costs a
+// fixed ~25 us of stream operations plus a pass over the grid (measured: profiles/r01_tick_kernels.txt).
+// EEA_COLLISION_MAP=0/1 forces one of them.
+bool use_hit_map(size_t poses, unsigned sequential_steps, const CollisionParams& c)
 {
   static const int forced = [] {
     const char* v = std::getenv("EEA_COLLISION_MAP");
     return v ? (std::atoi(v) != 0 ? 1 : 0) : -1;
   }();
   if (forced >= 0) return forced == 1;
-  return poses >= 4096;
+  if (poses >= 4096) return true;
+  const double cells = static_cast<double>(c.xsize) * c.ysize;
+  const double t_map_us = 25.0 + 2.0e-6 * cells, t_ring_us = 40.0 * (sequential_steps ? sequential_steps : 1u);
+  return t_map_us < t_ring_us;
 }
 }  // namespace
 
@@ -473,7 +479,7 @@ hipError_t launch_dwa_control(const CollisionParams& c, const DwaParams& d, cons
   if (lds > 64 * 1024) return hipErrorInvalidValue;
   // one lane per velocity sample: a single wavefront when the window has at most 64 samples
   const unsigned block = nsamp <= 64 ? 64 : kDwaBlock;
-  if (use_hit_map(static_cast<size_t>(P) * nsamp * d.steps)) {
+  if (use_hit_map(static_cast<size_t>(P) * nsamp * d.steps, d.steps, c)) {
     MapScratch sc;
     hipError_t e = build_hit_map(c, d_grid, sc, s);
     if (e == hipSuccess) {
@@ -494,7 +500,7 @@ hipError_t launch_collision_check(const CollisionParams& c, const int8_t* d_grid
 {
   if (P == 0) return hipSuccess;
   const dim3 grid((P + kBlock - 1) / kBlock);
-  if (use_hit_map(P)) {
+  if (use_hit_map(P, 1, c)) {
     MapScratch sc;
     hipError_t e = build_hit_map(c, d_grid, sc, s);
     if (e == hipSuccess) {
@@ -514,7 +520,7 @@ hipError_t launch_validate_control(const CollisionParams& c, const int8_t* d_gri
 {
   if (P == 0) return hipSuccess;
   const dim3 grid((P + kBlock - 1) / kBlock);
-  if (use_hit_map(static_cast<size_t>(P) * steps)) {
+  if (use_hit_map(static_cast<size_t>(P) * steps, steps, c)) {
     MapScratch sc;
     hipError_t e = build_hit_map(c, d_grid, sc, s);
     if (e == hipSuccess) {

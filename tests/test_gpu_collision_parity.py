@@ -84,8 +84,9 @@ def test_validate_control_matches_oracle():
     (0.1, (0.4, 0.4, 0.5, 0.8)),     # r_col beyond r_max: only the visited rings count
 ])
 def test_inflated_map_and_ring_search_agree_with_oracle(res, coll):
-    """Large calls answer from the inflated map (occupied cells dilated by the ring offsets), small
-    calls walk the rings; both must reproduce the oracle bit for bit, also for poses outside the map."""
+    """Calls answer from the inflated map (occupied cells dilated by the ring offsets) or walk the rings,
+    whichever the cost model picks; both must reproduce the oracle bit for bit, also for poses outside
+    the map (test_both_implementations_forced runs this file with each one forced)."""
     rng = np.random.default_rng(int(res * 1000) + int(coll[0] * 10))
     xs, ys = 90, 70
     xmin, ymin = -2.0, -1.5
@@ -108,8 +109,25 @@ def test_inflated_map_and_ring_search_agree_with_oracle(res, coll):
     d_hit = torch.full((P,), -1, dtype=torch.int32, device="cuda")
     capi.collision_check_batch(cfg, d_grid, d_pose, d_hit)            # >= 4096 poses: inflated map
     d_small = torch.full((500,), -1, dtype=torch.int32, device="cuda")
-    capi.collision_check_batch(cfg, d_grid, d_pose[:500], d_small)    # ring search
+    capi.collision_check_batch(cfg, d_grid, d_pose[:500], d_small)    # small call: whichever path the cost model picks
     torch.cuda.synchronize()
     assert np.array_equal(d_hit.cpu().numpy(), ref), np.nonzero(d_hit.cpu().numpy() != ref)[0][:10]
     assert np.array_equal(d_small.cpu().numpy(), ref[:500])
     assert 0 < ref.sum() < P
+
+
+@pytest.mark.parametrize("forced", ["0", "1"])
+def test_both_implementations_forced(forced):
+    """EEA_COLLISION_MAP=0 / 1 pins the ring search / the inflated map for every call (read once per
+    process, hence the subprocess): the collision and DWA parity tests must pass with either."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("EEA_COLLISION_MAP") is not None:
+        pytest.skip("already inside a forced run")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EEA_COLLISION_MAP=forced)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_collision_parity.py",
+                        "tests/test_gpu_dwa_parity.py", "-k", "not forced"], cwd=root, env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]

@@ -39,7 +39,8 @@ def main():
     data[rng.integers(0, ys, 4000), rng.integers(0, xs, 4000)] = -1
     ccfg = capi.make_collision_cfg(0.0, 0.0, res, xs, ys, *COLL)
     d_grid = torch.as_tensor(data).cuda()
-    for P in (4096, 65536):
+    sizes = [int(v) for v in os.environ.get("TICK_SIZES", "4096,65536").split(",")]
+    for P in sizes:
         x0 = np.stack([rng.uniform(2, 118, P), rng.uniform(2, 58, P), rng.uniform(-np.pi, np.pi, P)], 1)
         vb = np.stack([rng.uniform(-1, 1, P), rng.uniform(-1, 1, P), rng.uniform(-2, 2, P)], 1)
         d_x0, d_vb = torch.as_tensor(x0).cuda(), torch.as_tensor(vb).cuda()
