@@ -85,7 +85,10 @@ __device__ __forceinline__ double fma_mode<double>(double v, int k, double acc)
   return d;
 }
 
-constexpr int kSub = 16;     // points staged per wavefront per MFMA pass
+// points staged per wavefront per MFMA pass: 16; 8 for the K = 30 instance, whose tiles would
+// otherwise hold the kernel at one workgroup per CU (K = 30, T = 500: 83 KB -> 67 KB of LDS).
+// (K = 30 always runs the exact-K instance, so host-side sizing and kernel agree.)
+__host__ __device__ constexpr int stage_points(int K) { return K == 30 ? 8 : 16; }
 
 __host__ __device__ inline int up4(int n) { return (n + 3) & ~3; }
 __host__ __device__ inline int table_stride(int K) { return (K + 1) & ~1; }  // even: 16-byte rows
@@ -93,7 +96,7 @@ __host__ __device__ inline int table_stride(int K) { return (K + 1) & ~1; }  // 
 // at most 16 - KS elements for one 16x16 tile, 32 - KS for two
 __host__ __device__ inline int wave_tab_elems(int K)
 {
-  return up4(2 * kSub * table_stride(K) + (K <= 16 ? 16 : 32));
+  return up4(2 * stage_points(K) * table_stride(K) + (K <= 16 ? 16 : 32));
 }
 
 // LDS carve (element offsets; every segment a multiple of 4 elements => 16-byte aligned)
@@ -129,7 +132,13 @@ __host__ __device__ inline LdsLayout lds_layout(int T, int Nmax, int K, int wave
   L.D = o; o += up4(K * K);
   L.sw = o; o += 48;
   L.E = o;
-  o += up4(waves * wave_tab_elems(K));
+  {
+    // the tiles, later the wavefronts' c_k partials: one K^2 buffer per wavefront inside its own tile
+    // region when that fits, else two shared buffers (control_agent's "folded" reduction)
+    const int tiles = waves * wave_tab_elems(K);
+    const int red = (K * K <= wave_tab_elems(K)) ? 0 : (waves < 2 ? waves : 2) * K * K;
+    o += up4(tiles > red ? tiles : red);
+  }
   L.total = o;
   return L;
 }
@@ -452,9 +461,11 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
       for (int c = 0; c < NT; ++c) acc[a][c] = acc_t{ R(0), R(0), R(0), R(0) };
 
     R* const tabx = s_E + wave * wave_tab_elems(K);
+    constexpr int kSub = stage_points(KC);
     R* const taby = tabx + kSub * KS;
-    const int sub = lane >> 4;  // which 16-point pass stages this lane's point
-    const int pl = lane & 15;
+    const int sub = lane / kSub;  // which pass stages this lane's point
+    const int pl = lane % kSub;   // its row in the staged tile
+    const int mk = lane >> 4, mi = lane & 15;  // matrix-instruction operand coordinates of this lane
 
     for (int c0 = 0; c0 < (EEA_ABLATE == 2 ? 0 : N); c0 += BLK) {
       const int q = c0 + wave * kWave + lane;
@@ -517,7 +528,7 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
       // four points per matrix instruction: operand of lane l = element (4g + l/16) * KS + l%16
       auto mma_group = [&](int g) {
         if (EEA_ABLATE == 7) return;
-        const int off = (4 * g + sub) * KS + pl;
+        const int off = (4 * g + mk) * KS + mi;
         R av[NT], bv[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -559,9 +570,11 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
     EEA_STAMP(6);
     // each wavefront's partial sums go into its own tile region (K^2 <= wave_tab_elems(K)), in
     // program order after its last operand read: no barrier between the tiles and the reduction
-    const int red_stride = wave_tab_elems(K);
+    const bool own_region = K2 <= wave_tab_elems(K);
+    const int red_stride = own_region ? wave_tab_elems(K) : K2;
+    const int red_bufs = own_region ? WAVES : (WAVES < 2 ? WAVES : 2);
     R* const s_red = s_E;
-    {
+    auto put_partials = [&](int buf, bool add) {
       const int j = lane & 15;
 #pragma unroll
       for (int a = 0; a < NT; ++a)
@@ -571,15 +584,32 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
           for (int r = 0; r < 4; ++r) {
             const int k1 = 16 * a + M::row(lane, r);
             const int k2 = 16 * c + j;
-            if (a < nt && c < nt && k1 < K && k2 < K) s_red[wave * red_stride + k2 * K + k1] = acc[a][c][r];
+            if (a < nt && c < nt && k1 < K && k2 < K) {
+              R* const dst = s_red + buf * red_stride + k2 * K + k1;
+              *dst = add ? *dst + acc[a][c][r] : acc[a][c][r];
+            }
           }
+    };
+    if (own_region) {
+      put_partials(wave, false);
+    } else {
+      // large bases: K^2 partials do not fit a wavefront's tile region.  Two shared buffers, filled
+      // by wavefronts 0 and 1 and added to by 2 and 3 (same lane <-> same entries, fixed order)
+      __syncthreads();  // every wavefront is done reading its tiles
+      if (wave < 2) put_partials(wave, false);
+      if (WAVES > 2) {
+        __syncthreads();
+        if (wave >= 2) put_partials(wave - 2, true);
+      }
     }
     __syncthreads();
     const R invN = R(1) / static_cast<R>(N);
     for (int m = tid; m < K2; m += BLK) {
       R s = R(0);
 #pragma unroll
-      for (int w = 0; w < WAVES; ++w) s += s_red[w * red_stride + m];
+      for (int w = 0; w < WAVES; ++w) {
+        if (w < red_bufs) s += s_red[w * red_stride + m];
+      }
       const R c = invN * s;
       if (p.ck != nullptr) p.ck[static_cast<size_t>(b) * K2 + m] = c;
       // fourier_diff = lamdak % (ck - phik)  (ergodic_control.hpp:422)
