@@ -88,7 +88,10 @@ __device__ __forceinline__ double fma_mode<double>(double v, int k, double acc)
 // points staged per wavefront per MFMA pass: 16; 8 for the K = 30 instance, whose tiles would
 // otherwise hold the kernel at one workgroup per CU (K = 30, T = 500: 83 KB -> 67 KB of LDS).
 // (K = 30 always runs the exact-K instance, so host-side sizing and kernel agree.)
-__host__ __device__ constexpr int stage_points(int K) { return K == 30 ? 8 : 16; }
+#ifndef EEA_STAGE8_K10
+#define EEA_STAGE8_K10 0
+#endif
+__host__ __device__ constexpr int stage_points(int K) { return (K == 30 || (EEA_STAGE8_K10 && K == 10)) ? 8 : 16; }
 
 __host__ __device__ inline int up4(int n) { return (n + 3) & ~3; }
 __host__ __device__ inline int table_stride(int K) { return (K + 1) & ~1; }  // even: 16-byte rows
