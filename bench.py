@@ -45,7 +45,8 @@ def parse():
     ap.add_argument("--force-gather", action="store_true",
                     help="run the c_k all-gather even with one rank (exercises the RCCL path on 1 GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per leg; 0 = skip")
-    ap.add_argument("--latency", action="store_true", help="also time the B = 1 dependent-call mode")
+    ap.add_argument("--latency", action="store_true", help="(default on one GPU) also time the B = 1 dependent-call mode")
+    ap.add_argument("--no-latency", action="store_true", help="skip the B = 1 dependent-call leg")
     ap.add_argument("--agent-groups", type=int, default=1,
                     help="split the rank's agents into this many groups, each launched on its own HIP stream: the "
                          "drain of one group's launch overlaps the fill of another's (agents are independent)")
@@ -271,7 +272,7 @@ def main():
             one, allc = cpu_baseline(args, T, args.cpu_seconds)
             out["cpu_baseline"] = one
             out["cpu_baseline_all_cores"] = allc
-        if args.latency and world == 1:
+        if world == 1 and not args.no_latency:
             x = poses[0].astype(np.float64)
             for _ in range(20):
                 eng.control(MAP_BOUNDS, x)
