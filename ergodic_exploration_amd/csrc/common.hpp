@@ -47,6 +47,10 @@ struct ControlParams
   R* rhot;
   int* status;
   long long* dbg;     // phase-timing stamps [B][4 waves][16] (diagnostic build only), else null
+  // single-agent path: host-visible completion word, set to done_seq (system-scope release) after
+  // u0 / status of agent 0 are written; null for batches
+  int* done;
+  int done_seq;
 };
 
 template <typename R>

@@ -336,6 +336,9 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
   if (any_bad) {
     // the reference throws out of rk4_.solve; nothing else of this agent is touched
     if (tid == 0 && p.status != nullptr) p.status[b] = 2;  // EEA_ERR_INVALID_TWIST
+    if (tid == 0 && p.done != nullptr && b == 0) {
+      __hip_atomic_store(p.done, p.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     return;
   }
   if (tid == 0 && p.status != nullptr) p.status[b] = 0;
@@ -806,6 +809,10 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
           o[0] = u[0];
           o[1] = u[1];
           o[2] = u[2];
+          if (p.done != nullptr && b == 0) {
+            // the host polls this word instead of waiting for the kernel's completion signal
+            __hip_atomic_store(p.done, p.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
         }
       }
       c0 += t0;

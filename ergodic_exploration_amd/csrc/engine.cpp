@@ -66,7 +66,7 @@ struct Mailbox
   double pose[3];  // viewed as R[3]
   double u0[3];    // viewed as R[3]
   int status;
-  int pad;
+  int done;  // completion sequence number written by the kernel (polled by eea_control)
 };
 }  // namespace
 
@@ -100,6 +100,8 @@ struct eea_engine
   void* h_stage = nullptr;  // pinned staging for mem_cols / ut transfers
   size_t h_stage_cap = 0;
   double last_pose[3] = { 0, 0, 0 };
+  int mail_seq = 0;          // sequence number of the last single-agent launch
+  int* mail_done = nullptr;  // set while eea_control fills the launch parameters
 };
 
 namespace
@@ -302,6 +304,8 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
   p.bdx = static_cast<R*>(io->d_bdx);
   p.rhot = static_cast<R*>(io->d_rhot);
   p.status = io->d_status;
+  p.done = e->mail_done;
+  p.done_seq = e->mail_seq;
   const int n_mem_max = rollout_only ? 0 : static_cast<int>(p.mem_stride);
   const size_t lds = e->impl_v1 ? eea::v1::control_lds_bytes<R>(p.T, p.K, n_mem_max, p.chunk)
                                 : eea::control_lds_bytes<R>(p.T, p.K, n_mem_max, p.chunk);
@@ -425,7 +429,8 @@ eea_status eea_create(const eea_config* cfg, eea_engine** out)
   }
   hipError_t err = hipStreamCreateWithFlags(&e->stream1, hipStreamNonBlocking);
   if (err == hipSuccess) {
-    err = hipHostMalloc(reinterpret_cast<void**>(&e->h_mail), sizeof(Mailbox), hipHostMallocMapped);
+    err = hipHostMalloc(reinterpret_cast<void**>(&e->h_mail), sizeof(Mailbox),
+                        hipHostMallocMapped | hipHostMallocCoherent);
   }
   if (err == hipSuccess) {
     std::memset(e->h_mail, 0, sizeof(Mailbox));
@@ -746,10 +751,29 @@ eea_status eea_control(eea_engine* e, double xmin, double xmax, double ymin, dou
   io.d_u0 = dm->u0;
   io.d_status = &dm->status;
   io.d_ut = e->d_ut1.p;
+  e->mail_seq = (e->mail_seq % 1000000) + 1;
+  e->mail_done = &dm->done;
   st = e->f32 ? control_batch_impl<float>(e, 1, &io, false, e->stream1)
               : control_batch_impl<double>(e, 1, &io, false, e->stream1);
+  e->mail_done = nullptr;
   if (st != EEA_OK) return st;
-  EEA_HIP(hipStreamSynchronize(e->stream1));
+  // the kernel publishes u0 / status and then the sequence number with a system-scope release: poll it
+  // (a few microseconds earlier than the stream's completion signal); bounded, then the ordinary wait
+  static const bool poll = [] {
+    const char* v = std::getenv("EEA_MAILBOX_POLL");
+    return v == nullptr || std::atoi(v) != 0;
+  }();
+  bool seen = false;
+  if (poll) {
+    const volatile int* const flag = &e->h_mail->done;
+    for (int spin = 0; spin < 200000; ++spin) {
+      if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == e->mail_seq) {
+        seen = true;
+        break;
+      }
+    }
+  }
+  if (!seen) EEA_HIP(hipStreamSynchronize(e->stream1));
   if (e->h_mail->status == EEA_ERR_INVALID_TWIST) {
     return fail(EEA_ERR_INVALID_TWIST, "Invalid twist y-velocity must be 0.");
   }
