@@ -4,6 +4,8 @@ Tolerances: c_k <= 1e-11 abs; trajectory, co-state, gradi
 controls <= 1e-9 abs (the kernel re-associates the RK4 sums into scans and evaluates the
 separable basis by recurrence); headings compared modulo 2 pi.  fp32: <= 1e-4 on u.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -75,6 +77,8 @@ def run_batch_vs_oracle(model, K, horizon, dt, B, n_mem, calls, seed, precision=
             # from identical state (SURVEY.md section 7 "hard parts": never compare long closed loops)
             ors[b].ut = got["ut"][b].T
     eng.close()
+    if os.environ.get("EEA_PRINT_WORST"):
+        print("worst", model, K, T, n_mem, {k: "%.2e" % v for k, v in worst.items()})
     assert worst["ck"] <= tol_ck, worst
     for k in ("traj_xy", "traj_th", "edx", "bdx", "rhot", "ut", "u0"):
         assert worst[k] <= tol, worst
@@ -315,3 +319,18 @@ def test_random_shapes_against_oracle(seed):
     # the oracle costs O(K^2 (T + n_mem)) trig calls per agent and call: bound the batch
     B = 2 if K * K * (steps + n_mem) > 60000 else 4
     run_batch_vs_oracle(model, K, steps * dt, dt, B=B, n_mem=n_mem, calls=2, seed=seed)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_shapes_fp32_engine(seed):
+    """The same randomised shapes on the fp32 engine against the fp64 oracle: controls <= 1e-4,
+    co-state <= 5e-4, c_k <= 1e-5 (SURVEY.md 8(d) fp32 bars; measured worst 2.6e-5 / 2.8e-4 / 3e-6)."""
+    rng = np.random.default_rng(1000 + seed)
+    model = ["omni", "simple_cart"][seed % 2]
+    K = int(rng.choice([1, 2, 3, 5, 6, 9, 10, 11, 13, 16, 17, 20, 24, 30, 32]))
+    steps = int(rng.choice([2, 3, 7, 31, 64, 65, 97, 128, 160, 200, 257, 420]))
+    n_mem = int(rng.choice([0, 0, 1, 5, 33, 100]))
+    B = 2 if K * K * (steps + n_mem) > 60000 else 4
+    worst = run_batch_vs_oracle(model, K, steps * 0.0625, 0.0625, B=B, n_mem=n_mem, calls=2, seed=seed,
+                                precision=capi.PREC_F32, tol=5e-4, tol_ck=1e-5)
+    assert worst["u0"] <= 1e-4 and worst["ut"] <= 1e-4, worst
