@@ -99,7 +99,8 @@ __device__ __forceinline__ bool collision_check(const CollisionParams& c,
 struct HitMap
 {
   const uint8_t* cells;
-  int R, w, h;  // w = xsize + 2R, h = ysize + 2R
+  int R, w, h;    // w = xsize + 2R, h = ysize + 2R
+  uint8_t stamp;  // a cell is marked iff it holds this build's stamp (older stamps are stale, no clear)
 };
 
 // grid cell of a world point as collisionCheck derives it (grid.cpp:143-159), as signed ints
@@ -119,13 +120,14 @@ __device__ __forceinline__ bool hit_lookup(const HitMap& m, int cx, int cy)
   // centres further than R outside the grid see no cell at all (the unsigned cell indices of
   // collision.cpp:216-243 fall outside gridBounds)
   if (hx < 0 || hy < 0 || hx >= m.w || hy >= m.h) return false;
-  return m.cells[static_cast<size_t>(hy) * m.w + hx] != 0;
+  return m.cells[static_cast<size_t>(hy) * m.w + hx] == m.stamp;
 }
 
 // occupied cells mark every centre that reaches them through one of the ring offsets
 __global__ __launch_bounds__(kBlock) void inflate_kernel(const CollisionParams c, const int8_t* __restrict__ grid,
                                                          const short2* __restrict__ offsets, int n_off,
-                                                         uint8_t* __restrict__ cells, int R, int w)
+                                                         uint8_t* __restrict__ cells, int R, int w,
+                                                         uint8_t stamp)
 {
   const size_t q = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
   const size_t n = static_cast<size_t>(c.xsize) * c.ysize;
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(kBlock) void inflate_kernel(const CollisionParams c
   const int i = static_cast<int>(q / c.xsize), j = static_cast<int>(q - static_cast<size_t>(i) * c.xsize);
   for (int o = 0; o < n_off; ++o) {
     const short2 d = offsets[o];  // cell = centre + d
-    cells[static_cast<size_t>(i - d.y + R) * w + (j - d.x + R)] = 1;  // same value from every writer
+    cells[static_cast<size_t>(i - d.y + R) * w + (j - d.x + R)] = stamp;  // same value from every writer
   }
 }
 
@@ -409,11 +411,26 @@ hipError_t device_offsets(const CollisionParams& c, const short2** d_out, int* n
   return hipSuccess;
 }
 
-// stream-ordered scratch for one call: the inflated map
+// The map buffer of a (device, stream) pair is kept between calls: launches on one stream are
+// ordered, so a buffer is never written while an earlier call still reads it.  Every build marks
+// with a fresh stamp (1..255), which makes the marks of earlier builds stale without clearing the
+// buffer; it is cleared when the stamps wrap.  A build is then a single scatter kernel.
+struct MapBuffer
+{
+  int device;
+  hipStream_t stream;
+  uint8_t* cells;
+  size_t cap;
+  unsigned stamp;
+};
+std::mutex g_maps_mutex;
+std::vector<MapBuffer> g_maps;
+constexpr size_t kMaxMapBuffers = 64;
+
 struct MapScratch
 {
-  void* cells = nullptr;
-  HitMap map{ nullptr, 0, 0, 0 };
+  void* async_cells = nullptr;  // stream-ordered allocation (only when the buffer table is full)
+  HitMap map{ nullptr, 0, 0, 0, 0 };
 };
 
 hipError_t build_hit_map(const CollisionParams& c, const int8_t* d_grid, MapScratch& sc, hipStream_t s)
@@ -426,28 +443,69 @@ hipError_t build_hit_map(const CollisionParams& c, const int8_t* d_grid, MapScra
   const int R = c.r_col;
   const int w = static_cast<int>(c.xsize) + 2 * R, h = static_cast<int>(c.ysize) + 2 * R;
   const size_t bytes = static_cast<size_t>(w) * h;
-  e = hipMallocAsync(&sc.cells, bytes, s);
+  int device = 0;
+  e = hipGetDevice(&device);
   if (e != hipSuccess) return e;
-  e = hipMemsetAsync(sc.cells, 0, bytes, s);
-  if (e != hipSuccess) return e;
+
+  uint8_t* cells = nullptr;
+  unsigned stamp = 1;
+  {
+    std::lock_guard<std::mutex> lock(g_maps_mutex);
+    MapBuffer* buf = nullptr;
+    for (MapBuffer& b : g_maps) {
+      if (b.device == device && b.stream == s) buf = &b;
+    }
+    if (buf == nullptr && g_maps.size() < kMaxMapBuffers) {
+      g_maps.push_back(MapBuffer{ device, s, nullptr, 0, 0 });
+      buf = &g_maps.back();
+    }
+    if (buf != nullptr) {
+      if (buf->cap < bytes) {
+        if (buf->cells) (void)hipFree(buf->cells);  // waits for the kernels that still use it
+        buf->cells = nullptr;
+        buf->cap = 0;
+        e = hipMalloc(reinterpret_cast<void**>(&buf->cells), bytes);
+        if (e != hipSuccess) return e;
+        buf->cap = bytes;
+        buf->stamp = 0;
+        e = hipMemsetAsync(buf->cells, 0, bytes, s);
+        if (e != hipSuccess) return e;
+      }
+      if (++buf->stamp > 255u) {
+        e = hipMemsetAsync(buf->cells, 0, buf->cap, s);
+        if (e != hipSuccess) return e;
+        buf->stamp = 1;
+      }
+      cells = buf->cells;
+      stamp = buf->stamp;
+    }
+  }
+  if (cells == nullptr) {
+    e = hipMallocAsync(&sc.async_cells, bytes, s);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(sc.async_cells, 0, bytes, s);
+    if (e != hipSuccess) return e;
+    cells = static_cast<uint8_t*>(sc.async_cells);
+  }
   if (n_off > 0) {
     const size_t n = static_cast<size_t>(c.xsize) * c.ysize;
     hipLaunchKernelGGL(inflate_kernel, dim3(static_cast<unsigned>((n + kBlock - 1) / kBlock)), dim3(kBlock), 0, s, c,
-                       d_grid, d_off, n_off, static_cast<uint8_t*>(sc.cells), R, w);
+                       d_grid, d_off, n_off, cells, R, w, static_cast<uint8_t>(stamp));
     e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
-  sc.map.cells = static_cast<const uint8_t*>(sc.cells);
+  sc.map.cells = cells;
   sc.map.R = R;
   sc.map.w = w;
   sc.map.h = h;
+  sc.map.stamp = static_cast<uint8_t>(stamp);
   return hipSuccess;
 }
 
 void release_hit_map(MapScratch& sc, hipStream_t s)
 {
-  if (sc.cells) (void)hipFreeAsync(sc.cells, s);
-  sc.cells = nullptr;
+  if (sc.async_cells) (void)hipFreeAsync(sc.async_cells, s);
+  sc.async_cells = nullptr;
 }
 
 // Inflated map or ring search?  A ring search is a chain of ~200 dependent byte loads per pose
@@ -490,7 +548,7 @@ hipError_t launch_dwa_control(const CollisionParams& c, const DwaParams& d, cons
     release_hit_map(sc, s);
     return e;
   }
-  hipLaunchKernelGGL(dwa_control_kernel<false>, dim3(P), dim3(block), lds, s, c, d, HitMap{ nullptr, 0, 0, 0 }, d_grid,
+  hipLaunchKernelGGL(dwa_control_kernel<false>, dim3(P), dim3(block), lds, s, c, d, HitMap{ nullptr, 0, 0, 0, 0 }, d_grid,
                      d_x0, d_vb, d_vref, d_xt_ref, n_ref, dt_ref, d_u_opt, d_found);
   return hipGetLastError();
 }
@@ -531,7 +589,7 @@ hipError_t launch_validate_control(const CollisionParams& c, const int8_t* d_gri
     release_hit_map(sc, s);
     return e;
   }
-  hipLaunchKernelGGL(validate_control_kernel<false>, grid, dim3(kBlock), 0, s, c, HitMap{ nullptr, 0, 0, 0 }, d_grid,
+  hipLaunchKernelGGL(validate_control_kernel<false>, grid, dim3(kBlock), 0, s, c, HitMap{ nullptr, 0, 0, 0, 0 }, d_grid,
                      d_x0, d_u, dt, steps, P, d_valid);
   return hipGetLastError();
 }

@@ -124,8 +124,11 @@ eea_status stage_reserve(eea_engine* e, size_t bytes)
   if (e->h_stage) (void)hipHostFree(e->h_stage);
   e->h_stage = nullptr;
   e->h_stage_cap = 0;
-  EEA_HIP(hipHostMalloc(&e->h_stage, bytes, hipHostMallocDefault));
-  e->h_stage_cap = bytes;
+  // grows geometrically: the replay memory adds a column per tick until it reaches the batch size
+  size_t want = e->h_stage_cap ? 2 * e->h_stage_cap : 4096;
+  if (want < bytes) want = bytes;
+  EEA_HIP(hipHostMalloc(&e->h_stage, want, hipHostMallocDefault));
+  e->h_stage_cap = want;
   return EEA_OK;
 }
 
@@ -736,7 +739,11 @@ eea_status eea_control(eea_engine* e, double xmin, double xmax, double ymin, dou
     const size_t bytes = e->rs * 3 * n_mem;
     st = stage_reserve(e, bytes);
     if (st != EEA_OK) return st;
-    EEA_HIP(e->d_mem1.reserve(bytes));
+    {
+      size_t want = 4096;  // power-of-two steps: the replay memory grows by one column per tick
+      while (want < bytes) want *= 2;
+      EEA_HIP(e->d_mem1.reserve(want));
+    }
     if (e->f32) to_real<float>(h_mem_cols, static_cast<float*>(e->h_stage), 3 * static_cast<size_t>(n_mem));
     else std::memcpy(e->h_stage, h_mem_cols, bytes);
     EEA_HIP(hipMemcpyAsync(e->d_mem1.p, e->h_stage, bytes, hipMemcpyHostToDevice, e->stream1));

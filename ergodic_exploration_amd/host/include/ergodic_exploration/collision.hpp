@@ -1,11 +1,13 @@
 // Collision: Bresenham ring search around the robot cell (reference collision.hpp /
 // collision.cpp).  The search itself runs in the batched device kernels
-// (eea_collision_check_batch / eea_validate_control_batch); this class owns the parameters and a
-// device copy of the last grid it was asked about.
+// (eea_collision_check_batch / eea_validate_control_batch); this class owns the parameters.  The
+// device copy of a map's cells lives with the GridMap (device_cells), call arguments in a per-thread
+// scratch buffer: a call costs two small copies and one launch, no allocation.
 #pragma once
 
 #include <hip/hip_runtime_api.h>
 
+#include <cstring>
 #include <memory>
 #include <stdexcept>
 #include <vector>
@@ -44,30 +46,37 @@ public:
   std::vector<bool> collisionCheck(const GridMap& grid, const mat& poses) const
   {
     const unsigned P = static_cast<unsigned>(poses.n_cols());
-    std::vector<int> hit(P, 0);
     if (P == 0) return {};
-    Buffers b(grid, P, 1);
-    check(hipMemcpy(b.pose, poses.memptr(), sizeof(double) * 3 * P, hipMemcpyHostToDevice));
+    const int8_t* const d_grid = device_cells(grid);
+    const size_t pose_bytes = sizeof(double) * 3 * P;
+    const PinnedScratch sc = pinned_scratch(pose_bytes + sizeof(int) * P);
+    std::memcpy(sc.host, poses.memptr(), pose_bytes);
     const eea_collision_cfg cfg = config(grid);
-    throw_on_error(eea_collision_check_batch(device_ordinal(), &cfg, b.grid, b.pose, P, b.out, nullptr));
-    check(hipMemcpy(hit.data(), b.out, sizeof(int) * P, hipMemcpyDeviceToHost));
-    return std::vector<bool>(hit.begin(), hit.end());
+    throw_on_error(eea_collision_check_batch(device_ordinal(), &cfg, d_grid, static_cast<const double*>(sc.dev), P,
+                                             reinterpret_cast<int*>(static_cast<char*>(sc.dev) + pose_bytes), nullptr));
+    hip_check(hipStreamSynchronize(nullptr));
+    const int* const hit = reinterpret_cast<const int*>(static_cast<const char*>(sc.host) + pose_bytes);
+    return std::vector<bool>(hit, hit + P);
   }
 
   // validate_control (reference numerics.hpp:312-330) for P (state, twist) pairs: true = collision free
   std::vector<bool> validateControl(const GridMap& grid, const mat& x0, const mat& u, double dt, double horizon) const
   {
     const unsigned P = static_cast<unsigned>(x0.n_cols());
-    std::vector<int> ok(P, 0);
     if (P == 0) return {};
-    Buffers b(grid, P, 2);
-    check(hipMemcpy(b.pose, x0.memptr(), sizeof(double) * 3 * P, hipMemcpyHostToDevice));
-    check(hipMemcpy(b.pose + 3 * P, u.memptr(), sizeof(double) * 3 * P, hipMemcpyHostToDevice));
+    const int8_t* const d_grid = device_cells(grid);
+    const size_t pose_bytes = sizeof(double) * 3 * P;
+    const PinnedScratch sc = pinned_scratch(2 * pose_bytes + sizeof(int) * P);
+    std::memcpy(sc.host, x0.memptr(), pose_bytes);
+    std::memcpy(static_cast<char*>(sc.host) + pose_bytes, u.memptr(), pose_bytes);
     const eea_collision_cfg cfg = config(grid);
-    throw_on_error(eea_validate_control_batch(device_ordinal(), &cfg, b.grid, b.pose, b.pose + 3 * P, dt, horizon,
-                                              P, b.out, nullptr));
-    check(hipMemcpy(ok.data(), b.out, sizeof(int) * P, hipMemcpyDeviceToHost));
-    return std::vector<bool>(ok.begin(), ok.end());
+    char* const dev = static_cast<char*>(sc.dev);
+    throw_on_error(eea_validate_control_batch(device_ordinal(), &cfg, d_grid, reinterpret_cast<const double*>(dev),
+                                              reinterpret_cast<const double*>(dev + pose_bytes), dt, horizon, P,
+                                              reinterpret_cast<int*>(dev + 2 * pose_bytes), nullptr));
+    hip_check(hipStreamSynchronize(nullptr));
+    const int* const ok = reinterpret_cast<const int*>(static_cast<const char*>(sc.host) + 2 * pose_bytes);
+    return std::vector<bool>(ok, ok + P);
   }
 
   double totalPadding() const { return boundary_radius_ + obstacle_threshold_; }
@@ -75,10 +84,6 @@ public:
   eea_collision_cfg deviceConfig(const GridMap& grid) const { return config(grid); }
 
 private:
-  static void check(hipError_t e)
-  {
-    if (e != hipSuccess) throw std::runtime_error(std::string("hip: ") + hipGetErrorString(e));
-  }
   eea_collision_cfg config(const GridMap& grid) const
   {
     eea_collision_cfg c;
@@ -93,28 +98,6 @@ private:
     c.occupied_threshold = occupied_threshold_;
     return c;
   }
-  // scoped device buffers of one call
-  struct Buffers
-  {
-    int8_t* grid = nullptr;
-    double* pose = nullptr;
-    int* out = nullptr;
-    Buffers(const GridMap& g, unsigned P, unsigned pose_sets)
-    {
-      check(hipSetDevice(device_ordinal()));
-      const size_t cells = g.gridData().size();
-      check(hipMalloc(reinterpret_cast<void**>(&grid), cells ? cells : 1));
-      check(hipMalloc(reinterpret_cast<void**>(&pose), sizeof(double) * 3 * P * pose_sets));
-      check(hipMalloc(reinterpret_cast<void**>(&out), sizeof(int) * P));
-      if (cells) check(hipMemcpy(grid, g.gridData().data(), cells, hipMemcpyHostToDevice));
-    }
-    ~Buffers()
-    {
-      (void)hipFree(grid);
-      (void)hipFree(pose);
-      (void)hipFree(out);
-    }
-  };
   double boundary_radius_, search_radius_, obstacle_threshold_, occupied_threshold_;
 };
 

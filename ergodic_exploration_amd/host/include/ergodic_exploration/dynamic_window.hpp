@@ -9,6 +9,8 @@
 
 #include <cmath>
 #include <iostream>
+#include <algorithm>
+#include <cstring>
 #include <tuple>
 
 #include <ergodic_exploration/collision.hpp>
@@ -68,42 +70,38 @@ private:
     }
     return n;
   }
-  static void check(hipError_t e)
-  {
-    if (e != hipSuccess) throw std::runtime_error(std::string("hip: ") + hipGetErrorString(e));
-  }
   std::tuple<bool, vec> run(const GridMap& grid, const vec& x0, const vec& vb, const vec* vref, const mat* xt_ref,
                             double dt_ref) const
   {
-    check(hipSetDevice(device_ordinal()));
-    const size_t cells = grid.gridData().size();
     const size_t n_ref = xt_ref ? xt_ref->n_cols() : 0;
-    int8_t* d_grid = nullptr;
-    double* d_buf = nullptr;  // x0 | vb | vref | u_opt | xt_ref
-    int* d_found = nullptr;
-    check(hipMalloc(reinterpret_cast<void**>(&d_grid), cells ? cells : 1));
-    check(hipMalloc(reinterpret_cast<void**>(&d_buf), sizeof(double) * (12 + 3 * n_ref)));
-    check(hipMalloc(reinterpret_cast<void**>(&d_found), sizeof(int)));
-    if (cells) check(hipMemcpy(d_grid, grid.gridData().data(), cells, hipMemcpyHostToDevice));
-    check(hipMemcpy(d_buf, x0.memptr(), sizeof(double) * 3, hipMemcpyHostToDevice));
-    check(hipMemcpy(d_buf + 3, vb.memptr(), sizeof(double) * 3, hipMemcpyHostToDevice));
-    if (vref) check(hipMemcpy(d_buf + 6, vref->memptr(), sizeof(double) * 3, hipMemcpyHostToDevice));
-    if (xt_ref) check(hipMemcpy(d_buf + 12, xt_ref->memptr(), sizeof(double) * 3 * n_ref, hipMemcpyHostToDevice));
+    const int8_t* const d_grid = device_cells(grid);
+    // pinned block the kernel reads and writes directly: x0 | vb | vref | u_opt | found; the reference
+    // trajectory (read by every sample at every step) goes to device memory
+    const size_t n_head = 13;
+    const PinnedScratch sc = pinned_scratch(sizeof(double) * n_head);
+    double* const h = static_cast<double*>(sc.host);
+    double* const d_buf = static_cast<double*>(sc.dev);
+    for (int c = 0; c < 3; ++c) {
+      h[c] = x0(c);
+      h[3 + c] = vb(c);
+      h[6 + c] = vref ? (*vref)(c) : 0.0;
+    }
+    double* d_ref = nullptr;
+    if (xt_ref) {
+      d_ref = static_cast<double*>(device_scratch(sizeof(double) * 3 * n_ref));
+      hip_check(hipMemcpyAsync(d_ref, xt_ref->memptr(), sizeof(double) * 3 * n_ref, hipMemcpyHostToDevice, nullptr));
+    }
     const eea_collision_cfg ccfg = collision_.deviceConfig(grid);
     const eea_status st =
-        eea_dwa_control_batch(device_ordinal(), &ccfg, &cfg_, d_grid, d_buf, d_buf + 3, vref ? d_buf + 6 : nullptr,
-                              xt_ref ? d_buf + 12 : nullptr, static_cast<unsigned>(n_ref), dt_ref, 1, d_buf + 9,
-                              d_found, nullptr);
-    vec u(3);
-    int found = 0;
-    if (st == EEA_OK) {
-      check(hipMemcpy(u.memptr(), d_buf + 9, sizeof(double) * 3, hipMemcpyDeviceToHost));
-      check(hipMemcpy(&found, d_found, sizeof(int), hipMemcpyDeviceToHost));
-    }
-    (void)hipFree(d_grid);
-    (void)hipFree(d_buf);
-    (void)hipFree(d_found);
+        eea_dwa_control_batch(device_ordinal(), &ccfg, &cfg_, d_grid, d_buf, d_buf + 3, vref ? d_buf + 6 : nullptr, d_ref,
+                              static_cast<unsigned>(n_ref), dt_ref, 1, d_buf + 9, reinterpret_cast<int*>(d_buf + 12),
+                              nullptr);
     throw_on_error(st);
+    hip_check(hipStreamSynchronize(nullptr));  // also covers the pageable copy above
+    vec u(3);
+    for (int c = 0; c < 3; ++c) u(c) = h[9 + c];
+    int found = 0;
+    std::memcpy(&found, &h[12], sizeof(int));
     if (!found) std::cout << "DWA Failed! Not even 1 solution found" << std::endl;
     return std::make_tuple(found != 0, u);
   }

@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdint>
 #include <iostream>
+#include <memory>
 #include <stdexcept>
 #include <vector>
 
@@ -107,6 +108,9 @@ public:
   }
 
   const GridData& gridData() const { return grid_data_; }
+  // Opaque slot for a device copy of the cells, filled on first use by the classes that run on the
+  // device (collision.hpp).  The map is immutable after construction, so copies of a GridMap share it.
+  std::shared_ptr<const void>& deviceCache() const { return device_cache_; }
   double resolution() const { return resolution_; }
   double xmin() const { return xmin_; }
   double ymin() const { return ymin_; }
@@ -120,5 +124,6 @@ private:
   unsigned int xsize_, ysize_;
   double resolution_, xmin_, ymin_, xmax_, ymax_;
   GridData grid_data_;
+  mutable std::shared_ptr<const void> device_cache_;
 };
 }  // namespace ergodic_exploration

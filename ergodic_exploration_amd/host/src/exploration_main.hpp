@@ -9,6 +9,7 @@
 // compares the twists tick by tick (map_io.hpp describes both file formats).
 #pragma once
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <array>
@@ -224,8 +225,14 @@ int exploration_main(int argc, char** argv, bool is_cart)
     map_io::write_map(rec, occ);
   }
   ee::vec vb = { 0.0, 0.0, 0.0 };  // odometry twist: the simulated robot executes the command exactly
+  const auto loop_t0 = std::chrono::steady_clock::now();
+  double tick_us = 0.0;
   for (int t = 0; t < ticks; ++t) {
+    const auto t0 = std::chrono::steady_clock::now();
     const ee::vec u = exploration.tick(grid, pose, vb, val_dt, val_horizon);
+    const double this_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+    tick_us += this_us;
+    if (std::getenv("EEA_SLOW_TICKS") && this_us > 1000.0) std::fprintf(stderr, "slow tick %d: %.0f us (%s)\n", t, this_us, kSource[static_cast<int>(exploration.source())]);
     print_tick(t, pose, u);
     if (rec != nullptr) {
       map_io::Tick k;
@@ -242,6 +249,10 @@ int exploration_main(int argc, char** argv, bool is_cart)
     pose(2) = ee::normalize_angle_PI(pose(2));
     vb = u;
   }
+  const double loop_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - loop_t0).count();
+  std::printf("# loop: %d ticks, %.1f us per tick in Exploration::tick (control + validate_control + fallback "
+              "planner), %.1f us with printing and the simulated robot\n", ticks, ticks > 0 ? tick_us / ticks : 0.0,
+              ticks > 0 ? loop_us / ticks : 0.0);
   if (rec != nullptr) std::fclose(rec);
   return 0;
 }
