@@ -334,3 +334,20 @@ def test_random_shapes_fp32_engine(seed):
     worst = run_batch_vs_oracle(model, K, steps * 0.0625, 0.0625, B=B, n_mem=n_mem, calls=2, seed=seed,
                                 precision=capi.PREC_F32, tol=5e-4, tol_ck=1e-5)
     assert worst["u0"] <= 1e-4 and worst["ut"] <= 1e-4, worst
+
+
+def test_longest_horizon_and_lds_limit():
+    """Maximum sizes: a horizon of 1500 steps (K = 10, fp64: 140 KB of the 160 KB LDS, six chunks of
+    256 steps with carried scans) still matches the oracle; one that cannot fit is refused with
+    EEA_ERR_UNSUPPORTED at launch instead of producing garbage."""
+    run_batch_vs_oracle("omni", 10, 1500 * 0.0625, 0.0625, B=2, n_mem=0, calls=1, seed=77)
+    eng, _ = make_pair("omni", 10, 2600 * 0.0625, dt=0.0625, n_oracles=0)
+    T = eng.T
+    assert T == 2600
+    d_pose = dev(random_poses(np.random.default_rng(1), 1))
+    d_ut = torch.zeros((1, T, 3), dtype=torch.float64, device="cuda")
+    d_u0 = torch.empty((1, 3), dtype=torch.float64, device="cuda")
+    with pytest.raises(capi.EngineError) as ei:
+        eng.control_batch(1, d_pose, d_ut, d_u0)
+    assert ei.value.status == capi.ERR_UNSUPPORTED and "LDS" in str(ei.value)
+    eng.close()
