@@ -105,6 +105,11 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    # plumbing test on a single-GPU box: EEA_DIST_BACKEND=gloo with --no-gather runs several ranks on one
+    # device (RCCL refuses two ranks per GPU); on a real node every rank has its own device
+    backend = os.environ.get("EEA_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_gather
     if use_dist:
@@ -115,7 +120,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     f32 = args.precision == "f32"
     tdt = torch.float32 if f32 else torch.float64
