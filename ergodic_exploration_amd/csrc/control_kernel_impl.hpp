@@ -306,6 +306,7 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
   }
 
   // ---- controls: shift left by one column, last column zero (ergodic_control.hpp:233-234)
+  R w_own = R(0);  // this thread's yaw rate of the first chunk: the heading scan starts from registers
   {
     bool bad = false;
     for (int i = tid; i < T; i += BLK) {
@@ -322,26 +323,16 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
       s_vx[i] = vx;
       s_vy[i] = vy;
       s_w[i] = w;
+      if (i == tid) w_own = w;
       // SimpleCart::operator() rejects a lateral velocity (cart.hpp:167-170)
       if (MODEL == kModelSimpleCart && !(fabs(vy) < R(1.0e-12))) bad = true;
     }
-    // every wavefront publishes its own flag: no initialisation pass, one barrier
+    // every wavefront publishes its own flag: no initialisation pass; the flags and the controls
+    // become visible with the barrier inside the first heading scan (nothing is written before it)
     const bool wave_bad = __any(bad);
     if (lane == 0) s_bad[wave] = wave_bad ? 1 : 0;
   }
-  __syncthreads();
-  int any_bad = 0;
-#pragma unroll
-  for (int w = 0; w < WAVES; ++w) any_bad |= s_bad[w];
-  if (any_bad) {
-    // the reference throws out of rk4_.solve; nothing else of this agent is touched
-    if (tid == 0 && p.status != nullptr) p.status[b] = 2;  // EEA_ERR_INVALID_TWIST
-    if (tid == 0 && p.done != nullptr && b == 0) {
-      __hip_atomic_store(p.done, p.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-    return;
-  }
-  if (tid == 0 && p.status != nullptr) p.status[b] = 0;
+  if (WAVES == 1 || EEA_ABLATE == 4) __syncthreads();  // single wavefront: a fence, no s_barrier
   EEA_STAMP(1);
 
   const R dt = p.dt;
@@ -360,11 +351,25 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
       const bool act = i < T;
       R d = R(0), w = R(0);
       if (act) {
-        w = s_w[i];
+        w = (base == 0) ? w_own : s_w[i];
         d = dt6 * (((w + R(2) * w) + R(2) * w) + w);
       }
       R tot_th;
       const R inc = block_scan<R, WAVES>(d, s_sw, tot_th, multi_chunk);
+      if (base == 0) {
+        int any_bad = 0;
+#pragma unroll
+        for (int wv = 0; wv < WAVES; ++wv) any_bad |= s_bad[wv];
+        if (any_bad) {
+          // the reference throws out of rk4_.solve; nothing else of this agent is touched
+          if (tid == 0 && p.status != nullptr) p.status[b] = 2;  // EEA_ERR_INVALID_TWIST
+          if (tid == 0 && p.done != nullptr && b == 0) {
+            __hip_atomic_store(p.done, p.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          }
+          return;
+        }
+        if (tid == 0 && p.status != nullptr) p.status[b] = 0;
+      }
       EEA_STAMP(2);
 
       // pre-step heading (own prefix minus own increment), mid stage theta + dt (0.5 w) shared
