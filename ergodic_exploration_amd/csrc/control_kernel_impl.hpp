@@ -344,6 +344,9 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
   // heading: theta_i = wrap(theta_{i-1} + dt/6 (w + 2w + 2w + w)) (integrator.hpp:146-148,183)
   //          == wrap(theta_0 + prefix sum) up to rounding
   // position: x_i = x_{i-1} + dt/6 (k1 + 2 k2 + 2 k3 + k4) with k2 == k3 (integrator.hpp:176-184)
+  // basis sin/cos of this thread's own rollout point (last chunk): with no memory columns and a
+  // single chunk the contraction takes them from registers and needs no barrier in front of it
+  R own_c1x = R(0), own_s1x = R(0), own_c1y = R(0), own_s1y = R(0);
   {
     R carry_th = wrap_pi_fast(th0), carry_x = x0, carry_y = y0;
     for (int base = 0; base < T; base += BLK) {
@@ -421,9 +424,13 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
           sc_pi(x * p.inv_lx, &s, &c);
           s_c1x[nmem + i] = c;
           s_s1x[nmem + i] = s;
+          own_c1x = c;
+          own_s1x = s;
           sc_pi(y * p.inv_ly, &s, &c);
           s_c1y[nmem + i] = c;
           s_s1y[nmem + i] = s;
+          own_c1y = c;
+          own_s1y = s;
           // barrier gradient (ergodic_control.hpp:453-474), carried to the backward half
           const R eps = R(0.05), weight = R(25);
           R b0 = R(0), b1 = R(0);
@@ -456,7 +463,10 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
       s_s1y[j] = s;
     }
   }
-  __syncthreads();
+  // point q of the contraction is this thread's own rollout point when nothing is prepended and the
+  // horizon is one chunk; the other threads' points are first read after the reduction's barrier
+  const bool own_points = (nmem == 0) && !multi_chunk;
+  if (!own_points) __syncthreads();
   EEA_STAMP(5);
 
   // ---- c_k = (1/N) sum_p cos(a_k1 x_p) cos(b_k2 y_p)  (basis.cpp:109-120) on the matrix cores
@@ -483,8 +493,20 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
       int nvalid = N - (c0 + wave * kWave);
       nvalid = nvalid < 0 ? 0 : (nvalid > kWave ? kWave : nvalid);
       const bool have = q < N;
-      const R c1 = have ? s_c1x[q] : R(0), s1 = have ? s_s1x[q] : R(0);
-      const R d1 = have ? s_c1y[q] : R(0), e1 = have ? s_s1y[q] : R(0);
+      R c1 = R(0), s1 = R(0), d1 = R(0), e1 = R(0);
+      if (have) {
+        if (own_points) {  // wave-uniform
+          c1 = own_c1x;
+          s1 = own_s1x;
+          d1 = own_c1y;
+          e1 = own_s1y;
+        } else {
+          c1 = s_c1x[q];
+          s1 = s_s1x[q];
+          d1 = s_c1y[q];
+          e1 = s_s1y[q];
+        }
+      }
 
       constexpr int KA = KC > 0 ? KC : 1;
       R cxr[KA], cyr[KA];
