@@ -375,39 +375,39 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
       }
       EEA_STAMP(2);
 
-      // pre-step heading (own prefix minus own increment), mid stage theta + dt (0.5 w) shared
-      // by k2 and k3 (integrator.hpp:179-180), post-step heading
-      R cm = R(0), smid = R(0);
+      // pre-step heading (own prefix minus own increment) and mid stage theta + dt (0.5 w), shared by
+      // k2 and k3 (integrator.hpp:179-180), by sin/cos evaluation; the post-step heading is
+      // 2 mid - pre, so its sin/cos follow from the two by the double-angle and addition formulas
+      // (a few flops, ~4e-16) -- no exchange with the next thread, no barrier in the forward half
+      // between the two scans.  The table entries (pre-step values, read by the backward half as
+      // "heading after step i - 1") stay the directly evaluated ones.
+      R dx = R(0), dy = R(0);
       if (act) {
         // sin(pi t), cos(pi t) reduce any argument exactly: only the reported heading is wrapped
         const R th_pre = carry_th + (inc - d);
         const R th_post = carry_th + inc;
         if (traj != nullptr) traj[3 * i + 2] = wrap_pi_fast(th_post);
-        R s, c;
+        R s, c, smid, cm;
         sc_pi(th_pre * inv_pi, &s, &c);
         s_ct[i] = c;
         s_st[i] = s;
         sc_pi((th_pre + dt * (R(0.5) * w)) * inv_pi, &smid, &cm);
-        // the heading after the chunk's / horizon's last step has no later thread to produce it
+        const R c2m = R(1) - R(2) * smid * smid, s2m = R(2) * smid * cm;
+        const R cpost = c2m * c + s2m * s, spost = s2m * c - c2m * s;
+        // the heading after the chunk's / horizon's last step has no later thread to tabulate it
         if (tid == BLK - 1 || i == T - 1) {
-          sc_pi(th_post * inv_pi, &s, &c);
-          s_ct[i + 1] = c;
-          s_st[i + 1] = s;
+          s_ct[i + 1] = cpost;
+          s_st[i + 1] = spost;
         }
-      }
-      __syncthreads();
-      EEA_STAMP(3);
-
-      R dx = R(0), dy = R(0);
-      if (act) {
         const R vx = s_vx[i], vy = s_vy[i];
         R k1x, k1y, k2x, k2y, k4x, k4y;
-        model_xy<R, MODEL>(vx, vy, s_ct[i], s_st[i], k1x, k1y);
+        model_xy<R, MODEL>(vx, vy, c, s, k1x, k1y);
         model_xy<R, MODEL>(vx, vy, cm, smid, k2x, k2y);
-        model_xy<R, MODEL>(vx, vy, s_ct[i + 1], s_st[i + 1], k4x, k4y);
+        model_xy<R, MODEL>(vx, vy, cpost, spost, k4x, k4y);
         dx = dt6 * (((k1x + R(2) * k2x) + R(2) * k2x) + k4x);
         dy = dt6 * (((k1y + R(2) * k2y) + R(2) * k2y) + k4y);
       }
+      EEA_STAMP(3);
       R tx, ty;
       block_scan2<R, WAVES>(dx, dy, s_sw + 4, tx, ty, multi_chunk);
       if (act) {
