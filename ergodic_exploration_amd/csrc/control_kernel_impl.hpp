@@ -837,8 +837,12 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
           o[1] = u[1];
           o[2] = u[2];
           if (p.done != nullptr && b == 0) {
-            // the host polls this word instead of waiting for the kernel's completion signal
-            __hip_atomic_store(p.done, p.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // the host polls this word instead of waiting for the kernel's completion signal.  The
+            // sequence number stays in its scalar register until here (hoisted into a vector register
+            // it would live -- spilled -- across the whole backward half)
+            int seq = p.done_seq;
+            asm volatile("" : "+s"(seq));
+            __hip_atomic_store(p.done, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
           }
         }
       }

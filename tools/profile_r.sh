@@ -6,7 +6,7 @@ TAG=${1:-r01}
 OUT=gpurun_out/prof_${TAG}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0"
+BENCH="python3 bench.py --steps 20 --warmup 5 --cpu-seconds 0 --no-latency"
 # 1) kernel trace + stats (durations)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $BENCH > "$OUT/trace.log" 2>&1
 # 2) PMC passes, each in its own run (FETCH_SIZE and WRITE_SIZE do not fit one pass)
