@@ -365,3 +365,10 @@ def dwa_control_batch(ccfg, dcfg, grid, x0, vb, u_opt, found, vref=None, xt_ref=
     check(lib().eea_dwa_control_batch(device, C.byref(ccfg), C.byref(dcfg), _ptr(grid), _ptr(x0), _ptr(vb),
                                       _ptr(vref), _ptr(xt_ref), n_ref, dt_ref, x0.shape[0], _ptr(u_opt),
                                       _ptr(found), C.c_void_p(stream or 0)))
+
+
+def release_collision_caches():
+    """drops the cached ring offsets / inflated-map buffers of the collision, validate and DWA calls"""
+    L = lib()
+    L.eea_release_collision_caches.restype = None
+    L.eea_release_collision_caches()

@@ -526,6 +526,27 @@ bool use_hit_map(size_t poses, unsigned sequential_steps, const CollisionParams&
 }
 }  // namespace
 
+void release_collision_caches()
+{
+  int current = 0;
+  const bool have_device = hipGetDevice(&current) == hipSuccess;
+  {
+    std::lock_guard<std::mutex> lock(g_maps_mutex);
+    for (MapBuffer& b : g_maps) {
+      if (b.cells != nullptr && hipSetDevice(b.device) == hipSuccess) (void)hipFree(b.cells);  // waits for its users
+    }
+    g_maps.clear();
+  }
+  {
+    std::lock_guard<std::mutex> lock(g_offsets_mutex);
+    for (OffsetEntry& o : g_offsets) {
+      if (o.d_offsets != nullptr && hipSetDevice(o.device) == hipSuccess) (void)hipFree(o.d_offsets);
+    }
+    g_offsets.clear();
+  }
+  if (have_device) (void)hipSetDevice(current);
+}
+
 hipError_t launch_dwa_control(const CollisionParams& c, const DwaParams& d, const int8_t* d_grid,
                               const double* d_x0, const double* d_vb, const double* d_vref,
                               const double* d_xt_ref, unsigned n_ref, double dt_ref, unsigned P,

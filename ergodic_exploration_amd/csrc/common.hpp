@@ -152,6 +152,8 @@ hipError_t launch_dwa_control(const CollisionParams& c, const DwaParams& d, cons
                               const double* d_x0, const double* d_vb, const double* d_vref,
                               const double* d_xt_ref, unsigned n_ref, double dt_ref, unsigned P,
                               double* d_u_opt, int* d_found, hipStream_t s);
+// frees the cached ring offsets and inflated-map buffers of every device
+void release_collision_caches();
 
 // ======================================================================================
 // device helpers

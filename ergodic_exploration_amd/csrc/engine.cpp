@@ -1052,6 +1052,8 @@ eea_status eea_validate_control_batch(int device, const eea_collision_cfg* cfg, 
   return EEA_OK;
 }
 
+void eea_release_collision_caches(void) { eea::release_collision_caches(); }
+
 eea_status eea_dwa_control_batch(int device, const eea_collision_cfg* ccfg, const eea_dwa_cfg* dcfg,
                                  const int8_t* d_grid, const double* d_x0, const double* d_vb,
                                  const double* d_vref, const double* d_xt_ref, unsigned n_ref,

@@ -241,6 +241,11 @@ eea_status eea_dwa_control_batch(int device, const eea_collision_cfg* ccfg, cons
                                  const double* d_vref, const double* d_xt_ref, unsigned n_ref,
                                  double dt_ref, unsigned P, double* d_u_opt, int* d_found, void* stream);
 
+/* The three calls above keep small device caches between calls (the ring offsets per radii, one
+ * inflated-map buffer per (device, stream)).  A long-running process that changes streams or map sizes
+ * can drop them; synchronises the devices involved.  No reference counterpart. */
+void eea_release_collision_caches(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -131,3 +131,20 @@ def test_both_implementations_forced(forced):
                         "tests/test_gpu_dwa_parity.py", "-k", "not forced"], cwd=root, env=env, capture_output=True,
                        text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_release_caches_then_reuse():
+    """eea_release_collision_caches drops the per-stream map buffers and the offset tables; the next
+    call rebuilds them and answers the same."""
+    g, cfg, data = _grid(seed=2)
+    rng = np.random.default_rng(3)
+    poses = np.stack([rng.uniform(-1.5, 4.5, 5000), rng.uniform(-2.5, 2.5, 5000), np.zeros(5000)], 1)
+    d_grid, d_pose = torch.as_tensor(data).cuda(), torch.as_tensor(poses).cuda()
+    a = torch.empty((5000,), dtype=torch.int32, device="cuda")
+    b = torch.empty((5000,), dtype=torch.int32, device="cuda")
+    capi.collision_check_batch(cfg, d_grid, d_pose, a)
+    torch.cuda.synchronize()
+    capi.release_collision_caches()
+    capi.collision_check_batch(cfg, d_grid, d_pose, b)
+    torch.cuda.synchronize()
+    assert torch.equal(a, b) and 0 < int(a.sum()) < 5000
