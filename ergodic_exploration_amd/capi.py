@@ -37,7 +37,8 @@ class BatchIO(C.Structure):
     _fields_ = [("d_pose", C.c_void_p), ("d_ut", C.c_void_p), ("d_mem_cols", C.c_void_p),
                 ("d_n_mem", C.c_void_p), ("mem_stride", C.c_uint), ("d_u0", C.c_void_p),
                 ("d_traj", C.c_void_p), ("d_ck", C.c_void_p), ("d_edx", C.c_void_p),
-                ("d_bdx", C.c_void_p), ("d_rhot", C.c_void_p), ("d_status", C.c_void_p)]
+                ("d_bdx", C.c_void_p), ("d_rhot", C.c_void_p), ("d_status", C.c_void_p),
+                ("d_ck_shared", C.c_void_p)]
 
 
 class CollisionCfg(C.Structure):
@@ -116,7 +117,18 @@ def lib():
         L.eea_target_grid_size.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
         L.eea_get_target_grid.argtypes = [C.c_void_p, C.c_void_p]
         L.eea_control_batch.argtypes = [C.c_void_p, C.c_uint, C.POINTER(BatchIO), C.c_void_p]
-        L.eea_debug_phase_timing.argtypes = [C.c_void_p, C.c_uint, C.POINTER(BatchIO), C.c_void_p, C.c_void_p]
+        if hasattr(L, "eea_debug_phase_timing"):  # A/B library only (EEA_LIB_VARIANT=_ab, tools/ab/)
+            L.eea_debug_phase_timing.argtypes = [C.c_void_p, C.c_uint, C.POINTER(BatchIO), C.c_void_p, C.c_void_p]
+        L.eea_comm_get_unique_id.argtypes = [C.c_void_p]
+        L.eea_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.eea_comm_destroy.argtypes = [C.c_void_p]
+        L.eea_comm_destroy.restype = None
+        L.eea_comm_rank.argtypes = [C.c_void_p]
+        L.eea_comm_nranks.argtypes = [C.c_void_p]
+        L.eea_ck_sum.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.eea_comm_allgather_ck.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.eea_comm_consensus_ck.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.eea_comm_allreduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
         L.eea_rollout_batch.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]
         L.eea_control.argtypes = [C.c_void_p] + [C.c_double] * 4 + [C.c_void_p, C.c_void_p, C.c_uint,
@@ -251,15 +263,21 @@ class Engine:
         return out, nx.value, ny.value
 
     def control_batch(self, B, pose, ut, u0, mem_cols=None, n_mem=None, mem_stride=0, traj=None,
-                      ck=None, edx=None, bdx=None, rhot=None, status=None, stream=None):
+                      ck=None, edx=None, bdx=None, rhot=None, status=None, stream=None, ck_shared=None):
         io = BatchIO()
+        io.d_ck_shared = _ptr(ck_shared)
         io.d_pose, io.d_ut, io.d_u0 = _ptr(pose), _ptr(ut), _ptr(u0)
         io.d_mem_cols, io.d_n_mem, io.mem_stride = _ptr(mem_cols), _ptr(n_mem), mem_stride
         io.d_traj, io.d_ck, io.d_edx, io.d_bdx = _ptr(traj), _ptr(ck), _ptr(edx), _ptr(bdx)
         io.d_rhot, io.d_status = _ptr(rhot), _ptr(status)
         check(lib().eea_control_batch(self.h, B, C.byref(io), C.c_void_p(stream or 0)))
 
+    def ck_sum(self, B, ck, sums, stream=None):
+        """sums[:K2] = sum over the B agents of ck, sums[K2] = B (device tensors)"""
+        check(lib().eea_ck_sum(self.h, B, _ptr(ck), _ptr(sums), C.c_void_p(stream or 0)))
+
     def debug_phase_timing(self, B, pose, ut, u0, stamps, ck=None, stream=None):
+        """A/B library only (EEA_LIB_VARIANT=_ab): tools/phase_timing.py"""
         io = BatchIO()
         io.d_pose, io.d_ut, io.d_u0, io.d_ck = _ptr(pose), _ptr(ut), _ptr(u0), _ptr(ck)
         check(lib().eea_debug_phase_timing(self.h, B, C.byref(io), C.c_void_p(stream or 0), _ptr(stamps)))
@@ -372,3 +390,46 @@ def release_collision_caches():
     L = lib()
     L.eea_release_collision_caches.restype = None
     L.eea_release_collision_caches()
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id():
+    """128-byte RCCL id created on this rank (rank 0 hands it to the others)"""
+    buf = C.create_string_buffer(COMM_ID_BYTES)
+    check(lib().eea_comm_get_unique_id(buf))
+    return buf.raw
+
+
+class Comm:
+    """Communicator of the agent-batch exchange steps (RCCL over xGMI; ncclComm behind the C ABI).
+    uid=None with nranks == 1: local communicator without RCCL."""
+
+    def __init__(self, device, nranks, rank, uid=None):
+        self.h = C.c_void_p()
+        idbuf = C.create_string_buffer(uid, COMM_ID_BYTES) if uid is not None else None
+        check(lib().eea_comm_create(device, nranks, rank, idbuf, C.byref(self.h)))
+        self.nranks, self.rank = nranks, rank
+
+    def close(self):
+        if self.h:
+            lib().eea_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def allgather_ck(self, eng, B_local, ck_local, ck_all, stream=None):
+        check(lib().eea_comm_allgather_ck(eng.h, self.h, B_local, _ptr(ck_local), _ptr(ck_all),
+                                          C.c_void_p(stream or 0)))
+
+    def consensus_ck(self, eng, B_local, ck_local, ck_shared, stream=None):
+        check(lib().eea_comm_consensus_ck(eng.h, self.h, B_local, _ptr(ck_local), _ptr(ck_shared),
+                                          C.c_void_p(stream or 0)))
+
+    def allreduce_sum(self, eng, buf, n, stream=None):
+        check(lib().eea_comm_allreduce_sum(eng.h, self.h, _ptr(buf), n, C.c_void_p(stream or 0)))

@@ -1,0 +1,252 @@
+// Exchange steps of the agent-batched mode (include/ergodic_amd.h, "multi-GPU exchange"): the reductions of
+// the per-agent trajectory coefficients c_k on the device and their collectives over RCCL / xGMI.
+//
+// The reference is single-agent (no collective anywhere); the semantics come from the decentralised ergodic
+// control its README cites as ref. [2] (README.md:225-227): agents share c_k.  Two forms:
+//   * all-gather of every agent's c_k (K^2 reals per agent), the exchange north_star names;
+//   * consensus c_bar = mean over all agents of c_k: one all-reduce of K^2 + 1 reals (the agent count rides
+//     along), which is all the gradient needs (eea_batch_io::d_ck_shared).
+// RCCL is bound at run time (dlopen): a process that already carries an RCCL (PyTorch's) shares that
+// instance, a plain C++ host gets /opt/rocm's; libergodic_amd.so itself has no link dependency on it.
+#include "../../include/ergodic_amd.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <string>
+
+#include "abi_util.hpp"
+#include "common.hpp"
+
+namespace
+{
+struct RcclApi
+{
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                            hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+
+RcclApi& rccl()
+{
+  static RcclApi api = [] {
+    RcclApi a;
+    // an RCCL already mapped into the process (e.g. PyTorch's bundled one) is reused
+    const char* names[] = { "librccl.so", "librccl.so.1" };
+    for (const char* n : names) {
+      a.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+      if (a.handle) break;
+    }
+    for (int i = 0; a.handle == nullptr && i < 2; ++i) a.handle = dlopen(names[1 - i], RTLD_NOW | RTLD_GLOBAL);
+    if (a.handle == nullptr) return a;
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.handle, "ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.handle, "ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(a.handle, "ncclCommDestroy"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(a.handle, "ncclAllGather"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(a.handle, "ncclAllReduce"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.handle, "ncclGetErrorString"));
+    a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.AllReduce && a.GetErrorString;
+    return a;
+  }();
+  return api;
+}
+
+using eea::fail;
+
+#define EEA_RCCL(expr)                                                                        \
+  do {                                                                                        \
+    const ncclResult_t err__ = (expr);                                                        \
+    if (err__ != ncclSuccess) {                                                               \
+      return fail(EEA_ERR_HIP, std::string(#expr) + ": " + rccl().GetErrorString(err__));     \
+    }                                                                                         \
+  } while (0)
+
+// sums[m] = sum over the B local agents of ck[b][m] (fixed order: run-to-run deterministic);
+// sums[K2] = B.  One workgroup per 64 modes would starve the chip for K = 10, so: one wavefront per mode,
+// lanes stride the agents, DPP-free butterfly through __shfl_xor (cold path: once per exchange).
+template <typename R>
+__global__ __launch_bounds__(256) void ck_sum_kernel(const R* __restrict__ ck, unsigned B, int K2,
+                                                     R* __restrict__ sums)
+{
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m > K2) return;
+  if (m == K2) {
+    if (lane == 0) sums[K2] = static_cast<R>(B);
+    return;
+  }
+  R acc = R(0);
+  for (unsigned b = lane; b < B; b += 64) acc += ck[static_cast<size_t>(b) * K2 + m];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) sums[m] = acc;
+}
+
+// c_bar[m] = sums[m] / sums[K2]
+template <typename R>
+__global__ __launch_bounds__(256) void ck_mean_kernel(const R* __restrict__ sums, int K2, R* __restrict__ out)
+{
+  const R n = sums[K2];
+  for (int m = blockIdx.x * 256 + threadIdx.x; m < K2; m += gridDim.x * 256) out[m] = sums[m] / n;
+}
+
+template <typename R>
+hipError_t launch_ck_sum(const void* d_ck, unsigned B, int K2, void* d_sums, hipStream_t s)
+{
+  hipLaunchKernelGGL(ck_sum_kernel<R>, dim3((K2 + 1 + 3) / 4), dim3(256), 0, s, static_cast<const R*>(d_ck), B, K2,
+                     static_cast<R*>(d_sums));
+  return hipGetLastError();
+}
+template <typename R>
+hipError_t launch_ck_mean(const void* d_sums, int K2, void* d_out, hipStream_t s)
+{
+  hipLaunchKernelGGL(ck_mean_kernel<R>, dim3((K2 + 255) / 256), dim3(256), 0, s, static_cast<const R*>(d_sums), K2,
+                     static_cast<R*>(d_out));
+  return hipGetLastError();
+}
+}  // namespace
+
+struct eea_comm
+{
+  ncclComm_t comm = nullptr;
+  int device = 0, nranks = 1, rank = 0;
+  void* d_sums = nullptr;  // K^2 + 1 reals of scratch for the consensus reduction
+  size_t sums_cap = 0;
+};
+
+namespace
+{
+eea_status sums_reserve(eea_comm* c, size_t bytes)
+{
+  if (bytes <= c->sums_cap) return EEA_OK;
+  if (c->d_sums) (void)hipFree(c->d_sums);
+  c->d_sums = nullptr;
+  c->sums_cap = 0;
+  EEA_HIP(hipMalloc(&c->d_sums, bytes));
+  c->sums_cap = bytes;
+  return EEA_OK;
+}
+}  // namespace
+
+extern "C" {
+
+eea_status eea_comm_get_unique_id(void* id)
+{
+  static_assert(sizeof(ncclUniqueId) == EEA_COMM_ID_BYTES, "ncclUniqueId size");
+  if (id == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null id");
+  if (!rccl().ok) return fail(EEA_ERR_HIP, "librccl.so not loadable");
+  ncclUniqueId u;
+  EEA_RCCL(rccl().GetUniqueId(&u));
+  std::memcpy(id, &u, sizeof(u));
+  return EEA_OK;
+}
+
+eea_status eea_comm_create(int device, int nranks, int rank, const void* id, eea_comm** out)
+{
+  if (out == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (nranks < 1 || rank < 0 || rank >= nranks) return fail(EEA_ERR_INVALID_ARGUMENT, "bad rank / nranks");
+  if (nranks > 1 && id == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null id");
+  eea_comm* c = new eea_comm();
+  c->device = device;
+  c->nranks = nranks;
+  c->rank = rank;
+  if (id != nullptr) {
+    // a real RCCL communicator (also for one rank: the single-GPU tests drive the collectives through it);
+    // one rank per GPU (RCCL refuses two ranks of one communicator on the same device)
+    if (!rccl().ok) {
+      delete c;
+      return fail(EEA_ERR_HIP, "librccl.so not loadable");
+    }
+    const hipError_t he = hipSetDevice(device);
+    if (he != hipSuccess) {
+      delete c;
+      return fail(EEA_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(he));
+    }
+    ncclUniqueId u;
+    std::memcpy(&u, id, sizeof(u));
+    const ncclResult_t r = rccl().CommInitRank(&c->comm, nranks, u, rank);
+    if (r != ncclSuccess) {
+      const std::string msg = std::string("ncclCommInitRank: ") + rccl().GetErrorString(r);
+      delete c;
+      return fail(EEA_ERR_HIP, msg);
+    }
+  }
+  *out = c;
+  return EEA_OK;
+}
+
+void eea_comm_destroy(eea_comm* c)
+{
+  if (c == nullptr) return;
+  (void)hipSetDevice(c->device);
+  if (c->comm != nullptr && rccl().ok) (void)rccl().CommDestroy(c->comm);
+  if (c->d_sums) (void)hipFree(c->d_sums);
+  delete c;
+}
+
+int eea_comm_rank(const eea_comm* c) { return c ? c->rank : 0; }
+int eea_comm_nranks(const eea_comm* c) { return c ? c->nranks : 1; }
+
+eea_status eea_ck_sum(eea_engine* e, unsigned B, const void* d_ck, void* d_sums, void* stream)
+{
+  if (e == nullptr || d_ck == nullptr || d_sums == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  const int K2 = static_cast<int>(eea_num_modes(e));
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (eea_real_size(e) == 4) EEA_HIP(launch_ck_sum<float>(d_ck, B, K2, d_sums, s));
+  else EEA_HIP(launch_ck_sum<double>(d_ck, B, K2, d_sums, s));
+  return EEA_OK;
+}
+
+eea_status eea_comm_allgather_ck(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_local,
+                                 void* d_ck_all, void* stream)
+{
+  if (e == nullptr || d_ck_local == nullptr || d_ck_all == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  const size_t K2 = eea_num_modes(e), rs = eea_real_size(e);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t count = static_cast<size_t>(B_local) * K2;
+  if (c == nullptr || c->comm == nullptr) {
+    if (d_ck_all != d_ck_local) EEA_HIP(hipMemcpyAsync(d_ck_all, d_ck_local, count * rs, hipMemcpyDeviceToDevice, s));
+    return EEA_OK;
+  }
+  EEA_RCCL(rccl().AllGather(d_ck_local, d_ck_all, count, rs == 4 ? ncclFloat32 : ncclFloat64, c->comm, s));
+  return EEA_OK;
+}
+
+eea_status eea_comm_allreduce_sum(eea_engine* e, eea_comm* c, void* d_buf, unsigned n, void* stream)
+{
+  if (e == nullptr || d_buf == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  if (c == nullptr || c->comm == nullptr || n == 0) return EEA_OK;
+  EEA_RCCL(rccl().AllReduce(d_buf, d_buf, n, eea_real_size(e) == 4 ? ncclFloat32 : ncclFloat64, ncclSum, c->comm,
+                            static_cast<hipStream_t>(stream)));
+  return EEA_OK;
+}
+
+eea_status eea_comm_consensus_ck(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_local,
+                                 void* d_ck_shared, void* stream)
+{
+  if (e == nullptr || c == nullptr || d_ck_local == nullptr || d_ck_shared == nullptr) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  }
+  const int K2 = static_cast<int>(eea_num_modes(e));
+  const size_t rs = eea_real_size(e);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  eea_status st = sums_reserve(c, rs * (static_cast<size_t>(K2) + 1));
+  if (st != EEA_OK) return st;
+  st = eea_ck_sum(e, B_local, d_ck_local, c->d_sums, stream);
+  if (st != EEA_OK) return st;
+  st = eea_comm_allreduce_sum(e, c, c->d_sums, static_cast<unsigned>(K2 + 1), stream);
+  if (st != EEA_OK) return st;
+  if (rs == 4) EEA_HIP(launch_ck_mean<float>(c->d_sums, K2, d_ck_shared, s));
+  else EEA_HIP(launch_ck_mean<double>(c->d_sums, K2, d_ck_shared, s));
+  return EEA_OK;
+}
+
+}  // extern "C"

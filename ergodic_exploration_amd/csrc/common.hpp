@@ -42,6 +42,7 @@ struct ControlParams
   R* u0;
   R* traj;
   R* ck;
+  const R* ck_shared;  // [K^2] optional: consensus c_k used in place of the agent's own (one per launch)
   R* edx;
   R* bdx;
   R* rhot;
@@ -62,11 +63,12 @@ template <typename R>
 hipError_t launch_control(const ControlParams<R>& p, unsigned B, int model, int n_mem_max,
                           bool rollout_only, hipStream_t stream);
 
-// diagnostic instantiation (K = 10, fp64) that records per-phase shader-clock stamps into p.dbg
+#ifdef EEA_AB_BUILD
+// A/B library only (tools/ab/): diagnostic instantiation (K = 10, fp64) that records per-phase shader-clock
+// stamps into p.dbg, and the first version of the control kernel
 hipError_t launch_control_timing(const ControlParams<double>& p, unsigned B, int model, int n_mem_max,
                                  hipStream_t stream);
 
-// first version of the control kernel (control_kernel_v1.hip), kept as the A/B baseline
 namespace v1
 {
 template <typename R>
@@ -75,6 +77,7 @@ template <typename R>
 hipError_t launch_control(const ControlParams<R>& p, unsigned B, int model, int n_mem_max,
                           bool rollout_only, hipStream_t stream);
 }  // namespace v1
+#endif  // EEA_AB_BUILD
 
 // ---- phi_k path ----------------------------------------------------------------------
 // cos tables: out[k * n + i] = cos((k * pi_over_l) * coord[i]), k < K

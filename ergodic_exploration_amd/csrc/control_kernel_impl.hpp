@@ -30,15 +30,8 @@
 //     4 workgroups per CU.
 #include "common.hpp"
 
-// Phase stamps: compiled in only by control_kernel_timing.hip (EEA_TIMING); each wavefront's
-// lane 0 records the shader clock at the phase boundaries into p.dbg.
-// EEA_ABLATE = n builds a variant with one phase removed (marginal-cost measurement only; results
-// are wrong by construction): 1 gradient FMAs, 2 c_k tables + MFMA, 3 sin/cos evaluations,
-// 4 cross-wavefront scan exchange, 5 HBM loads/stores of the controls, 6 table staging writes,
-// 7 MFMA operand reads + matrix instructions, 8 table recurrence
-#ifndef EEA_ABLATE
-#define EEA_ABLATE 0
-#endif
+// Phase stamps: compiled in only by tools/ab/control_kernel_timing.hip (EEA_TIMING, A/B library);
+// each wavefront's lane 0 records the shader clock at the phase boundaries into p.dbg.
 
 // waves per SIMD the K <= 12 instances are compiled for (register budget 512 / waves)
 #ifndef EEA_WAVES_SMALL_K
@@ -63,12 +56,7 @@ namespace
 template <typename R>
 __device__ __forceinline__ void sc_pi(R t, R* s, R* c)
 {
-#if EEA_ABLATE == 3
-  *s = t;
-  *c = R(1) - t;
-#else
   sincospi_r(t, s, c);
-#endif
 }
 
 // acc + k * v for a small mode number k: fp64 takes the constant from a scalar register pair
@@ -155,10 +143,6 @@ __device__ __forceinline__ R block_scan(R v, R* s_w, R& total, bool reuse)
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);  // provably wave-uniform
   const R s = wave_inclusive_scan_dpp(v);
-#if EEA_ABLATE == 4
-  total = s;
-  return s;
-#endif
   if (lane == kWave - 1) s_w[wave] = s;
   __syncthreads();
   R off = R(0), tot = R(0);
@@ -180,13 +164,6 @@ __device__ __forceinline__ void block_scan2(R& a, R& b, R* s_w, R& tot_a, R& tot
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const R sa = wave_inclusive_scan_dpp(a);
   const R sb = wave_inclusive_scan_dpp(b);
-#if EEA_ABLATE == 4
-  a = sa;
-  b = sb;
-  tot_a = sa;
-  tot_b = sb;
-  return;
-#endif
   if (lane == kWave - 1) {
     s_w[wave] = sa;
     s_w[WAVES + wave] = sb;
@@ -312,13 +289,10 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
     for (int i = tid; i < T; i += BLK) {
       const int src = rollout_only ? i : i + 1;
       R vx = R(0), vy = R(0), w = R(0);
-      if (src < T && EEA_ABLATE != 5) {
+      if (src < T) {
         vx = ut[3 * src + 0];
         vy = ut[3 * src + 1];
         w = ut[3 * src + 2];
-      } else if (EEA_ABLATE == 5) {
-        vx = R(0.001) * i;
-        w = R(0.002) * i;
       }
       s_vx[i] = vx;
       s_vy[i] = vy;
@@ -332,7 +306,7 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
     const bool wave_bad = __any(bad);
     if (lane == 0) s_bad[wave] = wave_bad ? 1 : 0;
   }
-  if (WAVES == 1 || EEA_ABLATE == 4) __syncthreads();  // single wavefront: a fence, no s_barrier
+  if (WAVES == 1) __syncthreads();  // single wavefront: a fence, no s_barrier
   EEA_STAMP(1);
 
   const R dt = p.dt;
@@ -488,7 +462,7 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
     const int pl = lane % kSub;   // its row in the staged tile
     const int mk = lane >> 4, mi = lane & 15;  // matrix-instruction operand coordinates of this lane
 
-    for (int c0 = 0; c0 < (EEA_ABLATE == 2 ? 0 : N); c0 += BLK) {
+    for (int c0 = 0; c0 < N; c0 += BLK) {
       const int q = c0 + wave * kWave + lane;
       int nvalid = N - (c0 + wave * kWave);
       nvalid = nvalid < 0 ? 0 : (nvalid > kWave ? kWave : nvalid);
@@ -510,13 +484,7 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
 
       constexpr int KA = KC > 0 ? KC : 1;
       R cxr[KA], cyr[KA];
-      if (KC > 0 && EEA_ABLATE == 8) {
-#pragma unroll
-        for (int k = 0; k < KA; ++k) {
-          cxr[k] = c1;
-          cyr[k] = d1;
-        }
-      } else if (KC > 0) {
+      if (KC > 0) {
         // cos(k a) for k < K by the angle-addition recurrence; zero rows for padding points
         R ck = have ? R(1) : R(0), sk = R(0), dk = have ? R(1) : R(0), ek = R(0);
 #pragma unroll
@@ -534,7 +502,7 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
 
       // stage one pass of 16 points (this lane's point if it belongs to pass s)
       auto stage = [&](int s) {
-        if (sub == s && EEA_ABLATE != 6) {
+        if (sub == s) {
           R* const tx = tabx + pl * KS;
           R* const ty = taby + pl * KS;
           if (KC > 0) {
@@ -560,7 +528,6 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
       };
       // four points per matrix instruction: operand of lane l = element (4g + l/16) * KS + l%16
       auto mma_group = [&](int g) {
-        if (EEA_ABLATE == 7) return;
         const int off = (4 * g + mk) * KS + mi;
         R av[NT], bv[NT];
 #pragma unroll
@@ -643,8 +610,10 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
       for (int w = 0; w < WAVES; ++w) {
         if (w < red_bufs) s += s_red[w * red_stride + m];
       }
-      const R c = invN * s;
+      R c = invN * s;
       if (p.ck != nullptr) p.ck[static_cast<size_t>(b) * K2 + m] = c;
+      // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
+      if (p.ck_shared != nullptr) c = p.ck_shared[m];
       // fourier_diff = lamdak % (ck - phik)  (ergodic_control.hpp:422)
       const R lam = (m == tid) ? lam_m : p.lamdak[m];
       const R phi = (m == tid) ? phi_m : p.phik[m];
@@ -693,7 +662,7 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
           R dk = R(1), ek = R(0), accy = R(0);
           constexpr int kRowUnroll = (KA <= 12 && sizeof(R) == 8) ? KA : 1;
 #pragma unroll kRowUnroll
-          for (int k2 = 0; k2 < (EEA_ABLATE == 1 ? 1 : KA); ++k2) {
+          for (int k2 = 0; k2 < KA; ++k2) {
             const R* const Drow = s_D + k2 * KA;
             R ha = R(0), hb = R(0);
 #pragma unroll
@@ -820,11 +789,9 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
           const R ur = (p.Rinv[r] * n0 + p.Rinv[r + 3] * n1) + p.Rinv[r + 6] * n2;
           u[r] = clamp_std(ur, p.umin[r], p.umax[r]);
         }
-        if (EEA_ABLATE != 5 || u[0] == R(123456)) {
-          ut[3 * i + 0] = u[0];
-          ut[3 * i + 1] = u[1];
-          ut[3 * i + 2] = u[2];
-        }
+        ut[3 * i + 0] = u[0];
+        ut[3 * i + 1] = u[1];
+        ut[3 * i + 2] = u[2];
         if (p.rhot != nullptr) {
           R* const o = p.rhot + 3 * (static_cast<size_t>(T) * b + i);
           o[0] = rho0;

@@ -4,6 +4,9 @@
 // host code here only prepares their inputs the way the reference's host code does
 // (steps_ truncation, grid coordinates by accumulation, covariance inverse).
 #include "../../include/ergodic_amd.h"
+#ifdef EEA_AB_BUILD
+#include "../../tools/ab/ergodic_amd_ab.h"
+#endif
 
 #include <cmath>
 #include <cstdio>
@@ -12,25 +15,12 @@
 #include <string>
 #include <vector>
 
+#include "abi_util.hpp"
 #include "common.hpp"
 
 namespace
 {
-thread_local std::string g_err;
-
-eea_status fail(eea_status st, const std::string& msg)
-{
-  g_err = msg;
-  return st;
-}
-
-#define EEA_HIP(expr)                                                                         \
-  do {                                                                                        \
-    const hipError_t err__ = (expr);                                                          \
-    if (err__ != hipSuccess) {                                                                \
-      return fail(EEA_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(err__));         \
-    }                                                                                         \
-  } while (0)
+using eea::fail;
 
 // grid.hpp:61-64 of the reference (x86-64 cast semantics do not matter here: non-negative)
 unsigned axis_length(double lower, double upper, double resolution)
@@ -77,7 +67,9 @@ struct eea_engine
   bool f32 = false;
   size_t rs = 8;  // sizeof(real)
   int chunk = 128;
-  bool impl_v1 = false;  // EEA_CONTROL_IMPL=v1 selects the first kernel version (A/B baseline)
+#ifdef EEA_AB_BUILD
+  bool impl_v1 = false;  // A/B library: EEA_CONTROL_IMPL=v1 selects the first kernel version
+#endif
 
   // Basis state (basis_.lx_, ly_ start at 0: ergodic_control.hpp:208)
   double lx = 0.0, ly = 0.0, map_x = 0.0, map_y = 0.0;
@@ -121,12 +113,12 @@ eea_status use_device(const eea_engine* e)
 eea_status stage_reserve(eea_engine* e, size_t bytes)
 {
   if (bytes <= e->h_stage_cap) return EEA_OK;
-  if (e->h_stage) (void)hipHostFree(e->h_stage);
-  e->h_stage = nullptr;
-  e->h_stage_cap = 0;
   // grows geometrically: the replay memory adds a column per tick until it reaches the batch size
   size_t want = e->h_stage_cap ? 2 * e->h_stage_cap : 4096;
   if (want < bytes) want = bytes;
+  if (e->h_stage) (void)hipHostFree(e->h_stage);
+  e->h_stage = nullptr;
+  e->h_stage_cap = 0;
   EEA_HIP(hipHostMalloc(&e->h_stage, want, hipHostMallocDefault));
   e->h_stage_cap = want;
   return EEA_OK;
@@ -182,6 +174,18 @@ eea_status upload_axes_and_tables(eea_engine* e, unsigned nx, unsigned ny, hipSt
                                     static_cast<R*>(e->d_cx.p), s));
   EEA_HIP(eea::launch_cos_tables_t<R>(static_cast<const R*>(e->d_ys.p), ny, e->K, pi_ly,
                                       static_cast<R*>(e->d_cy.p), s));
+  return EEA_OK;
+}
+
+// A row tile is launched with ny = nrows and its tile geometry is recomputed from nrows; the rows-per-tile
+// rule is not monotone in ny, so the partials buffer is sized for both the whole grid and the tile
+template <typename R>
+eea_status reserve_tile_work(eea_engine* e, unsigned nx, unsigned ny_total, unsigned nrows)
+{
+  size_t elems = eea::spatial_work_elems(nx, ny_total, e->K);
+  const size_t tile = eea::spatial_work_elems(nx, nrows, e->K);
+  if (tile > elems) elems = tile;
+  EEA_HIP(e->d_work.reserve(sizeof(R) * elems));
   return EEA_OK;
 }
 
@@ -303,6 +307,7 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
   p.u0 = static_cast<R*>(io->d_u0);
   p.traj = static_cast<R*>(io->d_traj);
   p.ck = static_cast<R*>(io->d_ck);
+  p.ck_shared = static_cast<const R*>(io->d_ck_shared);
   p.edx = static_cast<R*>(io->d_edx);
   p.bdx = static_cast<R*>(io->d_bdx);
   p.rhot = static_cast<R*>(io->d_rhot);
@@ -310,23 +315,31 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
   p.done = e->mail_done;
   p.done_seq = e->mail_seq;
   const int n_mem_max = rollout_only ? 0 : static_cast<int>(p.mem_stride);
-  const size_t lds = e->impl_v1 ? eea::v1::control_lds_bytes<R>(p.T, p.K, n_mem_max, p.chunk)
-                                : eea::control_lds_bytes<R>(p.T, p.K, n_mem_max, p.chunk);
+  size_t lds = eea::control_lds_bytes<R>(p.T, p.K, n_mem_max, p.chunk);
+#ifdef EEA_AB_BUILD
+  if (e->impl_v1) lds = eea::v1::control_lds_bytes<R>(p.T, p.K, n_mem_max, p.chunk);
+#endif
   if (lds > 160 * 1024) {
     return fail(EEA_ERR_UNSUPPORTED, "horizon/memory/basis too large for one workgroup's 160 KiB LDS");
   }
+#ifdef EEA_AB_BUILD
   if (d_stamps != nullptr) {
     if constexpr (sizeof(R) == 8) {
       p.dbg = d_stamps;
       EEA_HIP(eea::launch_control_timing(p, B, e->cfg.model, n_mem_max, s));
+      return EEA_OK;
     } else {
       return fail(EEA_ERR_UNSUPPORTED, "phase timing is built for fp64 only");
     }
-  } else if (e->impl_v1) {
-    EEA_HIP(eea::v1::launch_control<R>(p, B, e->cfg.model, n_mem_max, rollout_only, s));
-  } else {
-    EEA_HIP(eea::launch_control<R>(p, B, e->cfg.model, n_mem_max, rollout_only, s));
   }
+  if (e->impl_v1) {
+    EEA_HIP(eea::v1::launch_control<R>(p, B, e->cfg.model, n_mem_max, rollout_only, s));
+    return EEA_OK;
+  }
+#else
+  (void)d_stamps;
+#endif
+  EEA_HIP(eea::launch_control<R>(p, B, e->cfg.model, n_mem_max, rollout_only, s));
   return EEA_OK;
 }
 
@@ -364,7 +377,8 @@ eea_status occupancy_rows_impl(eea_engine* e, unsigned nx, unsigned ny_total, un
   if (st != EEA_OK) return st;
   st = upload_entropy_table<R>(e, s);
   if (st != EEA_OK) return st;
-  // the work buffer was sized for the whole grid; a row tile needs no more
+  st = reserve_tile_work<R>(e, nx, ny_total, nrows);
+  if (st != EEA_OK) return st;
   EEA_HIP(eea::launch_spatial_coeff_cells<R>(d_occ_rows, nx, nrows, e->K, static_cast<const R*>(e->d_cx.p),
                                              static_cast<const R*>(e->d_cy.p) + static_cast<size_t>(row0) * e->K,
                                              static_cast<const R*>(e->d_lut.p), static_cast<R*>(e->d_work.p),
@@ -381,7 +395,7 @@ eea_status check_engine(const eea_engine* e)
 
 extern "C" {
 
-const char* eea_last_error(void) { return g_err.c_str(); }
+const char* eea_last_error(void) { return eea::g_last_error.c_str(); }
 unsigned eea_abi_version(void) { return EEA_ABI_VERSION; }
 
 eea_status eea_create(const eea_config* cfg, eea_engine** out)
@@ -424,7 +438,9 @@ eea_status eea_create(const eea_config* cfg, eea_engine** out)
     const int v = std::atoi(c);
     if (v >= 64 && v <= 1024 && (v % 64) == 0) e->chunk = v;
   }
+#ifdef EEA_AB_BUILD
   if (const char* c = std::getenv("EEA_CONTROL_IMPL")) e->impl_v1 = std::strcmp(c, "v1") == 0;
+#endif
   eea_status st = e->f32 ? upload_lamdak<float>(e) : upload_lamdak<double>(e);
   if (st != EEA_OK) {
     eea_destroy(e);
@@ -517,6 +533,8 @@ eea_status eea_spatial_coeff_rows(eea_engine* e, unsigned nx, unsigned ny_total,
   st = e->f32 ? upload_axes_and_tables<float>(e, nx, ny_total, s) : upload_axes_and_tables<double>(e, nx, ny_total, s);
   e->lx = keep_lx;
   e->ly = keep_ly;
+  if (st != EEA_OK) return st;
+  st = e->f32 ? reserve_tile_work<float>(e, nx, ny_total, nrows) : reserve_tile_work<double>(e, nx, ny_total, nrows);
   if (st != EEA_OK) return st;
   if (e->f32) {
     EEA_HIP(eea::launch_spatial_coeff<float>(static_cast<const float*>(d_phi_rows), nx, nrows, e->K,
@@ -620,11 +638,19 @@ eea_status eea_config_domain(eea_engine* e, double xmin, double xmax, double ymi
   if (!e->have_gauss) return fail(EEA_ERR_NO_TARGET, "configTarget before setTarget");
   eea_status st = use_device(e);
   if (st != EEA_OK) return st;
+  const double keep_lx = e->lx, keep_ly = e->ly;
   e->lx = mx;
   e->ly = my;
   hipStream_t s = static_cast<hipStream_t>(stream);
   st = e->f32 ? rebuild_phik<float>(e, s) : rebuild_phik<double>(e, s);
-  if (st == EEA_OK && rebuilt) *rebuilt = 1;
+  if (st != EEA_OK) {
+    // the reference throws out of the controller here; a failed rebuild must not leave the new extent
+    // behind (the next call would take the almost_equal early return with a stale phi_k)
+    e->lx = keep_lx;
+    e->ly = keep_ly;
+    return st;
+  }
+  if (rebuilt) *rebuilt = 1;
   return st;
 }
 
@@ -685,6 +711,7 @@ eea_status eea_control_batch(eea_engine* e, unsigned B, const eea_batch_io* io, 
                 : control_batch_impl<double>(e, B, io, false, s);
 }
 
+#ifdef EEA_AB_BUILD
 eea_status eea_debug_phase_timing(eea_engine* e, unsigned B, const eea_batch_io* io, void* stream,
                                   long long* d_stamps)
 {
@@ -698,6 +725,7 @@ eea_status eea_debug_phase_timing(eea_engine* e, unsigned B, const eea_batch_io*
   if (st != EEA_OK) return st;
   return control_batch_impl<double>(e, B, io, false, static_cast<hipStream_t>(stream), d_stamps);
 }
+#endif
 
 eea_status eea_rollout_batch(eea_engine* e, unsigned B, const void* d_pose, const void* d_ut,
                              void* d_traj, int* d_status, void* stream)

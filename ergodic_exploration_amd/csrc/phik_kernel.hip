@@ -154,217 +154,12 @@ __global__ __launch_bounds__(kBlock) void scale_by_inv_kernel(R* __restrict__ ph
   }
 }
 
-// pass 1: workgroup = (256 * CPT) grid columns x `rows_per_tile` grid rows.  Each lane owns CPT
-// adjacent columns (one vector load per row: 16 bytes for two fp64 / four fp32 columns, one dword
-// for four occupancy cells) and keeps K running sums per column; four rows are in flight per
-// iteration plus the prefetch of the next four.  More columns per lane divide the LDS traffic of
-// the y-table rows (K broadcast reads per row and wavefront, the bound for K >= 20 and for byte
-// input) by CPT.
-// EXACT: K == KMAX is known at compile time (no per-mode bounds tests in the streaming loop).
-// IN: element type of the grid in HBM.  IN = R: target values.  IN = int8_t: occupancy cells
-// (nav_msgs::OccupancyGrid::data, grid.cpp:63-94) decoded through a 256-entry table in LDS
-// (`lut`, indexed by the cell's byte: entropy(cell / 100), numerics.hpp:164-179) when a row is
-// consumed -- one byte per cell read from HBM instead of a materialised fp64 target grid.
-template <typename R, int KMAX, int CPT, bool EXACT, typename IN = R>
-__global__ __launch_bounds__(kBlock) void spatial_pass1_kernel(const IN* __restrict__ phi, int nx, int ny,
-                                                               int K_rt, int rows_per_tile,
-                                                               const R* __restrict__ cx,
-                                                               const R* __restrict__ cy,
-                                                               const R* __restrict__ lut,
-                                                               R* __restrict__ partials)
-{
-  constexpr bool kCells = !std::is_same<IN, R>::value;
-  static_assert(CPT == 1 || CPT == 2 || CPT == 4, "columns per lane");
-  static_assert(kCells || CPT * sizeof(R) <= 16, "one vector load per row");
-  // a lane's row data: CPT reals, or the CPT cells packed into one int
-  constexpr int RAWN = kCells ? 1 : CPT;
-  using raw_t = typename std::conditional<kCells, int, R>::type;
-  constexpr int kCols = kBlock * CPT;
-  constexpr int kPad = kBlock + 1;  // LDS row stride of the per-column sums (one column pass)
-  constexpr int kRowsInFlight = EEA_PHIK_ROWS_IN_FLIGHT;
-  const int K = EXACT ? KMAX : K_rt;
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  R* const s_S = reinterpret_cast<R*>(smem_raw);  // [K][kPad]
+// input kinds of the phi_k pass: fp64 values, fp32 values, occupancy cells (bytes)
+constexpr int kKindF64 = 0, kKindF32 = 1, kKindCells = 2;
 
-  const int tid = threadIdx.x;
-  const int ix0 = blockIdx.x * kCols;
-  const int ix = ix0 + tid * CPT;
-  const int r0 = blockIdx.y * rows_per_tile;
-  const int r1 = (r0 + rows_per_tile) < ny ? (r0 + rows_per_tile) : ny;
-  // vector loads need the whole CPT group in range and an aligned row pitch
-  const bool vec_ok = (CPT == 1) || ((ix + CPT <= nx) && ((nx % CPT) == 0));
-  int okmask = 0;  // bit c: column ix + c is inside the grid
-#pragma unroll
-  for (int c = 0; c < CPT; ++c) okmask |= (ix + c < nx) ? (1 << c) : 0;
-
-  R acc[CPT][KMAX];
-#pragma unroll
-  for (int c = 0; c < CPT; ++c)
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) acc[c][k] = R(0);
-
-  // the y-table rows of this tile, staged once: [rows_per_tile][KY] behind the column sums (KY = K
-  // rounded up to an even count so that every row starts 16-byte aligned).  In the streaming loop
-  // they are read back as LDS broadcasts, which can be issued ahead of the FMAs (scalar loads
-  // return out of order and force a full wait in front of every row).
-  constexpr int KY = (KMAX + 1) & ~1;
-  R* const s_cy = s_S + ((K * kPad + kBlock + 3) & ~3);
-  for (int e = tid; e < (r1 - r0) * K; e += kBlock) {
-    const int rr = e / K, kk = e - rr * K;
-    s_cy[rr * KY + kk] = cy[static_cast<size_t>(r0 + rr) * K + kk];
-  }
-  R* const s_lut = s_cy + ((rows_per_tile * KY + 3) & ~3);
-  if (kCells) s_lut[tid] = lut[tid];  // kBlock == 256 entries
-  __syncthreads();
-
-  auto decode = [&](const raw_t (&raw)[RAWN], int c) -> R {
-    if constexpr (kCells) {
-      const R e = s_lut[(raw[0] >> (8 * c)) & 0xff];
-      return ((okmask >> c) & 1) ? e : R(0);
-    } else {
-      return raw[c];
-    }
-  };
-  auto load_row = [&](int iy, raw_t (&v)[RAWN]) {
-    const IN* const row = phi + static_cast<size_t>(iy) * nx;
-    if constexpr (kCells) {
-      if (vec_ok) {
-        if (CPT == 4) v[0] = *reinterpret_cast<const int*>(row + ix);
-        else if (CPT == 2) v[0] = *reinterpret_cast<const unsigned short*>(row + ix);
-        else v[0] = (ix < nx) ? static_cast<int>(static_cast<unsigned char>(row[ix])) : 0;
-      } else {
-        int packed = 0;
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) {
-          if (ix + c < nx) packed |= static_cast<int>(static_cast<unsigned char>(row[ix + c])) << (8 * c);
-        }
-        v[0] = packed;
-      }
-    } else if (vec_ok) {
-      if (CPT == 1) {
-        v[0] = (ix < nx) ? row[ix] : R(0);
-      } else {
-        typedef R vecn __attribute__((ext_vector_type(CPT)));
-        const vecn t = *reinterpret_cast<const vecn*>(row + ix);
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) v[c] = t[c];
-      }
-    } else {
-#pragma unroll
-      for (int c = 0; c < CPT; ++c) v[c] = (ix + c < nx) ? row[ix + c] : R(0);
-    }
-  };
-  auto consume_row = [&](int iy, const raw_t (&raw)[RAWN]) {
-    const R* const cyrow = s_cy + (iy - r0) * KY;  // same address in every lane: broadcast
-    R val[CPT];
-#pragma unroll
-    for (int c = 0; c < CPT; ++c) val[c] = decode(raw, c);
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      if (EXACT || k < K) {
-        const R w = cyrow[k];
-#pragma unroll
-        for (int c = 0; c < CPT; ++c) acc[c][k] += val[c] * w;
-      }
-    }
-  };
-
-  // software pipeline: the loads of the next group of rows are issued before the current group is
-  // consumed, so HBM latency overlaps the K FMAs per element instead of preceding them
-  int iy = r0;
-  raw_t vcur[kRowsInFlight][RAWN], vnxt[kRowsInFlight][RAWN];
-  const bool have_first = iy + kRowsInFlight <= r1;
-  if (have_first) {
-#pragma unroll
-    for (int u = 0; u < kRowsInFlight; ++u) load_row(iy + u, vnxt[u]);
-  }
-  for (; iy + kRowsInFlight <= r1; iy += kRowsInFlight) {
-#pragma unroll
-    for (int u = 0; u < kRowsInFlight; ++u)
-#pragma unroll
-      for (int c = 0; c < RAWN; ++c) vcur[u][c] = vnxt[u][c];
-    if (iy + 2 * kRowsInFlight <= r1) {
-#pragma unroll
-      for (int u = 0; u < kRowsInFlight; ++u) load_row(iy + kRowsInFlight + u, vnxt[u]);
-    }
-#pragma unroll
-    for (int u = 0; u < kRowsInFlight; ++u) consume_row(iy + u, vcur[u]);
-  }
-  for (; iy < r1; ++iy) {
-    raw_t raw[RAWN];
-    load_row(iy, raw);
-    consume_row(iy, raw);
-  }
-
-  // epilogue: out[k2][k1] = sum_c S[k2][c] cx[k1][ix0 + c] -- a (K x kCols)(kCols x K) product, on the
-  // matrix cores: A[i = k2][k = column] from the LDS column sums, B[k = column][j = k1] from the x
-  // table (L2-resident), four columns per v_mfma_*_16x16x4, each wavefront a quarter of the column
-  // groups, then one add per mode across the four wavefronts.  One pass per column slot of the
-  // lanes (the LDS buffer holds 256 column sums per mode whatever CPT is).  Rows / columns beyond K
-  // are clamped to K - 1 (their products land in ignored accumulator entries); out-of-range grid
-  // columns carry zero sums.
-  using M = Mfma<R>;
-  using acc_t = typename M::acc_t;
-  constexpr int NT = (KMAX + 15) / 16;
-  const int lane = tid & (kWave - 1), wave = tid / kWave;
-  const int li = lane & 15, lk = lane >> 4;
-  acc_t macc[NT][NT];
-#pragma unroll
-  for (int a = 0; a < NT; ++a)
-#pragma unroll
-    for (int b = 0; b < NT; ++b) macc[a][b] = acc_t{ R(0), R(0), R(0), R(0) };
-  int rowA[NT], rowB[NT];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const int r = 16 * t + li;
-    rowA[t] = (r < K ? r : K - 1) * kPad;                             // k2 row of the column sums
-    rowB[t] = r < K ? r : K - 1;                                      // k1 row of the x table
-  }
-#pragma unroll
-  for (int cp = 0; cp < CPT; ++cp) {
-    if (cp > 0) __syncthreads();  // the previous pass's operand reads are done
-#pragma unroll
-    for (int k = 0; k < KMAX; ++k) {
-      if (EXACT || k < K) s_S[k * kPad + tid] = acc[cp][k];
-    }
-    __syncthreads();
-    for (int cg = wave; cg < kBlock / 4; cg += kBlock / kWave) {
-      const int t = 4 * cg + lk;                 // owner lane of this operand column
-      int gx = ix0 + t * CPT + cp;
-      gx = gx < nx ? gx : nx - 1;                // clamped: the matching column sum is zero
-      R av[NT], bv[NT];
-#pragma unroll
-      for (int q = 0; q < NT; ++q) {
-        av[q] = s_S[rowA[q] + t];
-        bv[q] = cx[static_cast<size_t>(rowB[q]) * nx + gx];
-      }
-#pragma unroll
-      for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int b = 0; b < NT; ++b) macc[a][b] = M::run(av[a], bv[b], macc[a][b]);
-    }
-  }
-  __syncthreads();  // every wavefront is done reading the column sums
-  R* const s_red = s_S;  // [4 wavefronts][K^2], reuses the column-sum region (K^2 * 4 <= K * kPad)
-  const int K2 = K * K;
-#pragma unroll
-  for (int a = 0; a < NT; ++a)
-#pragma unroll
-    for (int b = 0; b < NT; ++b)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int k2 = 16 * a + M::row(lane, r), k1 = 16 * b + li;
-        if (k2 < K && k1 < K) s_red[wave * K2 + k2 * K + k1] = macc[a][b][r];  // col = k2*K + k1
-      }
-  __syncthreads();
-  R* const out = partials + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * K2;
-  for (int m = tid; m < K2; m += kBlock) {
-    R t = R(0);
-#pragma unroll
-    for (int w = 0; w < kBlock / kWave; ++w) t += s_red[w * K2 + m];
-    out[m] = t;
-  }
-}
+#ifdef EEA_AB_BUILD
+#include "../../tools/ab/phik_pass1_kernel.inc"
+#endif
 
 // pass 1 on the matrix cores: S[k2][col] = sum_rows cy[row][k2] * phi[row][col] is a GEMM whose
 // B operand (4 rows x 16 columns per v_mfma_*_16x16x4) is exactly what a wavefront loads from the
@@ -623,54 +418,6 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const R* __restric
 }
 constexpr int kModesPerSumBlock = kBlock / kWave;
 
-// columns per lane.  kind: 0 = fp64 values, 1 = fp32 values, 2 = occupancy cells (bytes).
-// More columns per lane divide the y-table LDS reads per element; the accumulators (CPT * K reals
-// per lane) bound it.  EEA_PHIK_CPT overrides within what is built (tools/phik_prof.sh sweeps).
-constexpr int kKindF64 = 0, kKindF32 = 1, kKindCells = 2;
-inline int spatial_cpt_max(int K, int kind)
-{
-  if (!(K == 5 || K == 10 || K == 20 || K == 30)) return 1;  // run-time K instances: one column
-  if (kind == kKindF64) return 2;
-  return K <= 10 ? 4 : 2;
-}
-inline int spatial_cpt(int K, int kind)
-{
-  static const int forced = [] {
-    const char* v = std::getenv("EEA_PHIK_CPT");
-    return v ? std::atoi(v) : 0;
-  }();
-  const int cmax = spatial_cpt_max(K, kind);
-  if (forced == 1 || forced == 2 || forced == 4) return forced < cmax ? forced : cmax;
-  // measured on MI355X (profiles/r01_phik_rows_sweep.txt)
-  if (kind == kKindCells) return cmax;
-  if (kind == kKindF32) return K >= 20 ? 2 : 1;
-  return K >= 20 ? 2 : 1;
-}
-
-// rows per workgroup: tall tiles amortise the K^2 epilogue while leaving a few workgroups per CU
-// on large grids; the tile's y-table rows live in LDS, which caps the height
-inline int spatial_rows_per_tile(int nx, int ny, int K, int cpt)
-{
-  const int cols = kBlock * cpt;
-  const int col_tiles = (nx + cols - 1) / cols;
-  // tuning knob for tools/phik_prof.sh: EEA_PHIK_ROWS fixes the rows per tile
-  static const int forced = [] {
-    const char* v = std::getenv("EEA_PHIK_ROWS");
-    return v ? std::atoi(v) : 0;
-  }();
-  if (forced > 0) return forced < ny ? forced : ny;
-  // measured on MI355X (profiles/r01_phik_rows_sweep.txt): 128-row tiles for K <= 20 and 64-row
-  // tiles for larger K are best on 8192^2 grids
-  int row_tiles = (K > 20 ? 4096 : 2048) / col_tiles;
-  if (row_tiles < 1) row_tiles = 1;
-  int rpt = (ny + row_tiles - 1) / row_tiles;
-  const int cap = K > 20 ? 64 : 128;
-  if (rpt > cap) rpt = cap;
-  if (rpt < 32) rpt = 32;
-  if (rpt > ny) rpt = ny;
-  return rpt;
-}
-
 constexpr int kPointChunk = 128;        // points staged in LDS at a time
 constexpr int kPointsPerBlock = 2048;   // points one workgroup reduces
 
@@ -811,6 +558,7 @@ hipError_t launch_scale_by_inv(R* d_phi, size_t n, const R* d_sum, hipStream_t s
 }
 
 // ---- geometry of the matrix-core streaming kernel -------------------------------------------
+#ifdef EEA_AB_BUILD
 inline bool spatial_use_mfma()
 {
   static const bool valu = [] {
@@ -819,6 +567,7 @@ inline bool spatial_use_mfma()
   }();
   return !valu;  // EEA_PHIK_IMPL=valu selects the per-column accumulator kernel (A/B baseline)
 }
+#endif
 // columns per workgroup: 4 wavefronts x 16 x (columns per lane)
 inline int stream_cols(int kind, int NT)
 {
@@ -852,8 +601,9 @@ inline int stream_rows_per_tile(int nx, int ny, int kind, int NT)
 
 size_t spatial_work_elems(int nx, int ny, int K)
 {
-  // the largest tile count over the column-per-lane choices of any input kind
+  // the largest tile count over the input kinds
   size_t tiles = 0;
+#ifdef EEA_AB_BUILD
   for (int cpt = 1; cpt <= 4; cpt *= 2) {
     const int cols = kBlock * cpt;
     const int col_tiles = (nx + cols - 1) / cols;
@@ -862,6 +612,7 @@ size_t spatial_work_elems(int nx, int ny, int K)
     const size_t t = static_cast<size_t>(col_tiles) * row_tiles;
     tiles = t > tiles ? t : tiles;
   }
+#endif
   const int NT = K <= 16 ? 1 : 2;
   for (int kind = 0; kind < 3; ++kind) {
     const int cols = stream_cols(kind, NT);
@@ -881,7 +632,12 @@ hipError_t launch_spatial_generic(const IN* d_in, int nx, int ny, int K, const R
   constexpr bool kCells = !std::is_same<IN, R>::value;
   constexpr int kind = kCells ? kKindCells : (sizeof(R) == 8 ? kKindF64 : kKindF32);
   const int K2 = K * K;
-  if (spatial_use_mfma()) {
+#ifdef EEA_AB_BUILD
+  if (!spatial_use_mfma()) {
+#include "../../tools/ab/phik_pass1_dispatch.inc"
+  }
+#endif
+  {
     const int NT = K <= 16 ? 1 : 2;
     const int cols = stream_cols(kind, NT);
     const int col_tiles = (nx + cols - 1) / cols;
@@ -905,49 +661,6 @@ hipError_t launch_spatial_generic(const IN* d_in, int nx, int ny, int K, const R
                        d_work, col_tiles * row_tiles, K2, R(1), d_phik);
     return hipGetLastError();
   }
-  const int cpt = spatial_cpt(K, kind);
-  const int cols = kBlock * cpt;
-  const int col_tiles = (nx + cols - 1) / cols;
-  const int rpt = spatial_rows_per_tile(nx, ny, K, cpt);
-  const int row_tiles = (ny + rpt - 1) / rpt;
-  // column sums [K][257] plus the epilogue's per-group partials (<= 256 reals), the tile's
-  // y-table rows and (occupancy input) the 256-entry decode table
-  const int KYmax = ((K <= 16 ? (K == 5 ? 5 : (K == 10 ? 10 : 16)) : (K == 20 ? 20 : (K == 30 ? 30 : 32))) + 1) & ~1;
-  const size_t lds = (static_cast<size_t>(K) * (kBlock + 1) + kBlock + 4 + static_cast<size_t>(rpt) * KYmax + 4 +
-                      (kCells ? 256 : 0)) * sizeof(R);
-  const dim3 grid(col_tiles, row_tiles);
-  auto launch = [&](auto kern) -> hipError_t {
-    if (lds > 64 * 1024) {
-      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               static_cast<int>(lds));
-      if (e != hipSuccess) return e;
-    }
-    hipLaunchKernelGGL(kern, grid, dim3(kBlock), lds, s, d_in, nx, ny, K, rpt, d_cx, d_cy, d_lut, d_work);
-    return hipGetLastError();
-  };
-  // exact-K instances for the BASELINE basis sizes x the columns-per-lane choices of this input kind
-  constexpr bool kWide = kind != kKindF64;  // four columns per lane: 16-byte fp32 loads / one dword of cells
-  hipError_t e = hipErrorInvalidValue;
-  auto pick = [&](auto k_tag) -> hipError_t {
-    constexpr int KX = decltype(k_tag)::value;
-    if (cpt == 1) return launch(spatial_pass1_kernel<R, KX, 1, true, IN>);
-    if (cpt == 2) return launch(spatial_pass1_kernel<R, KX, 2, true, IN>);
-    if constexpr (kWide && KX <= 10) {
-      if (cpt == 4) return launch(spatial_pass1_kernel<R, KX, 4, true, IN>);
-    }
-    return hipErrorInvalidValue;
-  };
-  if (K == 5) e = pick(std::integral_constant<int, 5>{});
-  else if (K == 10) e = pick(std::integral_constant<int, 10>{});
-  else if (K == 20) e = pick(std::integral_constant<int, 20>{});
-  else if (K == 30) e = pick(std::integral_constant<int, 30>{});
-  else if (K <= 16) e = launch(spatial_pass1_kernel<R, 16, 1, false, IN>);
-  else e = launch(spatial_pass1_kernel<R, 32, 1, false, IN>);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(sum_partials_kernel<R>, dim3((K2 + kModesPerSumBlock - 1) / kModesPerSumBlock), dim3(kBlock), 0, s,
-                     d_work, col_tiles * row_tiles, K2, R(1), d_phik);
-  return hipGetLastError();
 }
 
 // out[m] = raw[m] / raw[0]: the (0,0) mode of the un-normalised sums is the sum of the target

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EEA_ABI_VERSION 1
+#define EEA_ABI_VERSION 2
 
 /* models usable with ErgodicControl (Cart/Mecanum cannot run under it) */
 enum { EEA_MODEL_OMNI = 0,        /* models::Omni        models/omni.hpp:164-215 */
@@ -154,22 +154,56 @@ typedef struct {
   void* d_bdx;            /* [B][T][3]  out, optional: gradBarrier (:273)              */
   void* d_rhot;           /* [B][T][3]  out, optional: co-state (:277)                 */
   int* d_status;          /* [B]        out, optional: per-agent eea_status            */
+  const void* d_ck_shared;/* [K^2]      in, optional (ABI 2): decentralised-consensus mode.
+                                        When set, fourier_diff = lamdak % (ck - phik)
+                                        (:422) is formed with this shared c_k (e.g. the mean
+                                        of all agents' c_k, eea_comm_consensus_ck) instead of
+                                        the agent's own; d_ck still receives the own c_k.
+                                        No counterpart in the single-agent reference: the
+                                        semantics are those of its README ref. [2]
+                                        (README.md:225-227).  NULL = reference behaviour      */
 } eea_batch_io;
 
 /* One receding-horizon optimisation per agent (ergodic_control.hpp:224-311, without the
  * configTarget call: use eea_config_domain first).  Asynchronous on `stream`. */
 eea_status eea_control_batch(eea_engine* e, unsigned B, const eea_batch_io* io, void* stream);
 
-/* Diagnostic (not part of the reference surface): same as eea_control_batch for an fp64,
- * K = 10 engine, through an instrumented build that records the shader clock of every
- * wavefront at 12 phase boundaries: d_stamps [B][4][16] int64 (tools/phase_timing.py). */
-eea_status eea_debug_phase_timing(eea_engine* e, unsigned B, const eea_batch_io* io, void* stream,
-                                  long long* d_stamps);
-
 /* Forward rollout only: ErgodicControl::optTraj / path (ergodic_control.hpp:313-342),
  * RungeKutta::solve (integrator.hpp:135-152).  d_ut is used as is (no shift). */
 eea_status eea_rollout_batch(eea_engine* e, unsigned B, const void* d_pose, const void* d_ut,
                              void* d_traj, int* d_status, void* stream);
+
+/* ---- multi-GPU exchange steps of the agent batch (RCCL over xGMI) -------------------- */
+/* The reference is single-agent; an agent batch sharded over the GPUs of a node (one process
+ * per GPU, contiguous agent blocks, no collective inside the control computation) exchanges the
+ * per-agent trajectory coefficients c_k the way decentralised ergodic control shares them
+ * (reference README ref. [2], README.md:225-227).  These calls are what a C++ host uses to shard
+ * without Python; RCCL is bound at run time (no link dependency).  All asynchronous on `stream`.
+ *
+ * Rank 0 obtains an id (EEA_COMM_ID_BYTES bytes) and hands it to the other ranks by any means
+ * (file, socket, MPI, torch.distributed); every rank then creates its communicator.
+ * id == NULL with nranks == 1 gives a local communicator without RCCL. */
+#define EEA_COMM_ID_BYTES 128
+typedef struct eea_comm eea_comm;
+eea_status eea_comm_get_unique_id(void* id);
+eea_status eea_comm_create(int device, int nranks, int rank, const void* id, eea_comm** out);
+void eea_comm_destroy(eea_comm* c);
+int eea_comm_rank(const eea_comm* c);
+int eea_comm_nranks(const eea_comm* c);
+/* sums[m] = sum over the B local agents of d_ck[b][m], m < K^2, and sums[K^2] = B (K^2 + 1 reals,
+ * device): the local half of the consensus reduction */
+eea_status eea_ck_sum(eea_engine* e, unsigned B, const void* d_ck, void* d_sums, void* stream);
+/* one in-place-capable ncclAllGather: d_ck_all [nranks * B_local][K^2] in rank order (equal shards) */
+eea_status eea_comm_allgather_ck(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_local,
+                                 void* d_ck_all, void* stream);
+/* consensus c_k: d_ck_shared[m] = mean over ALL agents of all ranks of c_k[m] -- eea_ck_sum, one
+ * ncclAllReduce(sum) of K^2 + 1 reals (808 B at K = 10), one divide; feed it to
+ * eea_batch_io::d_ck_shared */
+eea_status eea_comm_consensus_ck(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_local,
+                                 void* d_ck_shared, void* stream);
+/* in-place ncclAllReduce(sum) of n reals: the K^2 partial sums of a grid-tiled phi_k
+ * (eea_spatial_coeff_rows / eea_spatial_coeff_occupancy_rows) */
+eea_status eea_comm_allreduce_sum(eea_engine* e, eea_comm* c, void* d_buf, unsigned n, void* stream);
 
 /* ---- single agent, host pointers (what ErgodicControl<ModelT>::control binds to) ---- */
 /* vec control(const GridMap& grid, const vec& x) (ergodic_control.hpp:224-311) including

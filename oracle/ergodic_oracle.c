@@ -793,6 +793,9 @@ struct eo_control {
    * baseline free of allocator contention when one agent runs per thread */
   double *w_traj, *w_xt_total, *w_ck, *w_edx, *w_bdx, *w_rhot, *w_fk, *w_dfk, *w_diff;
   unsigned w_ncap;
+  /* decentralised-consensus option (not in the reference's single-agent code; README ref. [2]):
+   * when set, gradErgodicMetric uses this shared c_k in place of the agent's own */
+  double* ck_shared;
 };
 
 /* ergodic_control.hpp:187-222 */
@@ -850,6 +853,7 @@ void eo_control_destroy(eo_control* ec)
   free(ec->w_fk);
   free(ec->w_dfk);
   free(ec->w_diff);
+  free(ec->ck_shared);
   free(ec);
 }
 
@@ -857,6 +861,16 @@ unsigned eo_control_steps(const eo_control* ec) { return ec->steps; }
 const double* eo_control_phik(const eo_control* ec) { return ec->phik; }
 const double* eo_control_lamdak(const eo_control* ec) { return ec->lamdak; }
 double* eo_control_ut(eo_control* ec) { return ec->ut; }
+
+void eo_control_set_shared_ck(eo_control* ec, const double* ck_shared)
+{
+  free(ec->ck_shared);
+  ec->ck_shared = NULL;
+  if (ck_shared) {
+    ec->ck_shared = (double*)malloc(sizeof(double) * (ec->K2 ? ec->K2 : 1));
+    memcpy(ec->ck_shared, ck_shared, sizeof(double) * ec->K2);
+  }
+}
 
 /* ergodic_control.hpp:356-360 */
 void eo_control_set_target(eo_control* ec, unsigned n_gauss, const double* mu, const double* sigma)
@@ -932,6 +946,8 @@ static void grad_ergodic_metric(const eo_control* ec, const double* ck, const do
   const unsigned K2 = ec->K2;
   double* fourier_diff = ec->w_diff;
   double* dfk = ec->w_dfk;
+  /* :422 fourier_diff = lamdak % (ck - phik); with a shared c_k the agents' mean replaces ck */
+  if (ec->ck_shared) ck = ec->ck_shared;
   for (unsigned m = 0; m < K2; m++) fourier_diff[m] = ec->lamdak[m] * (ck[m] - ec->phik[m]);
   for (unsigned i = 0; i < ec->steps; i++) {
     eo_grad_fourier_basis(ec->lx, ec->ly, ec->K, xt + 3 * (size_t)i, dfk);
@@ -1095,6 +1111,7 @@ typedef struct {
   double xmin, xmax, ymin, ymax;
   unsigned first, last, calls;
   double* u_last;
+  double* ut_last; /* 3 x T per agent, may be NULL */
 } bench_job;
 
 static void* bench_worker(void* arg)
@@ -1109,6 +1126,7 @@ static void* bench_worker(void* arg)
                       NULL);
     }
     if (j->u_last) memcpy(j->u_last + 3 * (size_t)a, u, sizeof(u));
+    if (j->ut_last) memcpy(j->ut_last + 3 * (size_t)ec->steps * a, ec->ut, sizeof(double) * 3 * ec->steps);
   }
   return NULL;
 }
@@ -1126,6 +1144,15 @@ double eo_bench_control(const eo_control_config* cfg, unsigned n_gauss, const do
                         const double* sigma, double xmin, double xmax, double ymin, double ymax,
                         const double* poses, unsigned n_agents, unsigned calls, unsigned threads,
                         double* u_last)
+{
+  return eo_batch_control(cfg, n_gauss, mu, sigma, xmin, xmax, ymin, ymax, poses, n_agents, calls,
+                          threads, u_last, NULL);
+}
+
+double eo_batch_control(const eo_control_config* cfg, unsigned n_gauss, const double* mu,
+                        const double* sigma, double xmin, double xmax, double ymin, double ymax,
+                        const double* poses, unsigned n_agents, unsigned calls, unsigned threads,
+                        double* u_last, double* ut_last)
 {
   if (threads == 0) threads = 1;
   if (threads > n_agents) threads = n_agents ? n_agents : 1;
@@ -1157,11 +1184,13 @@ double eo_bench_control(const eo_control_config* cfg, unsigned n_gauss, const do
     jobs[t].last = (unsigned)(((uint64_t)n_agents * (t + 1)) / threads);
     jobs[t].calls = 1; /* warm-up */
     jobs[t].u_last = NULL;
+    jobs[t].ut_last = NULL;
   }
   bench_run(jobs, tids, threads);
   for (unsigned t = 0; t < threads; t++) {
     jobs[t].calls = calls;
     jobs[t].u_last = u_last;
+    jobs[t].ut_last = ut_last;
   }
   struct timespec t0, t1;
   clock_gettime(CLOCK_MONOTONIC, &t0);

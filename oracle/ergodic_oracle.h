@@ -174,6 +174,10 @@ int eo_control_step(eo_control* ec, double xmin, double xmax, double ymin, doubl
                     const double x[3], const double* mem_cols, unsigned n_mem, double u_out[3],
                     const eo_stage_out* stages);
 int eo_control_opt_traj(const eo_control* ec, double* traj /* 3 x T */);
+/* Decentralised-consensus switch (multi-agent extension, reference README ref. [2]; no single-agent
+ * counterpart in ergodic_control.hpp): ck_shared (K^2, copied) replaces the agent's own c_k in
+ * fourier_diff = lamdak % (ck - phik) (ergodic_control.hpp:422); NULL restores the reference behaviour */
+void eo_control_set_shared_ck(eo_control* ec, const double* ck_shared);
 
 /* bounded CPU-baseline loop for bench.py: runs `calls` control() calls on each of
  * n_agents independent controllers, spread over `threads` pthreads; returns
@@ -182,6 +186,12 @@ double eo_bench_control(const eo_control_config* cfg, unsigned n_gauss, const do
                         const double* sigma, double xmin, double xmax, double ymin, double ymax,
                         const double* poses, unsigned n_agents, unsigned calls, unsigned threads,
                         double* u_last /* 3 per agent, may be NULL */);
+/* same loop (one warm-up call + `calls` calls per agent) that also returns every agent's warm-start
+ * controls after the last call: ut_last 3 x T per agent (may be NULL).  Full-size parity checks. */
+double eo_batch_control(const eo_control_config* cfg, unsigned n_gauss, const double* mu,
+                        const double* sigma, double xmin, double xmax, double ymin, double ymax,
+                        const double* poses, unsigned n_agents, unsigned calls, unsigned threads,
+                        double* u_last, double* ut_last);
 
 #ifdef __cplusplus
 }

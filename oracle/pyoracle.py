@@ -82,6 +82,7 @@ def lib():
         L.eo_control_ut.restype = _dp
         L.eo_control_steps.restype = C.c_uint
         L.eo_bench_control.restype = C.c_double
+        L.eo_batch_control.restype = C.c_double
         L.eo_grid2rowmajor.restype = C.c_uint
         _lib = L
     return _lib
@@ -359,6 +360,15 @@ class ErgodicControl:
         lib().eo_control_set_target_grid(self.h, C.c_uint(nx), C.c_uint(ny), _p(phi_vals),
                                          C.c_double(lx), C.c_double(ly))
 
+    def set_shared_ck(self, ck_shared):
+        """consensus switch: the shared c_k (K^2) replaces the agent's own in the gradient; None resets"""
+        if ck_shared is None:
+            lib().eo_control_set_shared_ck(self.h, None)
+        else:
+            a = _d(ck_shared).reshape(-1)
+            assert a.size == self.K * self.K
+            lib().eo_control_set_shared_ck(self.h, _p(a))
+
     def config_target(self, bounds):
         return int(lib().eo_control_config_target(self.h, *[C.c_double(b) for b in bounds]))
 
@@ -435,3 +445,18 @@ def bench_control(cfg, mu, sigma, bounds, poses, calls, threads):
                                  *[C.c_double(b) for b in bounds], _p(poses), C.c_uint(n),
                                  C.c_uint(calls), C.c_uint(threads), _p(u_last))
     return sec, u_last
+
+
+def batch_control(cfg, mu, sigma, bounds, poses, calls, threads):
+    """One warm-up + `calls` control() calls on every agent (independent controllers, zero warm start,
+    one agent per thread).  returns (u_last (n, 3), ut_last (n, T, 3)) after the last call."""
+    mu, sigma = _d(mu).reshape(-1), _d(sigma).reshape(-1)
+    poses = _d(poses)
+    n = poses.shape[0]
+    T = steps(cfg.horizon, cfg.dt)
+    u_last = np.empty((n, 3))
+    ut_last = np.empty((n, T, 3))
+    lib().eo_batch_control(C.byref(cfg), C.c_uint(mu.size // 2), _p(mu), _p(sigma),
+                           *[C.c_double(b) for b in bounds], _p(poses), C.c_uint(n),
+                           C.c_uint(calls), C.c_uint(threads), _p(u_last), _p(ut_last))
+    return u_last, ut_last

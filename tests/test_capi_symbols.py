@@ -17,13 +17,22 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 25
     missing = [s for s in syms if not hasattr(L, s)]
     assert missing == []
-    assert capi.lib().eea_abi_version() == 1
+    assert capi.lib().eea_abi_version() == 2
+
+
+def test_library_exports_only_the_documented_abi():
+    # the product library carries no A/B kernels or diagnostics: its dynamic symbol table is exactly the
+    # set of entry points the header declares (csrc/exports.map; the superseded kernels live in tools/ab/)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == capi.declared_symbols()
 
 
 def test_struct_layouts_match_header():
     # sizes the C compiler gives the ABI structs (kept in sync with ergodic_amd.h by hand)
     assert C.sizeof(capi.Config) == 3 * 4 + 4 + 4 * 8 + 8 + 15 * 8  # ints, pad, doubles, K+pad, arrays
-    assert C.sizeof(capi.BatchIO) == 12 * 8
+    assert C.sizeof(capi.BatchIO) == 13 * 8
     assert C.sizeof(capi.CollisionCfg) == 3 * 8 + 2 * 4 + 4 * 8
 
 
@@ -48,3 +57,8 @@ def test_argument_errors_do_not_need_a_device():
     assert L.eea_create(C.byref(bad), C.byref(h)) == capi.ERR_INVALID_ARGUMENT  # Mecanum
     bad = capi.make_config(capi.MODEL_OMNI, 0.1, 1.0, 0.1, 1.0, 64, np.eye(3), [-1] * 3, [1] * 3)
     assert L.eea_create(C.byref(bad), C.byref(h)) == capi.ERR_UNSUPPORTED
+    # exchange steps: argument checks come before any device / RCCL call
+    assert L.eea_comm_create(0, 2, 5, None, C.byref(h)) == capi.ERR_INVALID_ARGUMENT
+    assert L.eea_comm_create(0, 2, 0, None, C.byref(h)) == capi.ERR_INVALID_ARGUMENT  # nranks > 1 needs an id
+    assert L.eea_comm_get_unique_id(None) == capi.ERR_INVALID_ARGUMENT
+    assert L.eea_comm_nranks(None) == 1 and L.eea_comm_rank(None) == 0

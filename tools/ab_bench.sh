@@ -1,5 +1,6 @@
 #!/bin/bash
 # A/B of library variants / kernel versions on the headline bench (interleaved rounds, one process each).
+# (EEA_CONTROL_IMPL=v1 and EEA_PHIK_IMPL=valu need the A/B library: make -C ergodic_exploration_amd/csrc AB=1, EEA_LIB_VARIANT=_ab)
 # usage: tools/ab_bench.sh "<label>:<env assignments>" ...   e.g.  "v1:EEA_CONTROL_IMPL=v1" "w4:EEA_LIB_VARIANT=_w4" "main:"
 ROUNDS=${ROUNDS:-3}
 for r in $(seq 1 $ROUNDS); do

@@ -9,6 +9,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+# the instrumented kernel lives in the A/B library: make -C ergodic_exploration_amd/csrc AB=1
+os.environ.setdefault("EEA_LIB_VARIANT", "_ab")
 from ergodic_exploration_amd import capi  # noqa: E402
 
 PHASES = ["load+shift controls", "heading scan", "heading sincos", "position scan", "basis sincos",
