@@ -1,22 +1,29 @@
 #!/usr/bin/env python3
 """Headline benchmark: receding-horizon optimisations/s at K = 10x10, T = 200, agent batch.
 
-One "step" = one batched `ErgodicControl::control` pass (eea_control_batch) over the rank's
-agents, each agent one complete receding-horizon optimisation.  Weak scaling: every rank (one
-process per GPU) owns `--agents` independent agents; after each step the per-agent c_k are
-all-gathered over RCCL (overlapped with the next step on a separate stream).
+One "pass" = one batched `ErgodicControl::control` (eea_control_batch) over the rank's agents, each agent one
+complete receding-horizon optimisation.  One "step" = `--passes-per-step` consecutive passes (the receding
+horizon: every pass starts from the controls the previous one left), so that the timed region of the
+driver's `--steps 20` lasts tens of milliseconds instead of one.
 
-  python bench.py --gpus 1 --steps 20 --warmup 5
+Weak scaling: every rank (one process per GPU) owns `--agents` independent agents; the control computation
+has no data-path collective, and `value` is that pure agent shard.  The exchange steps the agent batch can
+run on top are timed as separate legs and reported under "exchange": the consensus c_k (one all-reduce of
+K^2 + 1 reals per pass, consumed by the next passes through eea_batch_io::d_ck_shared) and the all-gather of
+every agent's c_k that north_star names.
+
+  python bench.py                                  # 1 GPU
+  python bench.py --gpus N --steps K --warmup W    # starts its N ranks itself (one child process per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-      --master-port P bench.py --gpus N --steps K --warmup W
+      --master-port P bench.py --gpus N --steps K --warmup W      # what the driver runs for N > 1
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -27,13 +34,16 @@ SIGMAS = [[1.5, 1.5], [1.5, 1.5]]
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_F64_PEAK_TF = 78.6     # fp64 vector peak
 VALU_F32_PEAK_TF = 157.3
+PARITY_TOL = {"f64": {"ck_phik": 1e-11, "traj_rho_u": 1e-9}, "f32": {"u": 1e-4, "rho": 5e-4}}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--passes-per-step", type=int, default=100,
+                    help="consecutive control passes per timed step (receding horizon)")
     ap.add_argument("--agents", type=int, default=4096, help="agents per GPU")
     ap.add_argument("--model", default="simple_cart", choices=["simple_cart", "omni"])
     ap.add_argument("--num-basis", type=int, default=10)
@@ -41,34 +51,81 @@ def parse():
     ap.add_argument("--dt", type=float, default=0.1)
     ap.add_argument("--n-mem", type=int, default=0)
     ap.add_argument("--precision", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--no-gather", action="store_true", help="skip the c_k all-gather (N > 1)")
-    ap.add_argument("--force-gather", action="store_true",
-                    help="run the c_k all-gather even with one rank (exercises the RCCL path on 1 GPU)")
+    ap.add_argument("--no-exchange", "--no-gather", dest="no_exchange", action="store_true",
+                    help="skip the exchange legs (consensus all-reduce, c_k all-gather)")
+    ap.add_argument("--force-exchange", "--force-gather", dest="force_exchange", action="store_true",
+                    help="run the all-gather leg even with one rank (single-rank RCCL communicator)")
+    ap.add_argument("--consensus-lag", type=int, default=2, choices=[1, 2],
+                    help="passes between producing c_k and consuming its consensus (2: the exchange overlaps a pass)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per leg; 0 = skip")
-    ap.add_argument("--latency", action="store_true", help="(default on one GPU) also time the B = 1 dependent-call mode")
     ap.add_argument("--no-latency", action="store_true", help="skip the B = 1 dependent-call leg")
+    ap.add_argument("--no-phik", action="store_true", help="skip the phi_k legs (roofline_phik)")
+    ap.add_argument("--phik-grid", type=int, default=16384, help="side of the square fp64 grid of the phi_k leg")
     ap.add_argument("--agent-groups", type=int, default=1,
-                    help="split the rank's agents into this many groups, each launched on its own HIP stream: the "
-                         "drain of one group's launch overlaps the fill of another's (agents are independent)")
+                    help="split the rank's agents into this many groups, each launched on its own HIP stream")
     return ap.parse_args()
 
 
-def cpu_baseline(args, T, seconds):
-    """Oracle (literal CPU restatement, kind 'port') timed on this host: 1 thread and all cores."""
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: this process has made NO GPU call (torch is not
+    even imported); it starts the N ranks as children of torch.distributed.run, forwards their output (rank 0
+    prints the ONE JSON line) and exits with their return code."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+def host_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    usable = ncores
+    try:  # a cgroup CPU quota (e.g. "1600000 100000" = 16 CPUs) caps the useful thread count
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            usable = max(1, min(ncores, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    cflags = "unknown"
+    try:
+        with open(os.path.join(ROOT, "oracle", "Makefile")) as f:
+            for line in f:
+                if line.startswith("CFLAGS"):
+                    cflags = "gcc " + line.split("=", 1)[1].strip()
+    except OSError:
+        pass
+    return {"cpu_model": model, "nproc": os.cpu_count() or 1, "usable_threads": usable, "cflags": cflags}
+
+
+def cpu_baseline(args, seconds):
+    """Oracle (literal CPU restatement, kind 'port') timed on this host: 1 thread and all usable cores."""
+    import numpy as np
     from oracle import pyoracle as po
     lim = np.array([1.0, 0.0, 2.0]) if args.model == "simple_cart" else np.array([1.0, 1.0, 2.0])
     Rinv = np.diag([1.0, 0.0, 2.0]) if args.model == "simple_cart" else np.diag([1.0, 1.0, 2.0])
     model = po.MODEL_SIMPLE_CART if args.model == "simple_cart" else po.MODEL_OMNI
     cfg = po.make_config(model, args.dt, args.horizon, 0.1, 1.0, args.num_basis, Rinv, -lim, lim)
     rng = np.random.default_rng(12345)
-    ncores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    try:  # a cgroup CPU quota (e.g. "1600000 100000" = 16 CPUs) caps the useful thread count
-        with open("/sys/fs/cgroup/cpu.max") as f:
-            quota, period = f.read().split()[:2]
-        if quota != "max":
-            ncores = max(1, min(ncores, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        pass
+    hi = host_info()
+    ncores = hi["usable_threads"]
 
     def poses(n):
         return np.stack([rng.uniform(-0.5, 10.5, n), rng.uniform(-0.5, 4.5, n), rng.uniform(-np.pi, np.pi, n)], 1)
@@ -80,21 +137,79 @@ def cpu_baseline(args, T, seconds):
     rate1 = 20.0 / max(sec, 1e-6)
     n1 = max(4, int(seconds * rate1 / calls))
     sec1, _ = po.bench_control(cfg, MEANS, SIGMAS, MAP_BOUNDS, poses(n1), calls, 1)
-    one = {"value": n1 * calls / sec1, "unit": "optimisations/s", "cores": 1, "kind": "port",
-           "sample": "%d agents x %d control() calls, oracle/ergodic_oracle.c gcc -O2, 1 thread, %.1f s"
-                     % (n1, calls, sec1)}
+    common = {"unit": "optimisations/s", "kind": "port", "cpu_model": hi["cpu_model"], "nproc": hi["nproc"],
+              "cflags": hi["cflags"]}
+    one = dict(common, value=n1 * calls / sec1, cores=1,
+               sample="%d agents x %d control() calls, oracle/ergodic_oracle.c, 1 thread, %.1f s" % (n1, calls, sec1))
     secc, _ = po.bench_control(cfg, MEANS, SIGMAS, MAP_BOUNDS, poses(2 * ncores), 3, ncores)
     raten = 6.0 * ncores / max(secc, 1e-6)
     nall = max(ncores, int(seconds * raten / calls))
     secn, _ = po.bench_control(cfg, MEANS, SIGMAS, MAP_BOUNDS, poses(nall), calls, ncores)
-    allc = {"value": nall * calls / secn, "unit": "optimisations/s", "cores": ncores, "kind": "port",
-            "sample": "%d agents x %d control() calls, one agent per thread, %d threads, %.1f s"
-                      % (nall, calls, ncores, secn)}
+    allc = dict(common, value=nall * calls / secn, cores=ncores,
+                sample="%d agents x %d control() calls, one agent per thread, %d threads, %.1f s"
+                       % (nall, calls, ncores, secn))
     return one, allc
+
+
+def phik_legs(args, torch, capi, np):
+    """The second kernel of the path (SURVEY.md 8(d): two kernels, two bounds): Basis::spatialCoeff streaming a
+    target grid larger than the Infinity Cache against the HBM roofline, and the wall time of a whole
+    configTarget rebuild (eea_config_domain) at the BASELINE grids."""
+    out = {}
+    n, K = args.phik_grid, args.num_basis
+    eng = capi.Engine(capi.make_config(capi.MODEL_OMNI, 0.1, 2.0, 0.1, 1.0, K, np.eye(3), [-1] * 3, [1] * 3))
+    phi = torch.rand((n * n,), dtype=torch.float64, device="cuda")
+    part = torch.empty((K * K,), dtype=torch.float64, device="cuda")
+    lx = ly = (n - 1) * 0.1
+    stream = torch.cuda.current_stream()
+    for _ in range(3):  # the first call builds the axis tables; later calls only stream the grid
+        eng.spatial_coeff_rows(n, n, 0, n, phi, lx, ly, part, stream=stream.cuda_stream)
+    torch.cuda.synchronize()
+    reps = 10
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    ev0.record(stream)
+    for _ in range(reps):
+        eng.spatial_coeff_rows(n, n, 0, n, phi, lx, ly, part, stream=stream.cuda_stream)
+    ev1.record(stream)
+    torch.cuda.synchronize()
+    ms = ev0.elapsed_time(ev1) / reps
+    nbytes = n * n * 8
+    gbs = nbytes / (ms * 1e-3) / 1e9
+    out["roofline_phik"] = {"bound": "hbm", "kernel": "spatial_stream_kernel (+ sum_partials_kernel)",
+                            "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                            "traffic": None, "traffic_source": "profiles/ (rocprofv3 --pmc passes, not collected in-run)",
+                            "bytes_per_launch": nbytes, "launch_ms": ms,
+                            "workload": "Basis::spatialCoeff, %dx%d fp64 target grid (%.2f GB) resident in HBM, K=%d"
+                                        % (n, n, nbytes / 1e9, K)}
+    eng.close()
+    del phi, part
+    torch.cuda.empty_cache()
+    # whole rebuild through the reference's entry (configTarget with a changed extent), Gaussian target
+    rebuild = []
+    for Kc, lxc, lyc in ((10, 12.0, 6.0), (20, 25.5, 25.5), (30, 102.3, 102.3)):
+        e2 = capi.Engine(capi.make_config(capi.MODEL_OMNI, 0.1, 2.0, 0.1, 1.0, Kc, np.eye(3), [-1] * 3, [1] * 3))
+        e2.set_target_gaussians(MEANS, SIGMAS)
+        for i in range(4):
+            e2.config_domain((0.0, lxc + 0.1 * (i % 2), 0.0, lyc))
+        reps = 50
+        t0 = time.perf_counter()
+        for i in range(reps):
+            e2.config_domain((0.0, lxc + 0.1 * (i % 2), 0.0, lyc))  # the extent changes on every call
+        us = 1e6 * (time.perf_counter() - t0) / reps
+        rebuild.append({"K": Kc, "grid": "%dx%d" % (round(lxc / 0.1) + 1, round(lyc / 0.1) + 1), "wall_us": us})
+        e2.close()
+    out["config_domain_rebuild"] = {"note": "wall time of one eea_config_domain with a changed extent (Target::fill + "
+                                            "normalisation + spatialCoeff on the device, one host synchronisation)",
+                                    "cases": rebuild}
+    return out
 
 
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))
+
+    import numpy as np
     import torch
     import torch.distributed as dist
     from ergodic_exploration_amd import capi
@@ -102,26 +217,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    # plumbing test on a single-GPU box: EEA_DIST_BACKEND=gloo with --no-gather runs several ranks on one
-    # device (RCCL refuses two ranks per GPU); on a real node every rank has its own device
-    backend = os.environ.get("EEA_DIST_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank = local_rank % max(1, torch.cuda.device_count())
-    torch.cuda.set_device(local_rank)
-    use_dist = world > 1 or args.force_gather
+    ndev = max(1, torch.cuda.device_count())   # counting devices does not initialise the GPU
+    shared_device = world > ndev               # plumbing runs: several ranks on one GPU
+    # RCCL refuses two ranks on one device: such runs rendezvous over gloo and stage the exchange through the host
+    backend = os.environ.get("EEA_DIST_BACKEND", "gloo" if shared_device else "nccl")
+    device = local_rank % ndev
+    torch.cuda.set_device(device)
+    use_dist = world > 1
     if use_dist:
         # RCCL writes its banner / warnings to stdout; keep stdout for the ONE JSON line
         os.environ["NCCL_DEBUG"] = os.environ.get("EEA_NCCL_DEBUG", "WARN")
         os.environ.setdefault("NCCL_DEBUG_FILE", "/tmp/eea_rccl_%h_%p.log")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         else:
             dist.init_process_group(backend)
 
@@ -135,121 +245,202 @@ def main():
     eng = capi.Engine(capi.make_config(model, args.dt, args.horizon, 0.1, 1.0, args.num_basis,
                                        np.diag(rdiag), -lim, lim,
                                        precision=capi.PREC_F32 if f32 else capi.PREC_F64,
-                                       device=local_rank))
+                                       device=device))
     eng.set_target_gaussians(MEANS, SIGMAS)
     eng.config_domain(MAP_BOUNDS)
     T, K2, B = eng.T, eng.K2, args.agents
+    R = max(1, args.passes_per_step)
 
-    # synthetic inputs: random poses, zero warm start
+    # synthetic inputs: random poses, zero warm start; resident in HBM before any timing
     rng = np.random.default_rng(12345 + rank)
     poses = np.stack([rng.uniform(0.5, 11.5, B) - 1.0, rng.uniform(0.5, 5.5, B) - 1.0,
                       rng.uniform(-np.pi, np.pi, B)], 1)
     d_pose = torch.as_tensor(poses, dtype=tdt).cuda()
     d_ut = torch.zeros((B, T, 3), dtype=tdt, device="cuda")
     d_u0 = torch.empty((B, 3), dtype=tdt, device="cuda")
-    d_ck = [torch.empty((B, K2), dtype=tdt, device="cuda") for _ in range(2)]
     d_mem = d_nmem = None
     if args.n_mem:
         mem = np.stack([rng.uniform(0.5, 11.5, B * args.n_mem) - 1.0, rng.uniform(0.5, 5.5, B * args.n_mem) - 1.0,
                         rng.uniform(-np.pi, np.pi, B * args.n_mem)], 1).reshape(B, args.n_mem, 3)
         d_mem = torch.as_tensor(mem, dtype=tdt).cuda()
         d_nmem = torch.full((B,), args.n_mem, dtype=torch.int32, device="cuda")
-    gather = (world > 1 or args.force_gather) and not args.no_gather
-    d_all = [torch.empty((world * B, K2), dtype=tdt, device="cuda") for _ in range(2)] if gather else None
 
     compute = torch.cuda.Stream()
-    torch.cuda.set_stream(compute)  # once, not per step: the step loop must out-run a 60 us kernel
-    cstream = compute.cuda_stream
-    works = [None, None]
-    all_gather = dist.all_gather_into_tensor if gather else None
+    torch.cuda.set_stream(compute)  # once, not per pass: the loop must out-run a ~40 us kernel
+    xstream = torch.cuda.Stream()   # exchange steps run beside the next pass
     # agent groups: contiguous slices of the batch, group 0 on the compute stream
     G = max(1, min(args.agent_groups, B))
-    bounds = [(g * B) // G for g in range(G + 1)]
+    gb = [(g * B) // G for g in range(G + 1)]
     gstreams = [compute] + [torch.cuda.Stream() for _ in range(G - 1)]
-    gevents = [torch.cuda.Event() for _ in range(G)]
 
     def sl(t, g):
-        return None if t is None else t[bounds[g]:bounds[g + 1]]
+        return None if t is None else t[gb[g]:gb[g + 1]]
 
-    # per-group argument tuples, built once (tensor slicing costs host time on every step otherwise)
-    gargs = [[dict(B=bounds[g + 1] - bounds[g], pose=sl(d_pose, g), ut=sl(d_ut, g), u0=sl(d_u0, g),
-                   mem_cols=sl(d_mem, g), n_mem=sl(d_nmem, g), ck=sl(d_ck[slot], g),
-                   stream=gstreams[g].cuda_stream) for g in range(G)] for slot in range(2)]
+    gargs = [dict(B=gb[g + 1] - gb[g], pose=sl(d_pose, g), ut=sl(d_ut, g), u0=sl(d_u0, g),
+                  mem_cols=sl(d_mem, g), n_mem=sl(d_nmem, g), stream=gstreams[g].cuda_stream) for g in range(G)]
 
-    def step(i):
-        slot = i & 1
-        if gather and works[slot] is not None:
-            works[slot].wait()  # the gather that read this slot two steps ago has finished
-        for a in gargs[slot]:
-            eng.control_batch(a["B"], a["pose"], a["ut"], a["u0"], mem_cols=a["mem_cols"], n_mem=a["n_mem"],
-                              mem_stride=args.n_mem, ck=a["ck"], stream=a["stream"])
-        if gather:
-            # RCCL all-gather of the per-agent c_k over xGMI; runs on the process group's
-            # stream and overlaps with the next step's kernel
-            for g in range(1, G):  # the gather reads every group's c_k
-                gevents[g].record(gstreams[g])
-                compute.wait_event(gevents[g])
-            works[slot] = all_gather(d_all[slot], d_ck[slot], async_op=True)
+    # ---- exchange plumbing -------------------------------------------------------------------------------
+    NB = 3  # c_k / consensus buffers in flight
+    d_ck = [torch.empty((B, K2), dtype=tdt, device="cuda") for _ in range(NB)]
+    d_cbar = [torch.zeros((K2,), dtype=tdt, device="cuda") for _ in range(NB)]
+    ev_ck = [torch.cuda.Event() for _ in range(NB)]
+    ev_x = [torch.cuda.Event() for _ in range(NB)]
+    comm = None
+    exchange_backend = "local (1 rank)"
+    if use_dist and not args.no_exchange or args.force_exchange:
+        if backend == "nccl" or not use_dist:
+            # the C ABI's own RCCL communicator: rank 0 creates the id, torch.distributed only carries it
+            uid = [capi.comm_unique_id() if rank == 0 else None]
+            if use_dist:
+                dist.broadcast_object_list(uid, src=0)
+            comm = capi.Comm(device, world, rank, uid[0])
+            exchange_backend = "rccl through the C ABI (eea_comm_*)"
+        else:
+            exchange_backend = "gloo, staged through the host (ranks share a GPU: plumbing run)"
+    if comm is None:
+        comm_local = capi.Comm(device, 1, 0, None)
+    d_all = None
 
-    def drain():
-        for w in works:
-            if w is not None:
-                w.wait()
+    def exchange_consensus(slot):
+        """c_bar of pass `slot`'s c_k over ALL agents of all ranks -> d_cbar[slot], on the exchange stream"""
+        xstream.wait_event(ev_ck[slot])
+        if comm is not None:
+            comm.consensus_ck(eng, B, d_ck[slot], d_cbar[slot], stream=xstream.cuda_stream)
+        elif use_dist:
+            with torch.cuda.stream(xstream):
+                sums = torch.cat([d_ck[slot].sum(0), torch.tensor([float(B)], dtype=tdt, device="cuda")]).cpu()
+            dist.all_reduce(sums)
+            with torch.cuda.stream(xstream):
+                d_cbar[slot].copy_((sums[:-1] / sums[-1]).cuda(), non_blocking=False)
+        else:
+            comm_local.consensus_ck(eng, B, d_ck[slot], d_cbar[slot], stream=xstream.cuda_stream)
+        ev_x[slot].record(xstream)
+
+    def exchange_allgather(slot):
+        xstream.wait_event(ev_ck[slot])
+        if comm is not None:
+            comm.allgather_ck(eng, B, d_ck[slot], d_all[slot % 2], stream=xstream.cuda_stream)
+        else:
+            with torch.cuda.stream(xstream):
+                h = d_ck[slot].cpu()
+            hall = torch.empty((world * B, K2), dtype=tdt)
+            dist.all_gather_into_tensor(hall, h)
+            with torch.cuda.stream(xstream):
+                d_all[slot % 2].copy_(hall)
+        ev_x[slot].record(xstream)
+
+    state = {"i": 0}
+
+    def one_pass(leg):
+        i = state["i"]
+        state["i"] = i + 1
+        slot = i % NB
+        if leg == "shard":
+            for a in gargs:
+                eng.control_batch(a["B"], a["pose"], a["ut"], a["u0"], mem_cols=a["mem_cols"], n_mem=a["n_mem"],
+                                  mem_stride=args.n_mem, stream=a["stream"])
+            return
+        shared = None
+        if leg == "consensus" and i >= args.consensus_lag:
+            src = (i - args.consensus_lag) % NB
+            compute.wait_event(ev_x[src])      # the consensus of pass i - lag has arrived
+            shared = d_cbar[src]
+        if leg == "allgather" and i >= 2:
+            compute.wait_event(ev_x[(i - 2) % NB])  # the gather that read this slot's predecessor is done
+        eng.control_batch(B, d_pose, d_ut, d_u0, mem_cols=d_mem, n_mem=d_nmem, mem_stride=args.n_mem,
+                          ck=d_ck[slot], ck_shared=shared, stream=compute.cuda_stream)
+        ev_ck[slot].record(compute)
+        if leg == "consensus":
+            exchange_consensus(slot)
+        else:
+            exchange_allgather(slot)
+
+    def timed(leg, steps, warmup):
+        """EXACTLY `steps` steps between barrier + synchronize on both sides; max over ranks"""
+        state["i"] = 0
+        d_ut.zero_()
+        for _ in range(warmup * R):
+            one_pass(leg)
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record(compute)
+        for _ in range(steps * R):
+            one_pass(leg)
+        ev1.record(compute)
+        enqueue_s = time.perf_counter() - t0
         torch.cuda.synchronize()  # all streams of the device
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        pass_ms = ev0.elapsed_time(ev1) / (steps * R)  # HIP events on the kernel's own stream
+        if use_dist:
+            t = torch.tensor([elapsed, pass_ms], dtype=torch.float64, device="cuda")
+            if backend == "nccl":
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            else:
+                th = t.cpu()
+                dist.all_reduce(th, op=dist.ReduceOp.MAX)
+                t = th
+            elapsed, pass_ms = float(t[0]), float(t[1])
+        return elapsed, pass_ms, enqueue_s
 
-    for i in range(args.warmup):
-        step(i)
-    drain()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record(compute)
-    for i in range(args.steps):
-        step(args.warmup + i)
-    ev1.record(compute)
-    enqueue_s = time.perf_counter() - t0  # host time to enqueue all steps (must stay below the device time)
-    drain()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the kernel's own stream
+    elapsed, pass_ms, enqueue_s = timed("shard", args.steps, args.warmup)
 
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        k = torch.tensor([kernel_ms], dtype=torch.float64, device="cuda")
-        dist.all_reduce(k, op=dist.ReduceOp.MAX)
-        kernel_ms = float(k.item())
+    exchange = None
+    if not args.no_exchange:
+        exchange = {"backend": exchange_backend, "consumer": "eea_batch_io::d_ck_shared (gradient uses c_bar)"}
+        e_s, p_ms, _ = timed("consensus", args.steps, args.warmup)
+        exchange["consensus_allreduce"] = {
+            "value": world * B * R * args.steps / e_s, "unit": "optimisations/s", "ms_per_step": 1e3 * e_s / args.steps,
+            "pass_ms": p_ms, "lag_passes": args.consensus_lag,
+            "bytes_per_rank_per_pass": rs * (K2 + 1),
+            "note": "every pass: eea_ck_sum + ncclAllReduce(K^2+1 reals) + divide on a second stream; pass i uses the "
+                    "consensus of pass i - lag"}
+        if use_dist or args.force_exchange:
+            d_all = [torch.empty((world * B, K2), dtype=tdt, device="cuda") for _ in range(2)]
+            e_s, p_ms, _ = timed("allgather", args.steps, args.warmup)
+            exchange["allgather_ck"] = {
+                "value": world * B * R * args.steps / e_s, "unit": "optimisations/s",
+                "ms_per_step": 1e3 * e_s / args.steps, "pass_ms": p_ms,
+                "bytes_received_per_rank_per_pass": rs * K2 * B * world,
+                "note": "every pass: one ncclAllGather of all agents' c_k (north_star's exchange); nothing on the "
+                        "control path consumes the gathered matrix -- the consensus leg is the consuming form"}
 
+    result_line = None
     if rank == 0:
         N = T + args.n_mem
         K = args.num_basis
-        total_opts = world * B * args.steps
-        value = total_opts / elapsed
-        # algorithmic HBM bytes per optimisation (DESIGN.md "Control kernel roofline"):
-        # pose in + ut in + ut out + u0 out + c_k out (+ memory columns in)
-        bytes_per_opt = rs * (3 + 3 * T + 3 * T + 3 + K2 + 3 * args.n_mem)
+        value = world * B * R * args.steps / elapsed
+        # algorithmic HBM bytes per optimisation (DESIGN.md "control kernel roofline"): pose in + ut in + ut out +
+        # u0 out (+ memory columns in); the shard leg writes no c_k (nothing consumes it there)
+        bytes_per_opt = rs * (3 + 3 * T + 3 * T + 3 + 3 * args.n_mem)
         flops_per_opt = 2 * K * K * N + 4 * K * K * T + (4 * K + 140) * T  # SURVEY.md 8(d) "W"
-        launch_s = kernel_ms * 1e-3
-        # per launch: with agent groups, the launches of group 0 (timed by the events on its stream)
-        Bl = bounds[1] - bounds[0]
+        launch_s = pass_ms * 1e-3
+        Bl = gb[1] - gb[0]   # agents per launch (group 0, whose stream carries the events)
         hbm_gbs = bytes_per_opt * Bl / launch_s / 1e9
         tflops = flops_per_opt * Bl / launch_s / 1e12
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_control_pmc.json")
-        if os.path.exists(pmc):
+        traffic, traffic_source = None, None
+        for name in ("r02_control_pmc.json", "r01_control_pmc.json"):
+            pmc = os.path.join(ROOT, "profiles", name)
+            if not os.path.exists(pmc):
+                continue
             try:
                 with open(pmc) as f:
                     rec = json.load(f)
-                if rec.get("agents") == Bl and rec.get("T") == T and rec.get("K") == K and rec.get("precision") == args.precision:
+                if (rec.get("agents") == Bl and rec.get("T") == T and rec.get("K") == K
+                        and rec.get("precision") == args.precision):
                     traffic = rec.get("hbm_bytes_per_launch")
+                    traffic_source = ("profiles/%s (separate rocprofv3 --pmc passes of this command; NOT measured "
+                                      "in this run)" % name)
+                    break
             except Exception:
-                traffic = None
-        host_us = 1e6 * enqueue_s / args.steps
+                pass
+        vpeak = VALU_F32_PEAK_TF if f32 else VALU_F64_PEAK_TF
         out = {
             "metric": "receding-horizon optimisations/sec at K=10x10, T=200; 1/2/4/8-GPU agent-batch",
             "value": value, "unit": "optimisations/s", "n_gpus": world, "steps": args.steps,
@@ -257,27 +448,32 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "BASELINE configs[3]: %d-agent batch per GPU, %s, two-Gaussian 12x6 m map, "
-                                   "K=%dx%d, T=%d steps (dt %.3g, horizon %.3g), n_mem=%d, c_k all-gather %s"
-                                   % (B, args.model, K, K, T, args.dt, args.horizon, args.n_mem,
-                                      "on" if gather else "off (1 GPU)"),
+                                   "K=%dx%d, T=%d steps (dt %.3g, horizon %.3g), n_mem=%d; pure agent shard "
+                                   "(no data-path collective)"
+                                   % (B, args.model, K, K, T, args.dt, args.horizon, args.n_mem),
                        "agents_per_gpu": B, "num_basis": K, "horizon_steps": T, "kinematics": args.model,
-                       "agent_groups": G,
-                       "parallelism": "agent-batch x%d" % world},
-            "host_enqueue_us_per_step": host_us,
-            "roofline": {"bound": "hbm", "kernel": "control_kernel", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_launch": bytes_per_opt * Bl, "launch_ms": kernel_ms,
-                         "agents_per_launch": Bl, "concurrent_launches": G},
-            "roofline_valu": {"bound": "valu-%s" % args.precision, "kernel": "control_kernel",
-                              "achieved": tflops, "peak": VALU_F32_PEAK_TF if f32 else VALU_F64_PEAK_TF,
-                              "unit": "TFLOP/s",
-                              "frac": tflops / (VALU_F32_PEAK_TF if f32 else VALU_F64_PEAK_TF),
-                              "flops_per_launch": flops_per_opt * Bl,
-                              "note": "the control kernel is vector-ALU/transcendental bound, not HBM bound "
-                                      "(SURVEY.md 8(d)); W = 2K^2N + 4K^2T + (4K+140)T flop per optimisation"},
+                       "passes_per_step": R, "optimisations_per_step": world * B * R,
+                       "agent_groups": G, "parallelism": "agent-batch x%d" % world,
+                       "dist_backend": backend if use_dist else None},
+            "timed_region_s": elapsed, "ms_per_pass": 1e3 * elapsed / (args.steps * R),
+            "host_enqueue_us_per_pass": 1e6 * enqueue_s / (args.steps * R),
+            "parity_tol": PARITY_TOL[args.precision],
+            "roofline": {"bound": "valu-%s" % args.precision, "kernel": "control kernel (one launch per pass)",
+                         "achieved": tflops, "peak": vpeak, "unit": "TFLOP/s", "frac": tflops / vpeak,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "flops_per_launch": flops_per_opt * Bl, "launch_ms": pass_ms, "agents_per_launch": Bl,
+                         "concurrent_launches": G,
+                         "note": "the control kernel is vector-ALU / transcendental bound, not HBM bound (SURVEY.md "
+                                 "8(d)); W = 2K^2N + 4K^2T + (4K+140)T flop per optimisation (reference formulation)"},
+            "roofline_hbm": {"bound": "hbm", "kernel": "control kernel", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS,
+                             "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                             "traffic_source": traffic_source, "bytes_per_launch": bytes_per_opt * Bl,
+                             "launch_ms": pass_ms},
         }
+        if exchange is not None:
+            out["exchange"] = exchange
         if world == 1 and args.cpu_seconds > 0:
-            one, allc = cpu_baseline(args, T, args.cpu_seconds)
+            one, allc = cpu_baseline(args, args.cpu_seconds)
             out["cpu_baseline"] = one
             out["cpu_baseline_all_cores"] = allc
         if world == 1 and not args.no_latency:
@@ -291,7 +487,14 @@ def main():
             lat = (time.perf_counter() - t0) / n
             out["latency_mode"] = {"value": 1.0 / lat, "unit": "optimisations/s", "us_per_call": 1e6 * lat,
                                    "note": "B = 1, dependent eea_control calls incl. host round trip"}
+        if world == 1 and not args.no_phik and not f32:
+            try:
+                out.update(phik_legs(args, torch, capi, np))
+            except Exception as exc:  # the headline line must not die with a secondary leg
+                out["roofline_phik"] = {"error": repr(exc)}
         result_line = json.dumps(out)
+    if comm is not None:
+        comm.close()
     eng.close()
     if use_dist:
         dist.destroy_process_group()

@@ -54,6 +54,18 @@ def consensus_ck(ck_all):
     return ck_all.mean(dim=0)
 
 
+def consensus_ck_allreduce(ck_local, group=None):
+    """The same consensus without gathering anything: each rank sums its own agents' c_k, ONE all-reduce of
+    K^2 + 1 reals (the agent count rides along) gives the global sum and count.  This is what
+    eea_comm_consensus_ck does on the device over RCCL; the result feeds eea_batch_io::d_ck_shared."""
+    import torch
+    import torch.distributed as dist
+    buf = torch.cat([ck_local.sum(dim=0), torch.tensor([float(ck_local.shape[0])], dtype=ck_local.dtype,
+                                                        device=ck_local.device)])
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=group)
+    return buf[:-1] / buf[-1]
+
+
 # ---- grid-tiled phi_k (BASELINE config 5): the target grid is sharded by rows ----------------
 def grid_row_tile(ny, rank, world):
     """Rows [row0, row0 + nrows) of the target grid owned by `rank`."""

@@ -759,6 +759,14 @@ static int dwa_search(const eo_dwa* d, const eo_collision* c, const eo_grid* g, 
   return eo_almost_equal(min_cost, DBL_MAX, 1.0e-12) ? 0 : 1;
 }
 
+/* cost of ONE candidate twist under the trajectory objective (:258-286): lets a test decide whether two
+ * different choices are a floating-point tie */
+double eo_dwa_objective_traj(const eo_dwa* d, const eo_collision* c, const eo_grid* g, const double x0[3],
+                             const double u[3], const double* xt_ref, unsigned n_ref, double dt_ref)
+{
+  return dwa_objective(d, c, g, x0, NULL, u, xt_ref, n_ref, (double)n_ref * dt_ref);
+}
+
 int eo_dwa_control_vref(const eo_dwa* d, const eo_collision* c, const eo_grid* g, const double x0[3],
                         const double vb[3], const double vref[3], double u_opt[3], double* min_cost)
 {

@@ -134,6 +134,10 @@ int eo_dwa_control_traj(const eo_dwa* d, const eo_collision* c, const eo_grid* g
                         const double vb[3], const double* xt_ref, unsigned n_ref, double dt_ref,
                         double u_opt[3], double* min_cost);
 
+/* objective(x0, u, xt_ref, dt_ref) of dynamic_window.cpp:258-286 for one candidate twist (DBL_MAX on collision) */
+double eo_dwa_objective_traj(const eo_dwa* d, const eo_collision* c, const eo_grid* g, const double x0[3],
+                             const double u[3], const double* xt_ref, unsigned n_ref, double dt_ref);
+
 /* ---- ergodic_control.hpp (ErgodicControl<ModelT>) ---------------------- */
 typedef struct eo_control eo_control;
 

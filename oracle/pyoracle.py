@@ -83,6 +83,7 @@ def lib():
         L.eo_control_steps.restype = C.c_uint
         L.eo_bench_control.restype = C.c_double
         L.eo_batch_control.restype = C.c_double
+        L.eo_dwa_objective_traj.restype = C.c_double
         L.eo_grid2rowmajor.restype = C.c_uint
         _lib = L
     return _lib
@@ -316,6 +317,16 @@ def dwa_control(dwa, coll, grid, x0, vb, vref=None, xt_ref=None, dt_ref=0.0):
         ok = lib().eo_dwa_control_traj(C.byref(d), C.byref(c), C.byref(grid.g), _p(x0), _p(vb), _p(xr),
                                        C.c_uint(xr.shape[0]), C.c_double(dt_ref), _p(u), C.byref(cost))
     return bool(ok), u, cost.value
+
+
+def dwa_objective_traj(dwa, coll, grid, x0, u, xt_ref, dt_ref):
+    """trajectory-distance cost of one candidate twist (dynamic_window.cpp:258-286)"""
+    d = Dwa(*dwa)
+    c = Collision(*[float(v) for v in coll])
+    x0, u = _d(x0), _d(u)
+    xr = _d(np.asarray(xt_ref).T)
+    return float(lib().eo_dwa_objective_traj(C.byref(d), C.byref(c), C.byref(grid.g), _p(x0), _p(u), _p(xr),
+                                             C.c_uint(xr.shape[0]), C.c_double(dt_ref)))
 
 
 def make_config(model, dt, horizon, resolution, expl_weight, num_basis, Rinv, umin, umax):

@@ -59,6 +59,9 @@ def _worker(rank, world, port, n_agents, ragged, q):
         work.wait()
         assert torch.equal(out2, ck_all)
     mean = ab.consensus_ck(ck_all)
+    # the consensus without the gather: one all-reduce of K^2 + 1 reals (unequal shards included)
+    mean2 = ab.consensus_ck_allreduce(ck_local)
+    assert torch.allclose(mean2, mean, rtol=0, atol=1e-15)
     if rank == 0:
         q.put((ck_all.numpy(), mean.numpy()))
     dist.barrier()

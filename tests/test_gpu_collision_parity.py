@@ -46,9 +46,30 @@ def test_collision_check_bit_exact():
     got = d_hit.cpu().numpy()
     assert np.array_equal(got, ref), np.nonzero(got != ref)[0][:10]
     assert 0 < ref.sum() < P
-    # robot centred inside the small obstacle block reports NO collision (ring search skips r < r_bnd)
-    centre = [po.collision_check(COLL, g, [1.0 + 0.25, -2.0 + 1.15, 0.0])[0]]
-    assert centre == [False] or centre == [True]  # documented behaviour, value pinned by the oracle
+
+
+def test_robot_centred_in_small_obstacle_reports_no_collision():
+    """cells closer than r_bnd = floor(0.7 / res) = 6 are never visited, so a robot
+    centred in an obstacle smaller than that ring reports NO collision -- reproduced, not fixed.  A larger
+    block (reaching the r_bnd ring) is a collision; both implementations of the lookup agree."""
+    xs, ys, res, xmin, ymin = 60, 60, 0.1, 0.0, 0.0
+    small = np.zeros((ys, xs), dtype=np.int8)
+    small[28:33, 28:33] = 100           # 5 x 5 cells around cell (30, 30): all within 2 cells of the centre
+    large = np.zeros((ys, xs), dtype=np.int8)
+    large[22:39, 22:39] = 100           # 17 x 17 cells: reaches the rings r = 6..8
+    pose = np.array([[3.05, 3.05, 0.0], [3.05, 3.05, 1.0], [4.05, 3.05, 0.0]])  # centre, centre, 1 m to the side
+    cfg = capi.make_collision_cfg(xmin, ymin, res, xs, ys, *COLL)
+    expect = {"small": [0, 0, 0], "large": [1, 1, 1]}
+    # 1 m to the side of the small block: its nearest cells are 7..8 cells away = inside r_col = 9 -> collision
+    expect["small"][2] = 1
+    for name, data in (("small", small), ("large", large)):
+        g = po.GridMap(xmin, xmin + xs * res, ymin, ymin + ys * res, res, data.reshape(-1))
+        ref = [int(po.collision_check(COLL, g, p)[0]) for p in pose]
+        assert ref == expect[name], (name, ref)
+        d_hit = torch.full((len(pose),), -1, dtype=torch.int32, device="cuda")
+        capi.collision_check_batch(cfg, torch.as_tensor(data).cuda(), torch.as_tensor(pose).cuda(), d_hit)
+        torch.cuda.synchronize()
+        assert d_hit.cpu().tolist() == expect[name], (name, d_hit.cpu().tolist())
 
 
 def test_validate_control_matches_oracle():

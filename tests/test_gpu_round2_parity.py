@@ -1,0 +1,244 @@
+"""GPU parity cases added in round 2 (all through the C ABI, checker = the CPU oracle):
+
+* the decentralised-consensus input (eea_batch_io::d_ck_shared) against the oracle's shared-c_k switch;
+* the exchange entry points (eea_ck_sum, eea_comm_*) on a single-rank RCCL communicator;
+* BASELINE config 4 at FULL size: 4096 agents, K = 10, T = 200, u0 and the whole warm-start matrix ut
+  against the oracle run on every host thread;
+* BASELINE config 5 END TO END: 1024 x 1024 seed-2024 occupancy grid -> eea_set_target_occupancy -> K = 30,
+  T = 500 control on the 102.4 m domain, phi_k and two consecutive control calls against the oracle;
+* `python bench.py --gpus 2` started the way the driver starts it (no launcher around it).
+
+Tolerances: c_k, phi_k <= 1e-11; trajectory / co-state / controls <= 1e-9.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import pyoracle as po
+from ergodic_exploration_amd import capi
+from tests.gpu_util import MAP_BOUNDS, MEANS, SIGMAS, MODELS, angle_diff, make_pair, random_poses
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOL_CK = 1e-11
+TOL = 1e-9
+
+
+def dev(a, dtype=torch.float64):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).cuda()
+
+
+@pytest.mark.parametrize("model,K,horizon,n_mem", [("simple_cart", 10, 20.0, 0), ("omni", 10, 5.0, 7),
+                                                   ("omni", 7, 3.0, 0), ("omni", 20, 5.0, 0)])
+def test_consensus_shared_ck_against_oracle(model, K, horizon, n_mem):
+    """d_ck_shared replaces the agent's own c_k in fourier_diff (ergodic_control.hpp:422); the own c_k is
+    still what d_ck receives.  c_bar = mean of the agents' c_k of the previous call, as bench.py feeds it."""
+    rng = np.random.default_rng(42)
+    B = 5
+    eng, ors = make_pair(model, K, horizon, n_oracles=B)
+    T, K2 = eng.T, eng.K2
+    poses = random_poses(rng, B)
+    ut0 = rng.uniform(-0.5, 0.5, (B, T, 3))
+    if model == "simple_cart":
+        ut0[:, :, 1] = 0.0
+    mem = random_poses(rng, B * n_mem).reshape(B, n_mem, 3) if n_mem else None
+    d_pose, d_ut = dev(poses), dev(ut0)
+    d_u0 = torch.empty((B, 3), dtype=torch.float64, device="cuda")
+    d_ck = torch.empty((B, K2), dtype=torch.float64, device="cuda")
+    outs = {k: torch.empty((B, T, 3), dtype=torch.float64, device="cuda") for k in ("edx", "rhot")}
+    d_mem = dev(mem) if n_mem else None
+    d_nmem = torch.full((B,), n_mem, dtype=torch.int32, device="cuda") if n_mem else None
+    sums = torch.empty((K2 + 1,), dtype=torch.float64, device="cuda")
+    d_cbar = torch.empty((K2,), dtype=torch.float64, device="cuda")
+    comm = capi.Comm(0, 1, 0, None)
+    for b in range(B):
+        ors[b].ut = ut0[b].T
+    cbar = None
+    for call in range(3):
+        eng.control_batch(B, d_pose, d_ut, d_u0, mem_cols=d_mem, n_mem=d_nmem, mem_stride=n_mem, ck=d_ck,
+                          ck_shared=(d_cbar if cbar is not None else None), **outs)
+        torch.cuda.synchronize()
+        ck = d_ck.cpu().numpy()
+        for b in range(B):
+            ors[b].set_shared_ck(cbar)
+            u, st = ors[b].control(MAP_BOUNDS, poses[b], mem[b].T if n_mem else None, stages=True)
+            assert np.abs(ck[b] - st["ck"]).max() <= TOL_CK          # own c_k, unaffected by the switch
+            assert np.abs(outs["edx"][b].cpu().numpy().T - st["edx"]).max() <= TOL
+            assert np.abs(outs["rhot"][b].cpu().numpy().T - st["rhot"]).max() <= TOL
+            assert np.abs(d_ut[b].cpu().numpy().T - st["ut"]).max() <= TOL
+            assert np.abs(d_u0[b].cpu().numpy() - u).max() <= TOL
+            ors[b].ut = d_ut[b].cpu().numpy().T
+        # consensus of this call's c_k through the exchange entry points (local communicator)
+        eng.ck_sum(B, d_ck, sums)
+        comm.consensus_ck(eng, B, d_ck, d_cbar)
+        torch.cuda.synchronize()
+        s = sums.cpu().numpy()
+        assert s[K2] == B and np.abs(s[:K2] - ck.sum(0)).max() < 1e-13
+        cbar = d_cbar.cpu().numpy()
+        assert np.abs(cbar - ck.mean(0)).max() < 1e-14
+    # with the consensus equal to the own c_k the result is the reference behaviour again
+    eng.close()
+    comm.close()
+
+
+def test_exchange_steps_on_single_rank_rccl():
+    """eea_comm_* with a real RCCL communicator of one rank (all a 1-GPU box can hold): the all-gather
+    returns the rank's c_k, the all-reduce leaves sums unchanged, the consensus is the local mean."""
+    eng, _ = make_pair("omni", 10, 2.0, n_oracles=0)
+    K2, B = eng.K2, 37
+    rng = np.random.default_rng(3)
+    ck = dev(rng.normal(size=(B, K2)))
+    comm = capi.Comm(0, 1, 0, capi.comm_unique_id())
+    allc = torch.zeros((B, K2), dtype=torch.float64, device="cuda")
+    cbar = torch.zeros((K2,), dtype=torch.float64, device="cuda")
+    buf = ck[0].clone()
+    s = torch.cuda.Stream()
+    comm.allgather_ck(eng, B, ck, allc, stream=s.cuda_stream)
+    comm.consensus_ck(eng, B, ck, cbar, stream=s.cuda_stream)
+    comm.allreduce_sum(eng, buf, K2, stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    assert torch.equal(allc, ck)
+    assert torch.equal(buf, ck[0])
+    assert np.abs(cbar.cpu().numpy() - ck.cpu().numpy().mean(0)).max() < 1e-14
+    # fp32 engine: same entry points on float buffers
+    e32, _ = make_pair("omni", 10, 2.0, n_oracles=0, precision=capi.PREC_F32)
+    ck32 = ck.float()
+    cbar32 = torch.zeros((K2,), dtype=torch.float32, device="cuda")
+    comm.consensus_ck(e32, B, ck32, cbar32)
+    torch.cuda.synchronize()
+    assert np.abs(cbar32.cpu().numpy() - ck32.cpu().numpy().astype(np.float64).mean(0)).max() < 1e-5
+    comm.close()
+    eng.close()
+    e32.close()
+
+
+@pytest.mark.parametrize("model", ["simple_cart", "omni"])
+def test_config4_full_size_against_oracle(model):
+    """BASELINE config 4 at full size: every one of the 4096 agents' u0 and warm-start matrix ut after two
+    control() calls from a zero warm start against independent oracle controllers (one per host thread)."""
+    B, K, horizon, dt = 4096, 10, 20.0, 0.1
+    om, em, rdiag, lim = MODELS[model]
+    eng, _ = make_pair(model, K, horizon, n_oracles=0)
+    T = eng.T
+    rng = np.random.default_rng(12345)
+    poses = random_poses(rng, B)
+    d_pose = dev(poses)
+    d_ut = torch.zeros((B, T, 3), dtype=torch.float64, device="cuda")
+    d_u0 = torch.empty((B, 3), dtype=torch.float64, device="cuda")
+    limv = np.array(lim)
+    cfg = po.make_config(om, dt, horizon, 0.1, 1.0, K, np.diag(rdiag), -limv, limv)
+    threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    worst = []
+    for calls in (1, 2):
+        eng.control_batch(B, d_pose, d_ut, d_u0)
+        torch.cuda.synchronize()
+        # the helper runs one warm-up call + (calls - 1) further calls == `calls` control() calls per agent
+        u_ref, ut_ref = po.batch_control(cfg, MEANS, SIGMAS, MAP_BOUNDS, poses, calls - 1, min(threads, 64))
+        ut = d_ut.cpu().numpy()
+        dut = np.abs(ut - ut_ref).max()
+        du = np.abs(d_u0.cpu().numpy() - ut_ref[:, 0, :]).max()
+        worst.append((du, dut))
+        if calls > 1:
+            assert np.abs(d_u0.cpu().numpy() - u_ref).max() == du
+    if os.environ.get("EEA_PRINT_WORST"):
+        print("config 4 full size", model, worst)
+    # first call: the single-call bar; second (dependent) call starts from controls that already differ
+    assert worst[0][0] <= TOL and worst[0][1] <= TOL, worst
+    assert worst[1][0] <= 10 * TOL and worst[1][1] <= 10 * TOL, worst
+    eng.close()
+
+
+def _occupancy_seed2024(n=1024, block=32):
+    """70 % free (0), 10 % occupied (100), 20 % unknown (-1) in 32 x 32 blocks"""
+    rng = np.random.default_rng(2024)
+    nb = n // block
+    r = rng.random((nb, nb))
+    cells = np.where(r < 0.7, 0, np.where(r < 0.8, 100, -1)).astype(np.int8)
+    return np.ascontiguousarray(np.kron(cells, np.ones((block, block), dtype=np.int8)))
+
+
+def test_config5_end_to_end_against_oracle():
+    """1024 x 1024 occupancy -> entropy target -> phi_k (K = 30) -> control (T = 500) on the 102.4 m domain.
+    phi_k at full size against eo_spatial_coeff (non-separated, ~1.9e9 cos calls: about half a minute), then
+    4 agents x 2 consecutive control() calls stage by stage."""
+    nx = ny = 1024
+    res, lx, ly, K = 0.1, 102.4, 102.4, 30
+    occ = _occupancy_seed2024(nx)
+    lut = np.array([po.lib().eo_entropy(float(np.int8(np.uint8(b))) / 100.0) for b in range(256)])
+    ent = lut[occ.reshape(-1).view(np.uint8)]
+    phi_vals = ent / ent.sum()
+    bounds = (0.0, lx, 0.0, ly)
+    lim = np.array([1.0, 1.0, 2.0])
+    Rinv = np.diag([1.0, 1.0, 2.0])
+    B, horizon, dt = 4, 50.0, 0.1
+    eng = capi.Engine(capi.make_config(capi.MODEL_OMNI, dt, horizon, res, 1.0, K, Rinv, -lim, lim))
+    eng.set_target_occupancy(nx, ny, torch.as_tensor(occ).cuda(), lx, ly)
+    assert not eng.config_domain(bounds)       # same extent: no rebuild, only map_pos is refreshed
+    ors = []
+    for b in range(B):
+        o = po.ErgodicControl(po.MODEL_OMNI, dt, horizon, res, 1.0, K, Rinv, -lim, lim)
+        if b == 0:
+            o.set_target_grid(nx, ny, phi_vals, lx, ly)   # the expensive one
+            phik_ref = o.phik
+        ors.append(o)
+    assert np.abs(eng.phik() - phik_ref).max() <= 1e-11
+    for o in ors[1:]:  # identical target: share the oracle's phi_k instead of recomputing it three times
+        o.set_target_grid(1, 1, np.zeros(1), lx, ly)      # sets lx, ly (phi_k of a one-point zero grid) ...
+        np.ctypeslib.as_array(po.lib().eo_control_phik(o.h), (K * K,))[:] = phik_ref  # ... then the real one
+    T, K2 = eng.T, eng.K2
+    assert T == 500
+    rng = np.random.default_rng(5)
+    poses = random_poses(rng, B, bounds)
+    ut0 = rng.uniform(-0.5, 0.5, (B, T, 3))
+    d_pose, d_ut = dev(poses), dev(ut0)
+    d_u0 = torch.empty((B, 3), dtype=torch.float64, device="cuda")
+    d_ck = torch.empty((B, K2), dtype=torch.float64, device="cuda")
+    outs = {k: torch.empty((B, T, 3), dtype=torch.float64, device="cuda") for k in ("traj", "edx", "bdx", "rhot")}
+    for b in range(B):
+        ors[b].ut = ut0[b].T
+    for call in range(2):
+        eng.control_batch(B, d_pose, d_ut, d_u0, ck=d_ck, **outs)
+        torch.cuda.synchronize()
+        for b in range(B):
+            u, st = ors[b].control(bounds, poses[b], None, stages=True)
+            g = {k: v[b].cpu().numpy().T for k, v in outs.items()}
+            assert np.abs(g["traj"][:2] - st["traj"][:2]).max() <= TOL
+            assert np.abs(angle_diff(g["traj"][2], st["traj"][2])).max() <= TOL
+            assert np.abs(d_ck[b].cpu().numpy() - st["ck"]).max() <= TOL_CK
+            for k in ("edx", "bdx", "rhot"):
+                assert np.abs(g[k] - st[k]).max() <= TOL, (k, call, b)
+            assert np.abs(d_ut[b].cpu().numpy().T - st["ut"]).max() <= TOL
+            assert np.abs(d_u0[b].cpu().numpy() - u).max() <= TOL
+            ors[b].ut = d_ut[b].cpu().numpy().T
+    eng.close()
+
+
+@pytest.mark.parametrize("extra", [["--no-exchange"], []])
+def test_bench_self_launches_its_ranks(extra):
+    """`python bench.py --gpus 2` exactly as the driver would type it for N > 1 without a launcher: the
+    parent makes no GPU call and starts the two ranks itself; on this 1-GPU box the ranks share the device
+    (gloo rendezvous, host-staged exchange).  One JSON line, n_gpus = 2, rc 0."""
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--passes-per-step", "3", "--agents", "256"] + extra
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    assert rec["config"]["optimisations_per_step"] == 2 * 256 * 3
+    if extra:
+        assert "exchange" not in rec
+    else:
+        assert rec["exchange"]["consensus_allreduce"]["value"] > 0
+        assert rec["exchange"]["allgather_ck"]["value"] > 0
