@@ -63,6 +63,14 @@ template <typename R>
 hipError_t launch_control(const ControlParams<R>& p, unsigned B, int model, int n_mem_max,
                           bool rollout_only, hipStream_t stream);
 
+// Wavefront-per-agent control kernel (control_wave_impl.hpp): horizons of at most 256 steps, K <= 16.
+// launch_control_wave needs control_wave_eligible.
+template <typename R>
+bool control_wave_eligible(const ControlParams<R>& p, bool rollout_only);
+template <typename R>
+hipError_t launch_control_wave(const ControlParams<R>& p, unsigned B, int model, bool rollout_only,
+                               hipStream_t stream);
+
 #ifdef EEA_AB_BUILD
 // A/B library only (tools/ab/): diagnostic instantiation (K = 10, fp64) that records per-phase shader-clock
 // stamps into p.dbg, and the first version of the control kernel

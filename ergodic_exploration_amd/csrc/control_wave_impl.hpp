@@ -1,0 +1,611 @@
+// Fused receding-horizon ergodic control kernel for gfx950 (MI355X), version 3: ONE WAVEFRONT PER AGENT.
+//
+// Same computation as control_kernel_impl.hpp -- one complete `ErgodicControl<ModelT>::control` call
+// (reference ergodic_control.hpp:224-311 minus configTarget) per agent, for ModelT in {Omni, SimpleCart} --
+// and the same three identities (separable basis, RK4 == Simpson as two prefix sums, co-state as two chained
+// suffix sums).  What changes is the mapping onto the machine:
+//
+//   * an agent is one 64-lane wavefront; lane l owns the S = ceil(T / 64) consecutive horizon steps
+//     S*l .. S*l + S - 1 (S <= 4, i.e. T <= 256).  No workgroup barrier exists anywhere in the kernel, no
+//     cross-wavefront exchange, no partial-sum reduction: the six horizon scans are a serial prefix over the
+//     lane's own steps plus ONE DPP wavefront scan of the lane totals (instead of one DPP scan per wavefront
+//     and an LDS hop between four of them);
+//   * the S steps of a lane are independent instruction streams: the fp64 sin/cos polynomials and the
+//     gradient's multiply-add chains of different steps interleave, so one wavefront keeps the vector pipe
+//     busy where the one-step-per-lane kernel waited on its own dependency chains;
+//   * c_k = (1/N) Cx Cy^T on the matrix cores, fed through a wavefront-private LDS tile of 32 points
+//     [point][k]: the accumulator of v_mfma_f64_16x16x4_f64 already holds the COMPLETE sums of the agent, so
+//     D = lambda (c - phi) is formed in registers and written once (both orientations) for the gradient;
+//   * cos(k a), sin(k a) by the Chebyshev three-term recurrences (T_{k+1} = 2c T_k - T_{k-1}, sin(k a) =
+//     sin(a) U_{k-1}): one multiply-add per table entry instead of the four of the rotation recurrence;
+//   * the gradient makes two passes over D (rows of D and of D^T from LDS, wavefront-uniform broadcast reads)
+//     with a K-entry cosine array of ONE step in registers at a time: 128 registers, 4 wavefronts per SIMD,
+//     9.3 KB of LDS per agent -- the 4096-agent batch is resident on the 1024 SIMDs in one round.
+//
+// Steps beyond 256 and bases beyond K = 16 stay on the workgroup-per-agent kernel
+// (control_kernel_impl.hpp); the engine picks.  rollout_only (optTraj / path) stops after the forward half,
+// so a rollout and the trajectory a control call reports are bitwise the same function of (pose, controls).
+#pragma once
+
+#include "common.hpp"
+
+namespace eea
+{
+namespace wave
+{
+constexpr int kMaxS = 4;        // steps per lane
+constexpr int kStageRows = 32;  // points staged per matrix-core pass (8 MFMAs)
+
+__host__ __device__ constexpr int tab_stride(int K) { return (K + 1) & ~1; }  // even: 16-byte rows
+// LDS carve per wavefront, in elements: heading park [2][kMaxS][64], tiles x / y (32 rows each) + the pad
+// the last rows' operand reads run into; D and D^T alias the tiles (written after the last operand read)
+__host__ __device__ constexpr int park_elems() { return 2 * kMaxS * kWave; }
+__host__ __device__ constexpr int tile_elems(int K)
+{
+  const int t = 2 * kStageRows * tab_stride(K) + 16;
+  const int d = 2 * (K * K + 1);
+  return ((t > d ? t : d) + 3) & ~3;
+}
+__host__ __device__ constexpr int wave_lds_elems(int K) { return park_elems() + tile_elems(K); }
+
+// orders this wavefront's own LDS writes before its own LDS reads (DS operations of one wavefront execute in
+// order; this stops the compiler from moving them across)
+__device__ __forceinline__ void lds_fence()
+{
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <typename R>
+__device__ __forceinline__ R read_lane63(R v);
+template <>
+__device__ __forceinline__ double read_lane63<double>(double v)
+{
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+  return __hiloint2double(hi, lo);
+}
+template <>
+__device__ __forceinline__ float read_lane63<float>(float v)
+{
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// acc + k * v for a small mode number k: fp64 takes the constant from a scalar register pair
+template <typename R>
+__device__ __forceinline__ R fma_k(R v, int k, R acc)
+{
+  return acc + static_cast<R>(k) * v;
+}
+template <>
+__device__ __forceinline__ double fma_k<double>(double v, int k, double acc)
+{
+  double d;
+  asm("v_fma_f64 %0, %1, %3, %2" : "=v"(d) : "v"(v), "v"(acc), "s"(static_cast<double>(k)));
+  return d;
+}
+
+template <typename R, int MODEL>
+__device__ __forceinline__ void model_xy(R vx, R vy, R c, R s, R& fx, R& fy)
+{
+  if (MODEL == kModelOmni) {  // omni.hpp:177-181
+    fx = vx * c - vy * s;
+    fy = vx * s + vy * c;
+  } else {  // cart.hpp:172
+    fx = vx * c;
+    fy = vx * s;
+  }
+}
+
+template <typename R>
+__device__ __forceinline__ R wrap_pi_fast(R rad)
+{
+  // normalize_angle_PI (numerics.hpp:78-90) with the quotient taken by a multiplication; a quotient off by
+  // one at an exact multiple is repaired by the two range fixes
+  const R pi = static_cast<R>(kPi), two_pi = static_cast<R>(2.0 * kPi);
+  const R q = floor((rad + pi) * static_cast<R>(1.0 / (2.0 * kPi)));
+  rad = (rad + pi) - q * two_pi;
+  if (rad < R(0)) rad += two_pi;
+  if (rad >= two_pi) rad -= two_pi;
+  return rad - pi;
+}
+
+// waves per SIMD the kernel is compiled for: 4 (128 registers) for the exact-K instances
+constexpr int waves_per_simd(int KC) { return KC <= 10 ? 4 : 3; }
+
+// KC: compile-time K (5, 10) or 16 = any K <= 16 at run time (loops unrolled to 16, guarded).
+// STAGES: the optional per-stage outputs (traj, edx, bdx, rhot) are compiled in.
+// WPB: wavefronts (= agents) per workgroup; they share nothing.
+template <typename R, int MODEL, int KC, bool STAGES, int WPB>
+__global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_kernel(
+    const ControlParams<R> p, const unsigned B, const int S, const int rollout_only)
+{
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const unsigned b = blockIdx.x * WPB + wv;
+  if (b >= B) return;  // wavefront-uniform
+
+  const int T = p.T;
+  const int K = (KC == 16) ? p.K : KC;
+  const int K2 = K * K;
+  constexpr int KS = (KC == 16) ? 16 : tab_stride(KC);
+
+  R* const sm = reinterpret_cast<R*>(smem_raw) + static_cast<size_t>(wv) * wave_lds_elems(KC == 16 ? 16 : KC);
+  R* const s_cp = sm;                       // cos of the post-step heading, [j][lane]
+  R* const s_sp = sm + kMaxS * kWave;       // sin
+  R* const tabx = sm + park_elems();        // [32 rows][KS]
+  R* const taby = tabx + kStageRows * KS;
+  R* const s_D = tabx;                      // D[k2 * K + k1]   (after the contraction)
+  R* const s_DT = tabx + ((K2 + 1) & ~1);   // D^T[k1 * K + k2]
+
+  const int i0 = S * lane;  // first horizon step of this lane
+  const R* const pose = p.pose + 3 * static_cast<size_t>(b);
+  R* const ut = p.ut + 3 * static_cast<size_t>(T) * b;
+
+  // ---- controls: shift left by one column, last column zero (ergodic_control.hpp:233-234) ------------
+  R vx[kMaxS], vy[kMaxS], w[kMaxS];
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < kMaxS; ++j) {
+    vx[j] = vy[j] = w[j] = R(0);
+    if (j < S) {
+      const int src = rollout_only ? i0 + j : i0 + j + 1;  // optTraj rolls the controls out as they are
+      if (src < T) {
+        vx[j] = ut[3 * src + 0];
+        vy[j] = ut[3 * src + 1];
+        w[j] = ut[3 * src + 2];
+      }
+      // SimpleCart::operator() rejects a lateral velocity (cart.hpp:167-170)
+      if (MODEL == kModelSimpleCart && i0 + j < T && !(fabs(vy[j]) < R(1.0e-12))) bad = true;
+    }
+  }
+  const R x0 = pose[0], y0 = pose[1], th0 = pose[2];
+  if (__any(bad)) {
+    // the reference throws out of rk4_.solve; nothing else of this agent is touched
+    if (lane == 0 && p.status != nullptr) p.status[b] = 2;  // EEA_ERR_INVALID_TWIST
+    if (lane == 0 && p.done != nullptr && b == 0) {
+      __hip_atomic_store(p.done, p.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    return;
+  }
+  if (lane == 0 && p.status != nullptr) p.status[b] = 0;
+
+  const R dt = p.dt, dt6 = p.dt6;
+  const R inv_pi = static_cast<R>(1.0 / kPi);
+
+  // ================= forward half ========================================================================
+  // heading: theta_i = wrap(theta_{i-1} + dt/6 (w + 2w + 2w + w)) (integrator.hpp:146-148,183)
+  //          == wrap(theta_0 + prefix sum) up to rounding
+  R thp[kMaxS];  // inclusive prefix of the heading increments within the lane
+  {
+    R run = R(0);
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      const R d = dt6 * (((w[j] + R(2) * w[j]) + R(2) * w[j]) + w[j]);
+      run += (j < S) ? d : R(0);
+      thp[j] = run;
+    }
+    const R incl = wave_inclusive_scan_dpp(run);
+    const R base = wrap_pi_fast(th0) + (incl - run);  // heading before the lane's first step
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) thp[j] += base;   // heading after step j
+  }
+
+  // position: x_i = x_{i-1} + dt/6 (k1 + 2 k2 + 2 k3 + k4) with k2 == k3 (integrator.hpp:176-184).
+  // sin/cos of the pre-step heading is evaluated for the lane's first step only; the later ones are the
+  // previous step's post-step values (2 mid - pre by the double-angle / addition formulas, ~4e-16 each)
+  R px[kMaxS], py[kMaxS];  // inclusive prefix of the position increments within the lane
+  {
+    R c, s;
+    {
+      const R th_pre0 = thp[0] - dt6 * (((w[0] + R(2) * w[0]) + R(2) * w[0]) + w[0]);
+      sincospi_r(th_pre0 * inv_pi, &s, &c);
+    }
+    R rx = R(0), ry = R(0);
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      if (j < S) {
+        // mid stage theta + dt (0.5 w), shared by k2 and k3 (integrator.hpp:179-180)
+        const R th_pre = (j == 0) ? thp[0] - dt6 * (((w[0] + R(2) * w[0]) + R(2) * w[0]) + w[0]) : thp[j - 1];
+        R sm_, cm;
+        sincospi_r((th_pre + dt * (R(0.5) * w[j])) * inv_pi, &sm_, &cm);
+        const R c2m = R(1) - R(2) * sm_ * sm_, s2m = R(2) * sm_ * cm;
+        const R cpost = c2m * c + s2m * s, spost = s2m * c - c2m * s;
+        R k1x, k1y, k2x, k2y, k4x, k4y;
+        model_xy<R, MODEL>(vx[j], vy[j], c, s, k1x, k1y);
+        model_xy<R, MODEL>(vx[j], vy[j], cm, sm_, k2x, k2y);
+        model_xy<R, MODEL>(vx[j], vy[j], cpost, spost, k4x, k4y);
+        const bool act = i0 + j < T;
+        rx += act ? dt6 * (((k1x + R(2) * k2x) + R(2) * k2x) + k4x) : R(0);
+        ry += act ? dt6 * (((k1y + R(2) * k2y) + R(2) * k2y) + k4y) : R(0);
+        // parked for the backward half: heading after step j (A = fdx(x_j, u_j), B = fdu(x_j))
+        s_cp[j * kWave + lane] = cpost;
+        s_sp[j * kWave + lane] = spost;
+        c = cpost;
+        s = spost;
+      }
+      px[j] = rx;
+      py[j] = ry;
+    }
+    const R ix = wave_inclusive_scan_dpp(rx), iy = wave_inclusive_scan_dpp(ry);
+    const R bx = x0 + (ix - rx), by = y0 + (iy - ry);
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      px[j] += bx;
+      py[j] += by;
+    }
+  }
+  if (STAGES && p.traj != nullptr) {
+    R* const traj = p.traj + 3 * static_cast<size_t>(T) * b;
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      if (j < S && i0 + j < T) {
+        traj[3 * (i0 + j) + 0] = px[j];
+        traj[3 * (i0 + j) + 1] = py[j];
+        traj[3 * (i0 + j) + 2] = wrap_pi_fast(thp[j]);
+      }
+    }
+  }
+
+  if (STAGES && rollout_only) return;  // optTraj / path (ergodic_control.hpp:313-342): the rollout is all
+
+  // basis angles of the rollout points (map frame -> Fourier frame, ergodic_control.hpp:243-244; one sin/cos
+  // pair per axis: angle = pi x / lx, basis.cpp:85 with k = 1) and the barrier gradient (:453-474)
+  R c1x[kMaxS], s1x[kMaxS], c1y[kMaxS], s1y[kMaxS], g0[kMaxS], g1[kMaxS];
+#pragma unroll
+  for (int j = 0; j < kMaxS; ++j) {
+    c1x[j] = s1x[j] = c1y[j] = s1y[j] = g0[j] = g1[j] = R(0);
+    if (j < S) {
+      const R x = px[j] - p.map_x, y = py[j] - p.map_y;
+      sincospi_r(x * p.inv_lx, &s1x[j], &c1x[j]);
+      sincospi_r(y * p.inv_ly, &s1y[j], &c1y[j]);
+      const R eps = R(0.05), weight = R(25);
+      R b0 = R(0), b1 = R(0);
+      b0 += R(2) * static_cast<R>(x > p.lx - eps) * (x - (p.lx - eps));
+      b1 += R(2) * static_cast<R>(y > p.ly - eps) * (y - (p.ly - eps));
+      b0 += R(2) * static_cast<R>(x < eps) * (x - eps);
+      b1 += R(2) * static_cast<R>(y < eps) * (y - eps);
+      g0[j] = b0 * weight;
+      g1[j] = b1 * weight;
+    }
+  }
+
+  // ---- c_k = (1/N) sum_p cos(a_k1 x_p) cos(b_k2 y_p)  (basis.cpp:109-120) on the matrix cores -----------
+  // sampled past states are prepended (buffer.cpp:78-108) and shifted like the rollout
+  int nmem = 0;
+  if (p.mem_cols != nullptr) {
+    nmem = (p.n_mem != nullptr) ? p.n_mem[b] : static_cast<int>(p.mem_stride);
+    nmem = nmem < 0 ? 0 : (nmem > static_cast<int>(p.mem_stride) ? static_cast<int>(p.mem_stride) : nmem);
+  }
+  const int N = T + nmem;
+  using M = Mfma<R>;
+  using acc_t = typename M::acc_t;
+  acc_t acc0 = acc_t{ R(0), R(0), R(0), R(0) }, acc1 = acc0;
+  const int mk = lane >> 4, mi = lane & 15;  // matrix-instruction operand coordinates of this lane
+  // lambda_k, phi_k of this lane's accumulator entries (mode = k2 * K + k1, k2 = mi, k1 = the accumulator row
+  // of register r): issued now, consumed after the contraction
+  R lam[4], phi[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int k1 = M::row(lane, r);
+    const bool ok = k1 < K && mi < K;
+    lam[r] = ok ? p.lamdak[mi * K + k1] : R(0);
+    phi[r] = ok ? p.phik[mi * K + k1] : R(0);
+  }
+
+  // one half pass: the 32 lanes [32 h, 32 h + 32) stage the cos tables of one point each (zero rows for
+  // invalid points), then up to 8 matrix instructions consume 4 rows each
+  auto stage_and_mma = [&](R ca, R cb, bool valid, int h, int rows_valid) {
+    if ((lane >> 5) == h) {
+      R* const tx = tabx + (lane & 31) * KS;
+      R* const ty = taby + (lane & 31) * KS;
+      // Chebyshev: cos(k a) = T_k(cos a); T_0 = 1, T_1 = c
+      const R one = valid ? R(1) : R(0);
+      R xa = one, xb = valid ? ca : R(0), ya = one, yb = valid ? cb : R(0);
+      const R twoa = ca + ca, twob = cb + cb;
+#pragma unroll
+      for (int k = 0; k < KS; k += 2) {
+        if (KC == 16 && k >= K) break;
+        if (sizeof(R) == 8) {
+          *reinterpret_cast<double2*>(tx + k) = double2{ static_cast<double>(xa), static_cast<double>(xb) };
+          *reinterpret_cast<double2*>(ty + k) = double2{ static_cast<double>(ya), static_cast<double>(yb) };
+        } else {
+          *reinterpret_cast<float2*>(tx + k) = float2{ static_cast<float>(xa), static_cast<float>(xb) };
+          *reinterpret_cast<float2*>(ty + k) = float2{ static_cast<float>(ya), static_cast<float>(yb) };
+        }
+        const R xc = twoa * xb - xa, xd = twoa * xc - xb;
+        const R yc = twob * yb - ya, yd = twob * yc - yb;
+        xa = xc;
+        xb = xd;
+        ya = yc;
+        yb = yd;
+      }
+    }
+    lds_fence();
+#pragma unroll
+    for (int m = 0; m < kStageRows / 4; m += 2) {
+      if (4 * m < rows_valid) {  // wavefront-uniform
+        const int off = (4 * m + mk) * KS + mi;
+        acc0 = M::run(tabx[off], taby[off], acc0);
+      }
+      if (4 * (m + 1) < rows_valid) {
+        const int off = (4 * (m + 1) + mk) * KS + mi;
+        acc1 = M::run(tabx[off], taby[off], acc1);
+      }
+    }
+    lds_fence();
+  };
+
+  {
+    // rollout points: lanes with a valid step j
+    const int lanes_valid_full = T / S;  // lanes whose steps are all valid ... per-j count below
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      if (j < S) {
+        // lanes l with S l + j < T  <=>  l < ceil((T - j) / S)
+        const int nl = (T - j + S - 1) / S;
+        const bool valid = i0 + j < T;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int rows = nl - 32 * h;
+          if (rows > 0) stage_and_mma(c1x[j], c1y[j], valid, h, rows > 32 ? 32 : rows);
+        }
+      }
+    }
+    (void)lanes_valid_full;
+    if (nmem > 0) {
+      const R* const mem = p.mem_cols + 3 * static_cast<size_t>(p.mem_stride) * b;
+      for (int c0 = 0; c0 < nmem; c0 += kWave) {
+        const int q = c0 + lane;
+        const bool valid = q < nmem;
+        R sa, ca = R(0), sb, cb = R(0);
+        if (valid) {
+          sincospi_r((mem[3 * q + 0] - p.map_x) * p.inv_lx, &sa, &ca);
+          sincospi_r((mem[3 * q + 1] - p.map_y) * p.inv_ly, &sb, &cb);
+        }
+        const int nl = nmem - c0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int rows = nl - 32 * h;
+          if (rows > 0) stage_and_mma(ca, cb, valid, h, rows > 32 ? 32 : rows);
+        }
+      }
+    }
+  }
+
+  // D = lambda (c - phi), fourier_diff of ergodic_control.hpp:422, in both orientations
+  {
+    const R invN = R(1) / static_cast<R>(N);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k1 = M::row(lane, r);
+      const int k2 = mi;
+      if (k1 < K && k2 < K) {
+        R c = invN * (acc0[r] + acc1[r]);
+        if (p.ck != nullptr) p.ck[static_cast<size_t>(b) * K2 + k2 * K + k1] = c;
+        // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
+        if (p.ck_shared != nullptr) c = p.ck_shared[k2 * K + k1];
+        const R d = lam[r] * (c - phi[r]);
+        s_D[k2 * K + k1] = d;
+        s_DT[k1 * K + k2] = d;
+      }
+    }
+    lds_fence();
+  }
+
+  // ================= backward half =======================================================================
+  // per step: ergodic-metric gradient (:418-436, basis.cpp:91-107)
+  //   edx_x = -pi/lx sin(a x) sum_k1 k1 U_{k1-1}(cos a x) G(k1),  G(k1) = sum_k2 D(k1,k2) cos(b_k2 y)
+  //   edx_y = -pi/ly sin(b y) sum_k2 k2 U_{k2-1}(cos b y) H(k2),  H(k2) = sum_k1 D(k1,k2) cos(a_k1 x)
+  // (sin(k a) = sin(a) U_{k-1}(cos a)); rows of D^T / D are wavefront-uniform LDS reads
+  constexpr int KA = (KC == 16) ? 16 : KC;
+  R ex[STAGES ? kMaxS : 1], ey[STAGES ? kMaxS : 1];  // kept apart from the barrier gradient only for the outputs
+#pragma unroll
+  for (int j = 0; j < kMaxS; ++j) {
+    if (STAGES) ex[j] = ey[j] = R(0);
+    // one step at a time: the rows of D are re-read per step; without the fence the compiler keeps them (and
+    // the cosine arrays of all four steps) in registers across the unrolled steps and spills
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (j < S) {
+      R accx, accy;
+      {
+        // y derivative: cosine array of the x angle, rows of D
+        R cxa[KA];
+        cxa[0] = R(1);
+        if (KA > 1) cxa[1] = c1x[j];
+        const R two = c1x[j] + c1x[j];
+#pragma unroll
+        for (int k = 2; k < KA; ++k) cxa[k] = two * cxa[k - 1] - cxa[k - 2];
+        const R twoy = c1y[j] + c1y[j];
+        R um = R(0), u0 = R(1);  // U_{k2-2}, U_{k2-1} of the y angle
+        R a = R(0);
+#pragma unroll
+        for (int k2 = 1; k2 < KA; ++k2) {
+          if (KC == 16 && k2 >= K) break;
+          const R* const row = s_D + k2 * K;
+          R ha = R(0), hb = R(0);
+#pragma unroll
+          for (int k1 = 0; k1 < KA; ++k1) {
+            if (KC == 16 && k1 >= K) break;
+            if (k1 & 1) hb += row[k1] * cxa[k1];
+            else ha += row[k1] * cxa[k1];
+          }
+          a = fma_k(u0 * (ha + hb), k2, a);
+          const R un = twoy * u0 - um;
+          um = u0;
+          u0 = un;
+        }
+        accy = a;
+      }
+      {
+        // x derivative: cosine array of the y angle, rows of D^T
+        R cya[KA];
+        cya[0] = R(1);
+        if (KA > 1) cya[1] = c1y[j];
+        const R two = c1y[j] + c1y[j];
+#pragma unroll
+        for (int k = 2; k < KA; ++k) cya[k] = two * cya[k - 1] - cya[k - 2];
+        const R twox = c1x[j] + c1x[j];
+        R um = R(0), u0 = R(1);
+        R a = R(0);
+#pragma unroll
+        for (int k1 = 1; k1 < KA; ++k1) {
+          if (KC == 16 && k1 >= K) break;
+          const R* const row = s_DT + k1 * K;
+          R ga = R(0), gb = R(0);
+#pragma unroll
+          for (int k2 = 0; k2 < KA; ++k2) {
+            if (KC == 16 && k2 >= K) break;
+            if (k2 & 1) gb += row[k2] * cya[k2];
+            else ga += row[k2] * cya[k2];
+          }
+          a = fma_k(u0 * (ga + gb), k1, a);
+          const R un = twox * u0 - um;
+          um = u0;
+          u0 = un;
+        }
+        accx = a;
+      }
+      const R exj = (-p.pi_lx * s1x[j] * accx) * p.expl_weight;
+      const R eyj = (-p.pi_ly * s1y[j] * accy) * p.expl_weight;
+      if (STAGES) {
+        ex[j] = exj;
+        ey[j] = eyj;
+      } else {
+        // g = edx + bdx (inactive steps contribute nothing to the suffix sums)
+        const bool act = i0 + j < T;
+        g0[j] = act ? exj + g0[j] : R(0);
+        g1[j] = act ? eyj + g1[j] : R(0);
+      }
+    }
+  }
+  if (STAGES) {
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      if (j < S && i0 + j < T) {
+        if (p.edx != nullptr) {
+          R* const o = p.edx + 3 * (static_cast<size_t>(T) * b + i0 + j);
+          o[0] = ex[j];
+          o[1] = ey[j];
+          o[2] = R(0);
+        }
+        if (p.bdx != nullptr) {
+          R* const o = p.bdx + 3 * (static_cast<size_t>(T) * b + i0 + j);
+          o[0] = g0[j];
+          o[1] = g1[j];
+          o[2] = R(0);
+        }
+      }
+    }
+  }
+
+  // co-state rows 0,1: rho_i = rho_{i+1} + dt g_i (suffix sums over the horizon, rho_T = 0,
+  // ergodic_control.hpp:203); row 2:
+  //   rho2_i = rho2_{i+1} + dt (S_i(rho_{i+1}) + dt/2 S_i(g_i)), S_i(v) = A(0,2) v0 + A(1,2) v1,
+  //   A = fdx(x_i, u_i) (omni.hpp:194-197, cart.hpp:183-186); then u_i = clamp(-Rinv B^T rho_i)
+  R r0[kMaxS], r1[kMaxS];  // inclusive suffix within the lane, then the co-state after step j
+  {
+    R s0 = R(0), s1 = R(0);
+#pragma unroll
+    for (int j = kMaxS - 1; j >= 0; --j) {
+      if (STAGES) {
+        const bool act = j < S && i0 + j < T;
+        g0[j] = act ? ex[j] + g0[j] : R(0);  // g = edx + bdx
+        g1[j] = act ? ey[j] + g1[j] : R(0);
+      }
+      s0 += dt * g0[j];
+      s1 += dt * g1[j];
+      r0[j] = s0;
+      r1[j] = s1;
+    }
+    // suffix over the lanes = wavefront total - inclusive prefix
+    const R i0s = wave_inclusive_scan_dpp(s0), i1s = wave_inclusive_scan_dpp(s1);
+    const R o0 = read_lane63(i0s) - i0s, o1 = read_lane63(i1s) - i1s;
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      r0[j] += o0;
+      r1[j] += o1;
+    }
+  }
+  R r2[kMaxS], cth[kMaxS], sth[kMaxS];
+  {
+    R s2 = R(0);
+#pragma unroll
+    for (int j = kMaxS - 1; j >= 0; --j) {
+      R qv = R(0);
+      cth[j] = sth[j] = R(0);
+      if (j < S) {
+        cth[j] = s_cp[j * kWave + lane];
+        sth[j] = s_sp[j * kWave + lane];
+        R a02, a12;
+        if (MODEL == kModelOmni) {
+          a02 = -vx[j] * sth[j] - vy[j] * cth[j];
+          a12 = vx[j] * cth[j] - vy[j] * sth[j];
+        } else {
+          a02 = -vx[j] * sth[j];
+          a12 = vx[j] * cth[j];
+        }
+        // rho_{i+1} = rho_i - dt g_i (rows 0,1)
+        const R sE = a02 * (r0[j] - dt * g0[j]) + a12 * (r1[j] - dt * g1[j]);
+        const R sG = a02 * g0[j] + a12 * g1[j];
+        qv = (i0 + j < T) ? dt * (sE + p.half_dt * sG) : R(0);
+      }
+      s2 += qv;
+      r2[j] = s2;
+    }
+    const R i2s = wave_inclusive_scan_dpp(s2);
+    const R o2 = read_lane63(i2s) - i2s;
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) r2[j] += o2;
+  }
+
+  // ---- u_i = clamp(-Rinv B(x_i)^T rho_i)  (ergodic_control.hpp:438-451) ---------------------------------
+#pragma unroll
+  for (int j = 0; j < kMaxS; ++j) {
+    if (j < S && i0 + j < T) {
+      const int i = i0 + j;
+      R v0, v1, v2;
+      if (MODEL == kModelOmni) {  // omni.hpp:205-212
+        v0 = cth[j] * r0[j] + sth[j] * r1[j];
+        v1 = -sth[j] * r0[j] + cth[j] * r1[j];
+        v2 = r2[j];
+      } else {  // cart.hpp:194-203: B^T rho has an exact zero in row 1
+        v0 = cth[j] * r0[j] + sth[j] * r1[j];
+        v1 = R(0);
+        v2 = r2[j];
+      }
+      const R n0 = -v0, n1 = -v1, n2 = -v2;
+      R u[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const R ur = (p.Rinv[r] * n0 + p.Rinv[r + 3] * n1) + p.Rinv[r + 6] * n2;
+        u[r] = clamp_std(ur, p.umin[r], p.umax[r]);
+      }
+      ut[3 * i + 0] = u[0];
+      ut[3 * i + 1] = u[1];
+      ut[3 * i + 2] = u[2];
+      if (STAGES && p.rhot != nullptr) {
+        R* const o = p.rhot + 3 * (static_cast<size_t>(T) * b + i);
+        o[0] = r0[j];
+        o[1] = r1[j];
+        o[2] = r2[j];
+      }
+      if (i == 0) {
+        R* const o = p.u0 + 3 * static_cast<size_t>(b);
+        o[0] = u[0];
+        o[1] = u[1];
+        o[2] = u[2];
+        if (p.done != nullptr && b == 0) {
+          // the host polls this word instead of waiting for the kernel's completion signal
+          __hip_atomic_store(p.done, p.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
+  }
+}
+
+}  // namespace wave
+}  // namespace eea

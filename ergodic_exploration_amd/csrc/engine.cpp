@@ -315,6 +315,20 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
   p.done = e->mail_done;
   p.done_seq = e->mail_seq;
   const int n_mem_max = rollout_only ? 0 : static_cast<int>(p.mem_stride);
+  // two kernels ship: one wavefront per agent (horizons <= 256 steps, K <= 16) and one workgroup per agent
+  // (everything else, and the rollout-only entry).  EEA_CONTROL_PATH=workgroup forces the second.
+  static const bool force_workgroup = [] {
+    const char* v = std::getenv("EEA_CONTROL_PATH");
+    return v != nullptr && std::strcmp(v, "workgroup") == 0;
+  }();
+  bool use_wave = !force_workgroup && eea::control_wave_eligible<R>(p, rollout_only);
+#ifdef EEA_AB_BUILD
+  if (e->impl_v1 || d_stamps != nullptr) use_wave = false;
+#endif
+  if (use_wave) {
+    EEA_HIP(eea::launch_control_wave<R>(p, B, e->cfg.model, rollout_only, s));
+    return EEA_OK;
+  }
   size_t lds = eea::control_lds_bytes<R>(p.T, p.K, n_mem_max, p.chunk);
 #ifdef EEA_AB_BUILD
   if (e->impl_v1) lds = eea::v1::control_lds_bytes<R>(p.T, p.K, n_mem_max, p.chunk);

@@ -188,7 +188,12 @@ def test_config5_end_to_end_against_oracle():
             o.set_target_grid(nx, ny, phi_vals, lx, ly)   # the expensive one
             phik_ref = o.phik
         ors.append(o)
-    assert np.abs(eng.phik() - phik_ref).max() <= 1e-11
+    # 2^20 grid points: the reference formulation adds them one after the other (Armadillo sum(fk_mat, 1),
+    # basis.cpp:132), so ITS rounding error is up to n eps / 2 * sum|terms| = 6e-11 on mode (0,0) (all terms
+    # positive, sum 1); the kernel's (0,0) coefficient is exactly 1 (it is the normaliser).  Measured 1.4e-11
+    # on that mode, <= 4e-15 on every other one.
+    dphi = np.abs(eng.phik() - phik_ref)
+    assert dphi[0] <= 1e-10 and dphi[1:].max() <= 1e-11, (dphi[0], dphi[1:].max())
     for o in ors[1:]:  # identical target: share the oracle's phi_k instead of recomputing it three times
         o.set_target_grid(1, 1, np.zeros(1), lx, ly)      # sets lx, ly (phi_k of a one-point zero grid) ...
         np.ctypeslib.as_array(po.lib().eo_control_phik(o.h), (K * K,))[:] = phik_ref  # ... then the real one
