@@ -29,6 +29,17 @@
 
 #include "common.hpp"
 
+// phase stamps: A/B library only (tools/phase_timing.py through eea_debug_phase_timing); lane 0 of every
+// wavefront records the shader clock at the phase boundaries into p.dbg [agent][16]
+#ifdef EEA_AB_BUILD
+#define EEA_WSTAMP(n)                                                                                   \
+  do {                                                                                                  \
+    if (p.dbg != nullptr && lane == 0) p.dbg[static_cast<size_t>(b) * 16 + (n)] = static_cast<long long>(__builtin_readcyclecounter()); \
+  } while (0)
+#else
+#define EEA_WSTAMP(n) do { } while (0)
+#endif
+
 namespace eea
 {
 namespace wave
@@ -40,10 +51,12 @@ __host__ __device__ constexpr int tab_stride(int K) { return (K + 1) & ~1; }  //
 // LDS carve per wavefront, in elements: heading park [2][kMaxS][64], tiles x / y (32 rows each) + the pad
 // the last rows' operand reads run into; D and D^T alias the tiles (written after the last operand read)
 __host__ __device__ constexpr int park_elems() { return 2 * kMaxS * kWave; }
+__host__ __device__ constexpr int d_elems(int K) { return (K * K + 3) & ~3; }
 __host__ __device__ constexpr int tile_elems(int K)
 {
+  // the tiles of the contraction; afterwards D [K^2] and the parked barrier gradient [2][kMaxS][64]
   const int t = 2 * kStageRows * tab_stride(K) + 16;
-  const int d = 2 * (K * K + 1);
+  const int d = d_elems(K) + 2 * kMaxS * kWave;
   return ((t > d ? t : d) + 3) & ~3;
 }
 __host__ __device__ constexpr int wave_lds_elems(int K) { return park_elems() + tile_elems(K); }
@@ -138,12 +151,13 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_k
   R* const tabx = sm + park_elems();        // [32 rows][KS]
   R* const taby = tabx + kStageRows * KS;
   R* const s_D = tabx;                      // D[k2 * K + k1]   (after the contraction)
-  R* const s_DT = tabx + ((K2 + 1) & ~1);   // D^T[k1 * K + k2]
+  R* const s_g = tabx + d_elems(KC == 16 ? 16 : KC);  // barrier gradient parked during the gradient, [2 j + r][lane]
 
   const int i0 = S * lane;  // first horizon step of this lane
   const R* const pose = p.pose + 3 * static_cast<size_t>(b);
   R* const ut = p.ut + 3 * static_cast<size_t>(T) * b;
 
+  EEA_WSTAMP(0);
   // ---- controls: shift left by one column, last column zero (ergodic_control.hpp:233-234) ------------
   R vx[kMaxS], vy[kMaxS], w[kMaxS];
   bool bad = false;
@@ -171,6 +185,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_k
     return;
   }
   if (lane == 0 && p.status != nullptr) p.status[b] = 0;
+  EEA_WSTAMP(1);
 
   const R dt = p.dt, dt6 = p.dt6;
   const R inv_pi = static_cast<R>(1.0 / kPi);
@@ -193,6 +208,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_k
     for (int j = 0; j < kMaxS; ++j) thp[j] += base;   // heading after step j
   }
 
+  EEA_WSTAMP(2);
   // position: x_i = x_{i-1} + dt/6 (k1 + 2 k2 + 2 k3 + k4) with k2 == k3 (integrator.hpp:176-184).
   // sin/cos of the pre-step heading is evaluated for the lane's first step only; the later ones are the
   // previous step's post-step values (2 mid - pre by the double-angle / addition formulas, ~4e-16 each)
@@ -237,6 +253,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_k
       py[j] += by;
     }
   }
+  EEA_WSTAMP(3);
   if (STAGES && p.traj != nullptr) {
     R* const traj = p.traj + 3 * static_cast<size_t>(T) * b;
 #pragma unroll
@@ -272,6 +289,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_k
     }
   }
 
+  EEA_WSTAMP(4);
   // ---- c_k = (1/N) sum_p cos(a_k1 x_p) cos(b_k2 y_p)  (basis.cpp:109-120) on the matrix cores -----------
   // sampled past states are prepended (buffer.cpp:78-108) and shifted like the rollout
   int nmem = 0;
@@ -285,42 +303,66 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_k
   acc_t acc0 = acc_t{ R(0), R(0), R(0), R(0) }, acc1 = acc0;
   const int mk = lane >> 4, mi = lane & 15;  // matrix-instruction operand coordinates of this lane
   // lambda_k, phi_k of this lane's accumulator entries (mode = k2 * K + k1, k2 = mi, k1 = the accumulator row
-  // of register r): issued now, consumed after the contraction
+  // of register r).  Loaded after the contraction: issued earlier (before it, or during its last pass) they
+  // hold 16 registers through the pipelined passes and cost 7 % of the launch (profiles/r02_ablation.txt)
   R lam[4], phi[4];
+  auto load_lam_phi = [&]() {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int k1 = M::row(lane, r);
-    const bool ok = k1 < K && mi < K;
-    lam[r] = ok ? p.lamdak[mi * K + k1] : R(0);
-    phi[r] = ok ? p.phik[mi * K + k1] : R(0);
-  }
+    for (int r = 0; r < 4; ++r) {
+      const int k1 = M::row(lane, r);
+      const bool ok = k1 < K && mi < K;
+      lam[r] = ok ? p.lamdak[mi * K + k1] : R(0);
+      phi[r] = ok ? p.phik[mi * K + k1] : R(0);
+    }
+  };
 
-  // one half pass: the 32 lanes [32 h, 32 h + 32) stage the cos tables of one point each (zero rows for
-  // invalid points), then up to 8 matrix instructions consume 4 rows each
+  // Tiles: 32 rows [point][k] per axis.  One pass of 8 matrix instructions consumes the 32 rows staged by one
+  // half of the wavefront (lanes [32 h, 32 h + 32): one point each, zero rows for invalid points).
+  // cos(k a) = T_k(cos a) by the Chebyshev recurrence, two entries (one 16-byte store per axis) per step.
+  struct Tab
+  {
+    R xa, xb, ya, yb, twoa, twob;
+  };
+  auto tab_init = [&](R ca, R cb, bool valid) {
+    Tab t;
+    const R one = valid ? R(1) : R(0);
+    t.xa = one;
+    t.xb = valid ? ca : R(0);
+    t.ya = one;
+    t.yb = valid ? cb : R(0);
+    t.twoa = ca + ca;
+    t.twob = cb + cb;
+    return t;
+  };
+  auto tab_store = [&](const Tab& t, int k) {  // entries k, k + 1 of this lane's row
+    R* const tx = tabx + (lane & 31) * KS + k;
+    R* const ty = taby + (lane & 31) * KS + k;
+    if (sizeof(R) == 8) {
+      *reinterpret_cast<double2*>(tx) = double2{ static_cast<double>(t.xa), static_cast<double>(t.xb) };
+      *reinterpret_cast<double2*>(ty) = double2{ static_cast<double>(t.ya), static_cast<double>(t.yb) };
+    } else {
+      *reinterpret_cast<float2*>(tx) = float2{ static_cast<float>(t.xa), static_cast<float>(t.xb) };
+      *reinterpret_cast<float2*>(ty) = float2{ static_cast<float>(t.ya), static_cast<float>(t.yb) };
+    }
+  };
+  auto tab_step = [&](Tab& t) {
+    const R xc = t.twoa * t.xb - t.xa, xd = t.twoa * xc - t.xb;
+    const R yc = t.twob * t.yb - t.ya, yd = t.twob * yc - t.yb;
+    t.xa = xc;
+    t.xb = xd;
+    t.ya = yc;
+    t.yb = yd;
+  };
+  constexpr int kPairs = KS / 2;  // 16-byte stores per row and axis
+  // plain (not software-pipelined) half pass: the replay-memory columns and the generic-K instance
   auto stage_and_mma = [&](R ca, R cb, bool valid, int h, int rows_valid) {
     if ((lane >> 5) == h) {
-      R* const tx = tabx + (lane & 31) * KS;
-      R* const ty = taby + (lane & 31) * KS;
-      // Chebyshev: cos(k a) = T_k(cos a); T_0 = 1, T_1 = c
-      const R one = valid ? R(1) : R(0);
-      R xa = one, xb = valid ? ca : R(0), ya = one, yb = valid ? cb : R(0);
-      const R twoa = ca + ca, twob = cb + cb;
+      Tab t = tab_init(ca, cb, valid);
 #pragma unroll
-      for (int k = 0; k < KS; k += 2) {
-        if (KC == 16 && k >= K) break;
-        if (sizeof(R) == 8) {
-          *reinterpret_cast<double2*>(tx + k) = double2{ static_cast<double>(xa), static_cast<double>(xb) };
-          *reinterpret_cast<double2*>(ty + k) = double2{ static_cast<double>(ya), static_cast<double>(yb) };
-        } else {
-          *reinterpret_cast<float2*>(tx + k) = float2{ static_cast<float>(xa), static_cast<float>(xb) };
-          *reinterpret_cast<float2*>(ty + k) = float2{ static_cast<float>(ya), static_cast<float>(yb) };
-        }
-        const R xc = twoa * xb - xa, xd = twoa * xc - xb;
-        const R yc = twob * yb - ya, yd = twob * yc - yb;
-        xa = xc;
-        xb = xd;
-        ya = yc;
-        yb = yd;
+      for (int q = 0; q < kPairs; ++q) {
+        if (KC == 16 && 2 * q >= K) break;
+        tab_store(t, 2 * q);
+        tab_step(t);
       }
     }
     lds_fence();
@@ -338,9 +380,75 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_k
     lds_fence();
   };
 
-  {
-    // rollout points: lanes with a valid step j
-    const int lanes_valid_full = T / S;  // lanes whose steps are all valid ... per-j count below
+  if (KC != 16) {
+    // Rollout points, software-pipelined: the 8 matrix instructions of a pass take 65 cycles of the matrix pipe
+    // each; the table recurrence and the LDS stores of the NEXT pass are issued in between them (in program
+    // order, pinned with scheduling barriers), so that only the operand reads wait.  Branch-free: passes beyond
+    // the horizon multiply zero rows.
+    R oa[kStageRows / 4], ob[kStageRows / 4];
+    auto read_operands = [&]() {
+#pragma unroll
+      for (int m = 0; m < kStageRows / 4; ++m) {
+        const int off = (4 * m + mk) * KS + mi;
+        oa[m] = tabx[off];
+        ob[m] = taby[off];
+      }
+    };
+    const bool lo = lane < 32;
+    Tab t = tab_init(c1x[0], c1y[0], i0 < T);
+    {
+      Tab u = t;
+      if (lo) {
+#pragma unroll
+        for (int q = 0; q < kPairs; ++q) {
+          tab_store(u, 2 * q);
+          tab_step(u);
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      if (j < S) {  // wavefront-uniform
+        lds_fence();
+        read_operands();  // rows of lanes 0..31, step j
+        lds_fence();      // operands in registers: the tile is free
+        // pass (j, lower half) on the matrix pipe; meanwhile lanes 32..63 store their rows of step j
+        {
+          Tab u = t;
+#pragma unroll
+          for (int m = 0; m < kStageRows / 4; ++m) {
+            if (m & 1) acc1 = M::run(oa[m], ob[m], acc1);
+            else acc0 = M::run(oa[m], ob[m], acc0);
+            if (m < kPairs) {
+              if (!lo) tab_store(u, 2 * m);
+              tab_step(u);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        lds_fence();
+        read_operands();  // rows of lanes 32..63, step j
+        lds_fence();
+        // pass (j, upper half); meanwhile the tables of step j + 1 and the stores of lanes 0..31
+        {
+          const int jn = (j + 1 < kMaxS) ? j + 1 : j;
+          t = tab_init(c1x[jn], c1y[jn], (j + 1 < S) && (i0 + j + 1 < T));
+          Tab u = t;
+#pragma unroll
+          for (int m = 0; m < kStageRows / 4; ++m) {
+            if (m & 1) acc1 = M::run(oa[m], ob[m], acc1);
+            else acc0 = M::run(oa[m], ob[m], acc0);
+            if (m < kPairs) {
+              if (lo) tab_store(u, 2 * m);
+              tab_step(u);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      }
+    }
+    lds_fence();
+  } else {
 #pragma unroll
     for (int j = 0; j < kMaxS; ++j) {
       if (j < S) {
@@ -354,27 +462,28 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_k
         }
       }
     }
-    (void)lanes_valid_full;
-    if (nmem > 0) {
-      const R* const mem = p.mem_cols + 3 * static_cast<size_t>(p.mem_stride) * b;
-      for (int c0 = 0; c0 < nmem; c0 += kWave) {
-        const int q = c0 + lane;
-        const bool valid = q < nmem;
-        R sa, ca = R(0), sb, cb = R(0);
-        if (valid) {
-          sincospi_r((mem[3 * q + 0] - p.map_x) * p.inv_lx, &sa, &ca);
-          sincospi_r((mem[3 * q + 1] - p.map_y) * p.inv_ly, &sb, &cb);
-        }
-        const int nl = nmem - c0;
+  }
+  if (nmem > 0) {
+    const R* const mem = p.mem_cols + 3 * static_cast<size_t>(p.mem_stride) * b;
+    for (int c0 = 0; c0 < nmem; c0 += kWave) {
+      const int q = c0 + lane;
+      const bool valid = q < nmem;
+      R sa, ca = R(0), sb, cb = R(0);
+      if (valid) {
+        sincospi_r((mem[3 * q + 0] - p.map_x) * p.inv_lx, &sa, &ca);
+        sincospi_r((mem[3 * q + 1] - p.map_y) * p.inv_ly, &sb, &cb);
+      }
+      const int nl = nmem - c0;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int rows = nl - 32 * h;
-          if (rows > 0) stage_and_mma(ca, cb, valid, h, rows > 32 ? 32 : rows);
-        }
+      for (int h = 0; h < 2; ++h) {
+        const int rows = nl - 32 * h;
+        if (rows > 0) stage_and_mma(ca, cb, valid, h, rows > 32 ? 32 : rows);
       }
     }
   }
 
+  load_lam_phi();
+  EEA_WSTAMP(5);
   // D = lambda (c - phi), fourier_diff of ergodic_control.hpp:422, in both orientations
   {
     const R invN = R(1) / static_cast<R>(N);
@@ -389,85 +498,91 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_k
         if (p.ck_shared != nullptr) c = p.ck_shared[k2 * K + k1];
         const R d = lam[r] * (c - phi[r]);
         s_D[k2 * K + k1] = d;
-        s_DT[k1 * K + k2] = d;
       }
     }
     lds_fence();
   }
 
+  EEA_WSTAMP(6);
   // ================= backward half =======================================================================
   // per step: ergodic-metric gradient (:418-436, basis.cpp:91-107)
   //   edx_x = -pi/lx sin(a x) sum_k1 k1 U_{k1-1}(cos a x) G(k1),  G(k1) = sum_k2 D(k1,k2) cos(b_k2 y)
   //   edx_y = -pi/ly sin(b y) sum_k2 k2 U_{k2-1}(cos b y) H(k2),  H(k2) = sum_k1 D(k1,k2) cos(a_k1 x)
   // (sin(k a) = sin(a) U_{k-1}(cos a)); rows of D^T / D are wavefront-uniform LDS reads
   constexpr int KA = (KC == 16) ? 16 : KC;
+  // the barrier gradient waits in LDS while the gradient needs the registers (the tiles are dead)
+  if (!STAGES) {
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      if (j < S) {
+        s_g[(2 * j + 0) * kWave + lane] = g0[j];
+        s_g[(2 * j + 1) * kWave + lane] = g1[j];
+      }
+    }
+  }
   R ex[STAGES ? kMaxS : 1], ey[STAGES ? kMaxS : 1];  // kept apart from the barrier gradient only for the outputs
 #pragma unroll
   for (int j = 0; j < kMaxS; ++j) {
     if (STAGES) ex[j] = ey[j] = R(0);
     // one step at a time: the rows of D are re-read per step; without the fence the compiler keeps them (and
-    // the cosine arrays of all four steps) in registers across the unrolled steps and spills
+    // the arrays of all four steps) in registers across the unrolled steps and spills
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     if (j < S) {
-      R accx, accy;
+      // one pass over D: G(k1) accumulates over the rows, H(k2) is complete at the end of row k2
+      R cxa[KA], G[KA];
+      cxa[0] = R(1);
+      if (KA > 1) cxa[1] = c1x[j];
       {
-        // y derivative: cosine array of the x angle, rows of D
-        R cxa[KA];
-        cxa[0] = R(1);
-        if (KA > 1) cxa[1] = c1x[j];
         const R two = c1x[j] + c1x[j];
 #pragma unroll
         for (int k = 2; k < KA; ++k) cxa[k] = two * cxa[k - 1] - cxa[k - 2];
-        const R twoy = c1y[j] + c1y[j];
-        R um = R(0), u0 = R(1);  // U_{k2-2}, U_{k2-1} of the y angle
-        R a = R(0);
-#pragma unroll
-        for (int k2 = 1; k2 < KA; ++k2) {
-          if (KC == 16 && k2 >= K) break;
-          const R* const row = s_D + k2 * K;
-          R ha = R(0), hb = R(0);
-#pragma unroll
-          for (int k1 = 0; k1 < KA; ++k1) {
-            if (KC == 16 && k1 >= K) break;
-            if (k1 & 1) hb += row[k1] * cxa[k1];
-            else ha += row[k1] * cxa[k1];
-          }
-          a = fma_k(u0 * (ha + hb), k2, a);
-          const R un = twoy * u0 - um;
-          um = u0;
-          u0 = un;
-        }
-        accy = a;
       }
+      // row k2 = 0: cos(0 y) = 1 and k2 sin(0) = 0: only G takes part
       {
-        // x derivative: cosine array of the y angle, rows of D^T
-        R cya[KA];
-        cya[0] = R(1);
-        if (KA > 1) cya[1] = c1y[j];
-        const R two = c1y[j] + c1y[j];
+        const R* const row = s_D;
 #pragma unroll
-        for (int k = 2; k < KA; ++k) cya[k] = two * cya[k - 1] - cya[k - 2];
-        const R twox = c1x[j] + c1x[j];
-        R um = R(0), u0 = R(1);
-        R a = R(0);
+        for (int k1 = 1; k1 < KA; ++k1) G[k1] = (KC == 16 && k1 >= K) ? R(0) : row[k1];
+        G[0] = R(0);
+      }
+      const R twoy = c1y[j] + c1y[j];
+      R um = R(0), u0 = R(1);         // U_{k2-2}, U_{k2-1} of the y angle
+      R tm = R(1), t0 = c1y[j];       // T_{k2-1}, T_{k2}
+      R accy = R(0);
+#pragma unroll
+      for (int k2 = 1; k2 < KA; ++k2) {
+        if (KC == 16 && k2 >= K) break;
+        const R* const row = s_D + k2 * K;
+        R ha = row[0], hb = R(0);     // cxa[0] = 1
 #pragma unroll
         for (int k1 = 1; k1 < KA; ++k1) {
           if (KC == 16 && k1 >= K) break;
-          const R* const row = s_DT + k1 * K;
-          R ga = R(0), gb = R(0);
-#pragma unroll
-          for (int k2 = 0; k2 < KA; ++k2) {
-            if (KC == 16 && k2 >= K) break;
-            if (k2 & 1) gb += row[k2] * cya[k2];
-            else ga += row[k2] * cya[k2];
-          }
-          a = fma_k(u0 * (ga + gb), k1, a);
-          const R un = twox * u0 - um;
-          um = u0;
-          u0 = un;
+          const R d = row[k1];
+          G[k1] += d * t0;
+          if (k1 & 1) hb += d * cxa[k1];
+          else ha += d * cxa[k1];
         }
-        accx = a;
+        accy = fma_k(u0 * (ha + hb), k2, accy);
+        const R un = twoy * u0 - um;
+        um = u0;
+        u0 = un;
+        const R tn = twoy * t0 - tm;
+        tm = t0;
+        t0 = tn;
+      }
+      // edx_x: sum_k1 k1 U_{k1-1}(cos a x) G(k1)
+      R accx = R(0);
+      {
+        const R twox = c1x[j] + c1x[j];
+        R vm = R(0), v0 = R(1);
+#pragma unroll
+        for (int k1 = 1; k1 < KA; ++k1) {
+          if (KC == 16 && k1 >= K) break;
+          accx = fma_k(v0 * G[k1], k1, accx);
+          const R vn = twox * v0 - vm;
+          vm = v0;
+          v0 = vn;
+        }
       }
       const R exj = (-p.pi_lx * s1x[j] * accx) * p.expl_weight;
       const R eyj = (-p.pi_ly * s1y[j] * accy) * p.expl_weight;
@@ -475,10 +590,11 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_k
         ex[j] = exj;
         ey[j] = eyj;
       } else {
-        // g = edx + bdx (inactive steps contribute nothing to the suffix sums)
+        // g = edx + bdx (inactive steps contribute nothing to the suffix sums); the basis registers of this
+        // step are dead from here on
         const bool act = i0 + j < T;
-        g0[j] = act ? exj + g0[j] : R(0);
-        g1[j] = act ? eyj + g1[j] : R(0);
+        g0[j] = act ? exj + s_g[(2 * j + 0) * kWave + lane] : R(0);
+        g1[j] = act ? eyj + s_g[(2 * j + 1) * kWave + lane] : R(0);
       }
     }
   }
@@ -502,6 +618,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_k
     }
   }
 
+  EEA_WSTAMP(7);
   // co-state rows 0,1: rho_i = rho_{i+1} + dt g_i (suffix sums over the horizon, rho_T = 0,
   // ergodic_control.hpp:203); row 2:
   //   rho2_i = rho2_{i+1} + dt (S_i(rho_{i+1}) + dt/2 S_i(g_i)), S_i(v) = A(0,2) v0 + A(1,2) v1,
@@ -562,6 +679,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_k
     for (int j = 0; j < kMaxS; ++j) r2[j] += o2;
   }
 
+  EEA_WSTAMP(8);
   // ---- u_i = clamp(-Rinv B(x_i)^T rho_i)  (ergodic_control.hpp:438-451) ---------------------------------
 #pragma unroll
   for (int j = 0; j < kMaxS; ++j) {
@@ -605,6 +723,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_k
       }
     }
   }
+  EEA_WSTAMP(9);
 }
 
 }  // namespace wave

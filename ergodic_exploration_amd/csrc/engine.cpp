@@ -323,7 +323,9 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
   }();
   bool use_wave = !force_workgroup && eea::control_wave_eligible<R>(p, rollout_only);
 #ifdef EEA_AB_BUILD
-  if (e->impl_v1 || d_stamps != nullptr) use_wave = false;
+  if (e->impl_v1) use_wave = false;
+  if (d_stamps != nullptr && !use_wave && sizeof(R) != 8) return fail(EEA_ERR_UNSUPPORTED, "phase timing is built for fp64 only");
+  if (d_stamps != nullptr && use_wave) p.dbg = d_stamps;  // [agent][16] stamps of the wavefront-per-agent kernel
 #endif
   if (use_wave) {
     EEA_HIP(eea::launch_control_wave<R>(p, B, e->cfg.model, rollout_only, s));

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Per-phase latency of the control kernel (K = 10, T = 200, fp64) from the instrumented build:
-mean shader-clock cycles each wavefront spends between the phase stamps."""
+"""Per-phase latency of the control kernel (K = 10, T = 200, fp64) from the instrumented A/B build
+(make -C ergodic_exploration_amd/csrc AB=1): mean shader-clock cycles every wavefront spends between the
+phase stamps.  Default: the wavefront-per-agent kernel ([agent][16] stamps); EEA_CONTROL_PATH=workgroup: the
+workgroup-per-agent kernel ([agent][4 waves][16])."""
 import os
 import sys
 
@@ -9,16 +11,18 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-# the instrumented kernel lives in the A/B library: make -C ergodic_exploration_amd/csrc AB=1
 os.environ.setdefault("EEA_LIB_VARIANT", "_ab")
 from ergodic_exploration_amd import capi  # noqa: E402
 
-PHASES = ["load+shift controls", "heading scan", "heading sincos", "position scan", "basis sincos",
-          "tables + MFMA c_k", "reduce c_k, D", "gradient", "rho01 scan", "rho2 scan", "update+store"]
+PHASES_WG = ["load+shift controls", "heading scan", "heading sincos", "position scan", "basis sincos",
+             "tables + MFMA c_k", "reduce c_k, D", "gradient", "rho01 scan", "rho2 scan", "update+store"]
+PHASES_WAVE = ["load+shift controls", "heading scan", "heading sincos + position scan", "basis sincos + barrier",
+               "tables + MFMA c_k", "D = lambda (c - phi)", "gradient", "rho scans", "update + store"]
 
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+    wg = os.environ.get("EEA_CONTROL_PATH") == "workgroup"
     model = capi.MODEL_SIMPLE_CART
     lim = np.array([1.0, 0.0, 2.0])
     eng = capi.Engine(capi.make_config(model, 0.1, 20.0, 0.1, 1.0, 10, np.diag([1.0, 0.0, 2.0]), -lim, lim))
@@ -30,23 +34,26 @@ def main():
     d_pose = torch.as_tensor(poses).cuda()
     d_ut = torch.zeros((B, T, 3), dtype=torch.float64, device="cuda")
     d_u0 = torch.empty((B, 3), dtype=torch.float64, device="cuda")
-    d_ck = torch.empty((B, K2), dtype=torch.float64, device="cuda")
     for _ in range(5):
-        eng.control_batch(B, d_pose, d_ut, d_u0, ck=d_ck)
+        eng.control_batch(B, d_pose, d_ut, d_u0)
     stamps = torch.zeros((B, 4, 16), dtype=torch.int64, device="cuda")
-    eng.debug_phase_timing(B, d_pose, d_ut, d_u0, stamps, ck=d_ck)
+    eng.debug_phase_timing(B, d_pose, d_ut, d_u0, stamps)
     torch.cuda.synchronize()
-    s = stamps.cpu().numpy()[:, :, :12].astype(np.float64)
-    d = np.diff(s, axis=2)                      # [B][4][11]
-    total = s[:, :, 11] - s[:, :, 0]
-    print("agents %d: wave lifetime mean %.0f cycles (min %.0f max %.0f); launch span %.0f cycles"
-          % (B, total.mean(), total.min(), total.max(), s[:, :, 11].max() - s[:, :, 0].min()))
-    for w in range(4):
-        print("wave %d: " % w + " ".join("%6.0f" % v for v in d[:, w, :].mean(0)))
-    print("%-24s %10s %7s" % ("phase", "cycles", "share"))
+    if wg:
+        s = stamps.cpu().numpy()[:, :, :12].astype(np.float64)
+        names = PHASES_WG
+    else:
+        s = stamps.cpu().numpy().reshape(-1)[:B * 16].reshape(B, 1, 16)[:, :, :10].astype(np.float64)
+        names = PHASES_WAVE
+    d = np.diff(s, axis=2)
+    total = s[:, :, -1] - s[:, :, 0]
+    print("agents %d: wave lifetime mean %.0f cycles (min %.0f max %.0f); launch span %.0f cycles; first start "
+          "spread %.0f cycles" % (B, total.mean(), total.min(), total.max(), s[:, :, -1].max() - s[:, :, 0].min(),
+                                  s[:, :, 0].max() - s[:, :, 0].min()))
+    print("%-34s %10s %7s" % ("phase", "cycles", "share"))
     m = d.mean((0, 1))
-    for name, v in zip(PHASES, m):
-        print("%-24s %10.0f %6.1f%%" % (name, v, 100 * v / m.sum()))
+    for name, v in zip(names, m):
+        print("%-34s %10.0f %6.1f%%" % (name, v, 100 * v / m.sum()))
     eng.close()
 
 

@@ -24,13 +24,13 @@ def main():
             name = r.get("Name", "")
             print("%-90s calls=%s total_ns=%s avg_ns=%s pct=%s" % (name[:90], r.get("Calls"), r.get("TotalDurationNs"),
                                                                    r.get("AverageNs"), r.get("Percentage")))
-            if "control_kernel" in name:
+            if "control_kernel" in name or "control_wave_kernel" in name:
                 summary["control_kernel_avg_ns"] = float(r.get("AverageNs", 0))
                 summary["control_kernel_calls"] = int(r.get("Calls", 0))
     # kernel trace: register / LDS use of the control kernel
     for p in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
         for r in rows(p):
-            if "control_kernel" in r.get("Kernel_Name", ""):
+            if "control_" in r.get("Kernel_Name", ""):
                 keys = ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size",
                         "Workgroup_Size", "Grid_Size")
                 summary["control_kernel_resources"] = {k: r.get(k) for k in keys if k in r}
@@ -40,7 +40,7 @@ def main():
     counters = defaultdict(list)
     for p in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
         for r in rows(p):
-            if "control_kernel" not in r.get("Kernel_Name", ""):
+            if "control_" not in r.get("Kernel_Name", ""):
                 continue
             counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
     print("== PMC (control_kernel, mean per dispatch over %d dispatches)" % (max([len(v) for v in counters.values()] or [0])))
