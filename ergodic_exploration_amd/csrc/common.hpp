@@ -88,6 +88,31 @@ hipError_t launch_control(const ControlParams<R>& p, unsigned B, int model, int 
 #endif  // EEA_AB_BUILD
 
 // ---- phi_k path ----------------------------------------------------------------------
+// Gaussians of a target passed to the fill kernel by value: [mean x, mean y (Fourier frame), cov_inv xx, yy]
+constexpr int kMaxGaussArgs = 8;
+constexpr int kFillPerThread = 16;  // grid points per thread of the fill kernel
+template <typename R>
+struct GaussArgs
+{
+  int n;
+  R g[kMaxGaussArgs][4];
+};
+// both axis tables of a rebuild in one launch (cx: [K][nx], cy: [ny][K]); d_coord: the accumulated coordinates
+template <typename R>
+hipError_t launch_axis_tables(const R* d_coord, int nx, int ny, int K, R pi_lx, R pi_ly, R* d_cx, R* d_cy,
+                              hipStream_t s);
+// un-normalised Target::fill with the Gaussians in the kernel arguments; target_fill_blocks(P) partial sums
+int target_fill_blocks(size_t P);
+// (and, when d_cx != nullptr, the two axis tables in the same launch)
+template <typename R>
+hipError_t launch_target_fill_args(const R* d_coord, int nx, int ny, const GaussArgs<R>& ga, R* d_phi,
+                                   R* d_partials, int K, R pi_lx, R pi_ly, R* d_cx, R* d_cy, hipStream_t s);
+// spatialCoeff of an UN-normalised grid divided by its mass (the sum of d_mass_partials); d_mass[0] receives
+// the mass
+template <typename R>
+hipError_t launch_spatial_coeff_normalised(const R* d_phi_raw, int nx, int ny, int K, const R* d_cx, const R* d_cy,
+                                           R* d_work, R* d_phik, const R* d_mass_partials, int n_mass, R* d_mass,
+                                           hipStream_t s);
 // cos tables: out[k * n + i] = cos((k * pi_over_l) * coord[i]), k < K
 template <typename R>
 hipError_t launch_cos_tables(const R* d_coord, int n, int K, R pi_over_l, R* d_out, hipStream_t s);

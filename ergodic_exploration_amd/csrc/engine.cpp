@@ -80,8 +80,17 @@ struct eea_engine
   DevBuf d_phik, d_lamdak;
   // phi grid of the last rebuild
   unsigned nx = 0, ny = 0;
-  bool have_fill_grid = false;  // d_phi holds the Target::fill output of the last rebuild
-  DevBuf d_phi, d_xs, d_ys, d_cx, d_cy, d_work, d_gauss, d_sum;
+  bool have_fill_grid = false;  // d_phi holds the Target::fill output of the last rebuild ...
+  bool phi_is_raw = false;      // ... un-normalised: d_sum[0] is its mass (eea_get_target_grid divides)
+  DevBuf d_phi, d_axis, d_cx, d_cy, d_work, d_gauss, d_sum;
+  // accumulated grid coordinates 0, res, res + res, ... (ergodic_control.hpp:387-408): one device array serves
+  // both axes of every grid of this engine (the resolution is fixed); grown on demand
+  unsigned axis_n = 0;
+  // key of the cos tables in d_cx / d_cy: a repeated rebuild / row tile on the same grid and domain reuses them
+  unsigned tab_nx = 0, tab_ny = 0;
+  double tab_lx = 0.0, tab_ly = 0.0;
+  bool have_lut = false;  // the entropy decode table is uploaded once
+  hipEvent_t ev_done = nullptr;  // completion of a rebuild: polled (a few microseconds earlier than a blocking wait)
   DevBuf d_lut, d_raw, d_occ;  // occupancy targets: decode table, un-normalised sums, staged cells
 
   // single-agent path
@@ -124,6 +133,20 @@ eea_status stage_reserve(eea_engine* e, size_t bytes)
   return EEA_OK;
 }
 
+// waits for everything enqueued on `s` so far: records an event and polls it (bounded), then the ordinary wait
+eea_status wait_stream_spin(eea_engine* e, hipStream_t s)
+{
+  if (e->ev_done == nullptr) EEA_HIP(hipEventCreateWithFlags(&e->ev_done, hipEventDisableTiming));
+  EEA_HIP(hipEventRecord(e->ev_done, s));
+  for (int spin = 0; spin < 200000; ++spin) {
+    const hipError_t q = hipEventQuery(e->ev_done);
+    if (q == hipSuccess) return EEA_OK;
+    if (q != hipErrorNotReady) return fail(EEA_ERR_HIP, std::string("hipEventQuery: ") + hipGetErrorString(q));
+  }
+  EEA_HIP(hipStreamSynchronize(s));
+  return EEA_OK;
+}
+
 template <typename R>
 eea_status upload_lamdak(eea_engine* e)
 {
@@ -142,38 +165,56 @@ eea_status upload_lamdak(eea_engine* e)
   return EEA_OK;
 }
 
-// coordinates of configTarget's grid: repeated += resolution (ergodic_control.hpp:387-408)
+// coordinates of configTarget's grid: repeated += resolution (ergodic_control.hpp:387-408).  The sequence does
+// not depend on the domain, only on the resolution, so it is generated once per engine (and extended when a
+// larger grid appears): no upload, no synchronisation on the rebuild path.
 template <typename R>
-std::vector<R> axis_coords(unsigned n, double resolution)
+eea_status ensure_axis(eea_engine* e, unsigned n)
 {
-  std::vector<R> v(n);
+  if (n <= e->axis_n) return EEA_OK;
+  unsigned cap = e->axis_n ? 2 * e->axis_n : 2048;
+  if (cap < n) cap = n;
+  std::vector<R> v(cap);
   double x = 0.0;
-  for (unsigned i = 0; i < n; ++i) {
+  for (unsigned i = 0; i < cap; ++i) {
     v[i] = static_cast<R>(x);
-    x += resolution;
+    x += e->cfg.resolution;
   }
-  return v;
+  EEA_HIP(hipDeviceSynchronize());  // kernels of earlier rebuilds may still read the old array
+  EEA_HIP(e->d_axis.reserve(sizeof(R) * cap));
+  EEA_HIP(hipMemcpy(e->d_axis.p, v.data(), sizeof(R) * cap, hipMemcpyHostToDevice));
+  e->axis_n = cap;
+  return EEA_OK;
 }
 
+// cos tables of the current domain (e->lx, e->ly) on an nx x ny grid: one launch, reused while grid and domain
+// stay the same
+// returns through *stale whether the tables have to be (re)computed; the caller that fuses their computation
+// into its own launch passes stale != nullptr, everybody else gets the separate table launch
 template <typename R>
-eea_status upload_axes_and_tables(eea_engine* e, unsigned nx, unsigned ny, hipStream_t s)
+eea_status upload_axes_and_tables(eea_engine* e, unsigned nx, unsigned ny, hipStream_t s, bool* stale = nullptr)
 {
-  const std::vector<R> xs = axis_coords<R>(nx, e->cfg.resolution);
-  const std::vector<R> ys = axis_coords<R>(ny, e->cfg.resolution);
-  EEA_HIP(e->d_xs.reserve(sizeof(R) * nx));
-  EEA_HIP(e->d_ys.reserve(sizeof(R) * ny));
-  EEA_HIP(e->d_cx.reserve(sizeof(R) * nx * e->K));
-  EEA_HIP(e->d_cy.reserve(sizeof(R) * ny * e->K));
-  EEA_HIP(e->d_work.reserve(sizeof(R) * eea::spatial_work_elems(nx, ny, e->K)));
-  EEA_HIP(hipMemcpyAsync(e->d_xs.p, xs.data(), sizeof(R) * nx, hipMemcpyHostToDevice, s));
-  EEA_HIP(hipMemcpyAsync(e->d_ys.p, ys.data(), sizeof(R) * ny, hipMemcpyHostToDevice, s));
-  // the copies read pageable host vectors that die with this scope
-  EEA_HIP(hipStreamSynchronize(s));
+  if (stale) *stale = false;
+  eea_status st = ensure_axis<R>(e, nx > ny ? nx : ny);
+  if (st != EEA_OK) return st;
+  const size_t need_cx = sizeof(R) * nx * e->K, need_cy = sizeof(R) * ny * e->K;
+  const size_t need_work = sizeof(R) * eea::spatial_work_elems(nx, ny, e->K);
+  if (need_cx > e->d_cx.cap || need_cy > e->d_cy.cap || need_work > e->d_work.cap) {
+    EEA_HIP(hipDeviceSynchronize());  // the buffers about to be replaced may still be in use
+    EEA_HIP(e->d_cx.reserve(need_cx));
+    EEA_HIP(e->d_cy.reserve(need_cy));
+    EEA_HIP(e->d_work.reserve(need_work));
+    e->tab_nx = e->tab_ny = 0;
+  }
+  if (e->tab_nx == nx && e->tab_ny == ny && e->tab_lx == e->lx && e->tab_ly == e->ly) return EEA_OK;
   const R pi_lx = static_cast<R>(eea::kPi / e->lx), pi_ly = static_cast<R>(eea::kPi / e->ly);
-  EEA_HIP(eea::launch_cos_tables<R>(static_cast<const R*>(e->d_xs.p), nx, e->K, pi_lx,
-                                    static_cast<R*>(e->d_cx.p), s));
-  EEA_HIP(eea::launch_cos_tables_t<R>(static_cast<const R*>(e->d_ys.p), ny, e->K, pi_ly,
-                                      static_cast<R*>(e->d_cy.p), s));
+  if (stale) *stale = true;
+  else EEA_HIP(eea::launch_axis_tables<R>(static_cast<const R*>(e->d_axis.p), nx, ny, e->K, pi_lx, pi_ly,
+                                     static_cast<R*>(e->d_cx.p), static_cast<R*>(e->d_cy.p), s));
+  e->tab_nx = nx;
+  e->tab_ny = ny;
+  e->tab_lx = e->lx;
+  e->tab_ly = e->ly;
   return EEA_OK;
 }
 
@@ -189,7 +230,8 @@ eea_status reserve_tile_work(eea_engine* e, unsigned nx, unsigned ny_total, unsi
   return EEA_OK;
 }
 
-// Target::fill + Basis::spatialCoeff on the device
+// Target::fill + Basis::spatialCoeff on the device: three launches (tables + fill, streaming pass, final sums
+// with the normalisation folded in) and ONE host synchronisation at the end
 template <typename R>
 eea_status rebuild_phik(eea_engine* e, hipStream_t s)
 {
@@ -202,12 +244,13 @@ eea_status rebuild_phik(eea_engine* e, hipStream_t s)
   }
   e->nx = nx;
   e->ny = ny;
-  eea_status st = upload_axes_and_tables<R>(e, nx, ny, s);
+  const int ng = static_cast<int>(e->mu.size() / 2);
+  bool tables_stale = false;
+  eea_status st = upload_axes_and_tables<R>(e, nx, ny, s, ng <= eea::kMaxGaussArgs ? &tables_stale : nullptr);
   if (st != EEA_OK) return st;
 
   // Gaussian parameters as the reference prepares them: mean translated into the Fourier
   // frame (target.hpp:99), cov_inv = inv(diagmat(sigma^2)) (target.hpp:69; 2x2 inverse)
-  const int ng = static_cast<int>(e->mu.size() / 2);
   std::vector<R> g(static_cast<size_t>(4) * (ng ? ng : 1));
   for (int i = 0; i < ng; ++i) {
     const double a = e->sigma[2 * i] * e->sigma[2 * i], d = e->sigma[2 * i + 1] * e->sigma[2 * i + 1];
@@ -217,26 +260,57 @@ eea_status rebuild_phik(eea_engine* e, hipStream_t s)
     g[4 * i + 2] = static_cast<R>(d / det);
     g[4 * i + 3] = static_cast<R>(a / det);
   }
-  const int fill_blocks = static_cast<int>((P + eea::kBlock - 1) / eea::kBlock);
-  EEA_HIP(e->d_gauss.reserve(sizeof(R) * g.size()));
-  EEA_HIP(e->d_phi.reserve(sizeof(R) * P));
-  EEA_HIP(e->d_sum.reserve(sizeof(R) * (static_cast<size_t>(fill_blocks) + 1)));
-  EEA_HIP(hipMemcpyAsync(e->d_gauss.p, g.data(), sizeof(R) * g.size(), hipMemcpyHostToDevice, s));
-  EEA_HIP(hipStreamSynchronize(s));
-
-  R* const d_partials = static_cast<R*>(e->d_sum.p) + 1;
+  const size_t need_phi = sizeof(R) * P;
+  const int fill_blocks_args = eea::target_fill_blocks(P);
+  const int fill_blocks_buf = static_cast<int>((P + eea::kBlock - 1) / eea::kBlock);
+  const size_t need_sum = sizeof(R) * (static_cast<size_t>(ng <= eea::kMaxGaussArgs ? fill_blocks_args : fill_blocks_buf) + 1);
+  if (need_phi > e->d_phi.cap || need_sum > e->d_sum.cap) {
+    EEA_HIP(hipDeviceSynchronize());
+    EEA_HIP(e->d_phi.reserve(need_phi));
+    EEA_HIP(e->d_sum.reserve(need_sum));
+  }
+  R* const d_mass = static_cast<R*>(e->d_sum.p);
+  R* const d_partials = d_mass + 1;
   int n_partials = 0;
-  EEA_HIP(eea::launch_target_fill<R>(static_cast<const R*>(e->d_xs.p), static_cast<const R*>(e->d_ys.p),
-                                     nx, ny, static_cast<const R*>(e->d_gauss.p), ng,
-                                     static_cast<R*>(e->d_phi.p), d_partials, &n_partials, s));
-  EEA_HIP(eea::launch_reduce_sum<R>(d_partials, n_partials, static_cast<R*>(e->d_sum.p), s));
-  EEA_HIP(eea::launch_scale_by_inv<R>(static_cast<R*>(e->d_phi.p), P, static_cast<const R*>(e->d_sum.p), s));
-  EEA_HIP(eea::launch_spatial_coeff<R>(static_cast<const R*>(e->d_phi.p), nx, ny, e->K,
-                                       static_cast<const R*>(e->d_cx.p), static_cast<const R*>(e->d_cy.p),
-                                       static_cast<R*>(e->d_work.p), static_cast<R*>(e->d_phik.p), s));
-  EEA_HIP(hipStreamSynchronize(s));
+  if (ng <= eea::kMaxGaussArgs) {
+    eea::GaussArgs<R> ga;
+    std::memset(&ga, 0, sizeof(ga));
+    ga.n = ng;
+    for (int i = 0; i < ng; ++i) {
+      for (int c = 0; c < 4; ++c) ga.g[i][c] = g[4 * i + c];
+    }
+    n_partials = fill_blocks_args;
+    // the fill and (when the domain changed) the two axis tables in ONE launch
+    EEA_HIP(eea::launch_target_fill_args<R>(static_cast<const R*>(e->d_axis.p), nx, ny, ga,
+                                            static_cast<R*>(e->d_phi.p), d_partials, e->K,
+                                            static_cast<R>(eea::kPi / e->lx), static_cast<R>(eea::kPi / e->ly),
+                                            tables_stale ? static_cast<R*>(e->d_cx.p) : nullptr,
+                                            static_cast<R*>(e->d_cy.p), s));
+    if (tables_stale) {
+      e->tab_nx = nx;
+      e->tab_ny = ny;
+      e->tab_lx = e->lx;
+      e->tab_ly = e->ly;
+    }
+  } else {
+    // more Gaussians than the kernel arguments hold: parameters through a device buffer (one more sync)
+    EEA_HIP(e->d_gauss.reserve(sizeof(R) * g.size()));
+    EEA_HIP(hipMemcpyAsync(e->d_gauss.p, g.data(), sizeof(R) * g.size(), hipMemcpyHostToDevice, s));
+    EEA_HIP(hipStreamSynchronize(s));
+    EEA_HIP(eea::launch_target_fill<R>(static_cast<const R*>(e->d_axis.p), static_cast<const R*>(e->d_axis.p),
+                                       nx, ny, static_cast<const R*>(e->d_gauss.p), ng,
+                                       static_cast<R*>(e->d_phi.p), d_partials, &n_partials, s));
+  }
+  // phi_k = spatialCoeff(phi / sum(phi)) = spatialCoeff(phi) / sum(phi)  (target.cpp:87, basis.cpp:122-133)
+  EEA_HIP(eea::launch_spatial_coeff_normalised<R>(static_cast<const R*>(e->d_phi.p), nx, ny, e->K,
+                                                  static_cast<const R*>(e->d_cx.p), static_cast<const R*>(e->d_cy.p),
+                                                  static_cast<R*>(e->d_work.p), static_cast<R*>(e->d_phik.p),
+                                                  d_partials, n_partials, d_mass, s));
+  st = wait_stream_spin(e, s);
+  if (st != EEA_OK) return st;
   e->have_phik = true;
   e->have_fill_grid = true;
+  e->phi_is_raw = true;
   return EEA_OK;
 }
 
@@ -377,10 +451,12 @@ eea_status upload_entropy_table(eea_engine* e, hipStream_t s)
     const int cell = static_cast<int>(static_cast<int8_t>(static_cast<uint8_t>(b)));
     lut[b] = static_cast<R>(cell_entropy(static_cast<double>(cell) / 100.0));  // getCell: grid.cpp:176-184
   }
-  EEA_HIP(e->d_lut.reserve(sizeof(R) * 256));
   EEA_HIP(e->d_raw.reserve(sizeof(R) * e->K2));
+  if (e->have_lut) return EEA_OK;
+  EEA_HIP(e->d_lut.reserve(sizeof(R) * 256));
   EEA_HIP(hipMemcpyAsync(e->d_lut.p, lut.data(), sizeof(R) * 256, hipMemcpyHostToDevice, s));
   EEA_HIP(hipStreamSynchronize(s));
+  e->have_lut = true;
   return EEA_OK;
 }
 
@@ -491,10 +567,11 @@ void eea_destroy(eea_engine* e)
     (void)hipStreamSynchronize(e->stream1);
     (void)hipStreamDestroy(e->stream1);
   }
-  DevBuf* bufs[] = { &e->d_phik, &e->d_lamdak, &e->d_phi, &e->d_xs, &e->d_ys, &e->d_cx, &e->d_cy,
+  DevBuf* bufs[] = { &e->d_phik, &e->d_lamdak, &e->d_phi, &e->d_axis, &e->d_cx, &e->d_cy,
                      &e->d_work, &e->d_gauss, &e->d_sum, &e->d_ut1, &e->d_traj1, &e->d_mem1,
                      &e->d_lut, &e->d_raw, &e->d_occ };
   for (DevBuf* b : bufs) b->release();
+  if (e->ev_done) (void)hipEventDestroy(e->ev_done);
   if (e->h_mail) (void)hipHostFree(e->h_mail);
   if (e->h_stage) (void)hipHostFree(e->h_stage);
   delete e;
@@ -710,7 +787,20 @@ eea_status eea_get_target_grid(eea_engine* e, double* h_phi_vals)
   if (e->d_phi.p == nullptr || e->nx == 0 || !e->have_fill_grid) {
     return fail(EEA_ERR_NO_TARGET, "no Target::fill grid on the device (explicit / occupancy targets are not kept)");
   }
-  return download_reals(e, e->d_phi.p, static_cast<size_t>(e->nx) * e->ny, h_phi_vals);
+  const size_t P = static_cast<size_t>(e->nx) * e->ny;
+  eea_status st = download_reals(e, e->d_phi.p, P, h_phi_vals);
+  if (st != EEA_OK || !e->phi_is_raw) return st;
+  // the device keeps the un-normalised grid and its mass; phi_vals / sum(phi_vals) as target.cpp:87 forms it
+  double mass = 0.0;
+  st = download_reals(e, e->d_sum.p, 1, &mass);
+  if (st != EEA_OK) return st;
+  if (e->f32) {
+    const float m = static_cast<float>(mass);
+    for (size_t i = 0; i < P; ++i) h_phi_vals[i] = static_cast<double>(static_cast<float>(h_phi_vals[i]) / m);
+  } else {
+    for (size_t i = 0; i < P; ++i) h_phi_vals[i] = h_phi_vals[i] / mass;
+  }
+  return EEA_OK;
 }
 
 eea_status eea_control_batch(eea_engine* e, unsigned B, const eea_batch_io* io, void* stream)

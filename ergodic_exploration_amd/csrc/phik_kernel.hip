@@ -82,6 +82,72 @@ __global__ __launch_bounds__(kBlock) void cos_table_kernel(const R* __restrict__
   out[transpose ? (i * K + k) : idx] = v;
 }
 
+// both tables of a rebuild in one launch: cx[k * nx + i] and the transposed y table cy[i * K + k]; the two axes
+// share the coordinate sequence (both start at 0 and add the resolution, ergodic_control.hpp:387-408)
+template <typename R>
+__global__ __launch_bounds__(kBlock) void axis_tables_kernel(const R* __restrict__ coord, int nx, int ny, int K,
+                                                             R pi_lx, R pi_ly, R* __restrict__ cx,
+                                                             R* __restrict__ cy)
+{
+  const int idx = blockIdx.x * kBlock + threadIdx.x;
+  const int nxk = nx * K;
+  if (idx < nxk) {
+    const int k = idx / nx, i = idx - k * nx;
+    cx[idx] = cos_r((static_cast<R>(k) * pi_lx) * coord[i]);
+  } else if (idx < nxk + ny * K) {
+    const int t = idx - nxk;
+    const int k = t / ny, i = t - k * ny;
+    cy[i * K + k] = cos_r((static_cast<R>(k) * pi_ly) * coord[i]);
+  }
+}
+
+// Target::fill without the normalisation, Gaussians passed by value (no upload, no synchronisation):
+// kFillPerThread grid points per thread, one partial sum of phi per workgroup (fixed order).  The workgroups
+// beyond fill_blocks compute the two axis tables of the rebuild (axis_tables_kernel's job) in the same launch.
+template <typename R>
+__global__ __launch_bounds__(kBlock) void target_fill_args_kernel(const R* __restrict__ coord, int nx, int ny,
+                                                                  const GaussArgs<R> ga, R* __restrict__ phi,
+                                                                  R* __restrict__ partials, int fill_blocks, int K,
+                                                                  R pi_lx, R pi_ly, R* __restrict__ cx,
+                                                                  R* __restrict__ cy)
+{
+  __shared__ R s_w[kBlock / kWave];
+  if (static_cast<int>(blockIdx.x) >= fill_blocks) {  // whole workgroup
+    const int idx = (blockIdx.x - fill_blocks) * kBlock + threadIdx.x;
+    const int nxk = nx * K;
+    if (idx < nxk) {
+      const int k = idx / nx, i = idx - k * nx;
+      cx[idx] = cos_r((static_cast<R>(k) * pi_lx) * coord[i]);
+    } else if (idx < nxk + ny * K) {
+      const int t = idx - nxk;
+      const int k = t / ny, i = t - k * ny;
+      cy[i * K + k] = cos_r((static_cast<R>(k) * pi_ly) * coord[i]);
+    }
+    return;
+  }
+  const size_t P = static_cast<size_t>(nx) * ny;
+  const size_t base = static_cast<size_t>(blockIdx.x) * (kBlock * kFillPerThread);
+  R acc = R(0);
+#pragma unroll 4
+  for (int r = 0; r < kFillPerThread; ++r) {
+    const size_t q = base + static_cast<size_t>(r) * kBlock + threadIdx.x;
+    if (q < P) {
+      const int iy = static_cast<int>(q / nx), ix = static_cast<int>(q - static_cast<size_t>(iy) * nx);
+      const R x = coord[ix], y = coord[iy];
+      R val = R(0);
+      for (int g = 0; g < ga.n; ++g) {
+        const R dx = x - ga.g[g][0], dy = y - ga.g[g][1];
+        // dot(diff.t() * cov_inv, diff) with a diagonal cov_inv (target.hpp:101)
+        val += exp_r(R(-0.5) * ((dx * ga.g[g][2]) * dx + (dy * ga.g[g][3]) * dy));
+      }
+      phi[q] = val;
+      acc += val;
+    }
+  }
+  const R t = block_sum(acc, s_w);
+  if (threadIdx.x == 0) partials[blockIdx.x] = t;
+}
+
 // un-normalised sum of axis-aligned Gaussians on the grid; gauss: [n][4] = mean (Fourier
 // frame) and diagonal of the inverse covariance
 template <typename R>
@@ -418,6 +484,32 @@ __global__ __launch_bounds__(kBlock) void sum_partials_kernel(const R* __restric
 }
 constexpr int kModesPerSumBlock = kBlock / kWave;
 
+// the same with the normalisation of Target::fill (target.cpp:87) folded in: the coefficient sums of the
+// UN-normalised grid divided by its mass (spatialCoeff is linear in phi_vals); every wavefront adds the mass
+// partials itself, in a fixed order; mass_out[0] receives the mass (for eea_get_target_grid)
+template <typename R>
+__global__ __launch_bounds__(kBlock) void sum_partials_norm_kernel(const R* __restrict__ partials, int n_parts,
+                                                                   int K2, const R* __restrict__ mass_partials,
+                                                                   int n_mass, R* __restrict__ out,
+                                                                   R* __restrict__ mass_out)
+{
+  const int lane = threadIdx.x & (kWave - 1);
+  const int m = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+  if (m >= K2) return;  // whole wavefront
+  R s = R(0), w = R(0);
+  for (int b = lane; b < n_parts; b += kWave) s += partials[static_cast<size_t>(b) * K2 + m];
+  for (int b = lane; b < n_mass; b += kWave) w += mass_partials[b];
+#pragma unroll
+  for (int o = kWave / 2; o > 0; o >>= 1) {
+    s += __shfl_down(s, o, kWave);
+    w += __shfl_down(w, o, kWave);
+  }
+  if (lane == 0) {
+    out[m] = s / w;
+    if (m == 0) mass_out[0] = w;
+  }
+}
+
 constexpr int kPointChunk = 128;        // points staged in LDS at a time
 constexpr int kPointsPerBlock = 2048;   // points one workgroup reduces
 
@@ -512,6 +604,31 @@ hipError_t launch_cos_tables_t(const R* d_coord, int n, int K, R pi_over_l, R* d
   const int total = n * K;
   hipLaunchKernelGGL(cos_table_kernel<R>, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), 0, s,
                      d_coord, n, K, pi_over_l, d_out, 1);
+  return hipGetLastError();
+}
+
+template <typename R>
+hipError_t launch_axis_tables(const R* d_coord, int nx, int ny, int K, R pi_lx, R pi_ly, R* d_cx, R* d_cy,
+                              hipStream_t s)
+{
+  const int total = (nx + ny) * K;
+  hipLaunchKernelGGL(axis_tables_kernel<R>, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d_coord, nx,
+                     ny, K, pi_lx, pi_ly, d_cx, d_cy);
+  return hipGetLastError();
+}
+
+int target_fill_blocks(size_t P) { return static_cast<int>((P + kBlock * kFillPerThread - 1) / (kBlock * kFillPerThread)); }
+
+template <typename R>
+hipError_t launch_target_fill_args(const R* d_coord, int nx, int ny, const GaussArgs<R>& ga, R* d_phi,
+                                   R* d_partials, int K, R pi_lx, R pi_ly, R* d_cx, R* d_cy, hipStream_t s)
+{
+  const size_t P = static_cast<size_t>(nx) * ny;
+  const int fill_blocks = target_fill_blocks(P);
+  // d_cx == nullptr: the tables are current, fill only
+  const int tab_blocks = d_cx != nullptr ? ((nx + ny) * K + kBlock - 1) / kBlock : 0;
+  hipLaunchKernelGGL(target_fill_args_kernel<R>, dim3(fill_blocks + tab_blocks), dim3(kBlock), 0, s, d_coord, nx,
+                     ny, ga, d_phi, d_partials, fill_blocks, K, pi_lx, pi_ly, d_cx, d_cy);
   return hipGetLastError();
 }
 
@@ -627,7 +744,8 @@ namespace
 {
 template <typename R, typename IN>
 hipError_t launch_spatial_generic(const IN* d_in, int nx, int ny, int K, const R* d_cx, const R* d_cy,
-                                  const R* d_lut, R* d_work, R* d_phik, hipStream_t s)
+                                  const R* d_lut, R* d_work, R* d_phik, hipStream_t s,
+                                  const R* d_mass_partials = nullptr, int n_mass = 0, R* d_mass = nullptr)
 {
   constexpr bool kCells = !std::is_same<IN, R>::value;
   constexpr int kind = kCells ? kKindCells : (sizeof(R) == 8 ? kKindF64 : kKindF32);
@@ -657,8 +775,14 @@ hipError_t launch_spatial_generic(const IN* d_in, int nx, int ny, int K, const R
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(sum_partials_kernel<R>, dim3((K2 + kModesPerSumBlock - 1) / kModesPerSumBlock), dim3(kBlock), 0, s,
-                       d_work, col_tiles * row_tiles, K2, R(1), d_phik);
+    if (d_mass_partials != nullptr) {
+      hipLaunchKernelGGL(sum_partials_norm_kernel<R>, dim3((K2 + kModesPerSumBlock - 1) / kModesPerSumBlock),
+                         dim3(kBlock), 0, s, d_work, col_tiles * row_tiles, K2, d_mass_partials, n_mass, d_phik,
+                         d_mass);
+    } else {
+      hipLaunchKernelGGL(sum_partials_kernel<R>, dim3((K2 + kModesPerSumBlock - 1) / kModesPerSumBlock), dim3(kBlock), 0, s,
+                         d_work, col_tiles * row_tiles, K2, R(1), d_phik);
+    }
     return hipGetLastError();
   }
 }
@@ -679,6 +803,15 @@ hipError_t launch_spatial_coeff(const R* d_phi, int nx, int ny, int K, const R* 
                                 R* d_work, R* d_phik, hipStream_t s)
 {
   return launch_spatial_generic<R, R>(d_phi, nx, ny, K, d_cx, d_cy, nullptr, d_work, d_phik, s);
+}
+
+template <typename R>
+hipError_t launch_spatial_coeff_normalised(const R* d_phi_raw, int nx, int ny, int K, const R* d_cx, const R* d_cy,
+                                           R* d_work, R* d_phik, const R* d_mass_partials, int n_mass, R* d_mass,
+                                           hipStream_t s)
+{
+  return launch_spatial_generic<R, R>(d_phi_raw, nx, ny, K, d_cx, d_cy, nullptr, d_work, d_phik, s, d_mass_partials,
+                                      n_mass, d_mass);
 }
 
 template <typename R>
@@ -720,6 +853,11 @@ hipError_t launch_point_coeff(const R* d_x, const R* d_y, const R* d_w, unsigned
 }
 
 #define EEA_INSTANTIATE(R)                                                                          \
+  template hipError_t launch_axis_tables<R>(const R*, int, int, int, R, R, R*, R*, hipStream_t);    \
+  template hipError_t launch_target_fill_args<R>(const R*, int, int, const GaussArgs<R>&, R*, R*,   \
+                                                 int, R, R, R*, R*, hipStream_t);                   \
+  template hipError_t launch_spatial_coeff_normalised<R>(const R*, int, int, int, const R*, const R*, R*, R*, \
+                                                         const R*, int, R*, hipStream_t);           \
   template hipError_t launch_cos_tables<R>(const R*, int, int, R, R*, hipStream_t);                 \
   template hipError_t launch_cos_tables_t<R>(const R*, int, int, R, R*, hipStream_t);               \
   template hipError_t launch_target_fill<R>(const R*, const R*, int, int, const R*, int, R*, R*,    \
