@@ -5,6 +5,7 @@
     (tests/golden/survey_anchors.json).
 CPU only.  The oracle is test infrastructure; nothing here touches the product path."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -221,3 +222,72 @@ def test_missing_target_gives_nan():
     ec.set_target(np.zeros((0, 2)), np.zeros((0, 2)))
     u = ec.control((0, 12, 0, 6), [1, 1, 0.3])
     assert np.isnan(u).any()
+
+
+# ---- per-stage fixtures and the independent numpy restatement (round 2) -------------------------------------
+import glob as _glob
+
+STAGE_FIXTURES = sorted(_glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stages_*.npz")))
+
+
+def _load_stage_fixture(path):
+    z = np.load(path)
+    return {k: z[k] for k in z.files}
+
+
+def test_stage_fixtures_exist_for_every_survey_config():
+    names = {os.path.basename(p)[len("stages_"):-len(".npz")] for p in STAGE_FIXTURES}
+    assert {"cfg1_omni_K5_T5", "yaml_omni_K10_T50", "yaml_cart_K10_T50", "cfg2_cart_K10_T20",
+            "metric_cart_K10_T200", "metric_omni_K10_T200_mem", "cfg3_omni_K20_T250"} <= names
+
+
+@pytest.mark.parametrize("path", STAGE_FIXTURES, ids=[os.path.basename(p)[7:-4] for p in STAGE_FIXTURES])
+def test_numpy_restatement_reproduces_stage_fixtures(path):
+    """The second restatement (tests/np_restatement.py, written from the reference's lines) against the
+    fixtures the C oracle generated (tools/gen_golden.py): every stage of three consecutive control() calls to
+    1e-12, and phi_k of the configuration (Target::fill + spatialCoeff) to 1e-12."""
+    from tests import np_restatement as nr
+    f = _load_stage_fixture(path)
+    dt, horizon, res, w, K = f["params"]
+    K = int(K)
+    model = nr.Omni() if str(f["model"]) == "omni" else nr.SimpleCart()
+    Rinv = np.diag(f["Rinv_diag"])
+    lim = f["limits"]
+    bounds = tuple(f["bounds"])
+    phik, _, _, _ = nr.config_target_phik(bounds, res, K, f["means"], f["sigmas"])
+    assert np.abs(phik - f["phik"]).max() <= 1e-12
+    assert np.abs(nr.Basis(bounds[1] - bounds[0], bounds[3] - bounds[2], K).lamdak - f["lamdak"]).max() <= 1e-15
+    mem = f["mem_cols"] if f["mem_cols"].shape[1] else None
+    for call in range(3):
+        st = nr.control_stages(model, dt, horizon, w, K, Rinv, -lim, lim, bounds, f["phik"], f["pose"],
+                               f["ut_in_%d" % call], mem)
+        for k in ("traj", "ck", "edx", "bdx", "rhot", "ut", "u0"):
+            d = st[k] - f["%s_%d" % (k, call)]
+            if k == "traj":
+                d[2] = (d[2] + np.pi) % (2 * np.pi) - np.pi
+            scale = max(1.0, float(np.abs(f["%s_%d" % (k, call)]).max()))
+            assert np.abs(d).max() <= 1e-12 * scale, (k, call, float(np.abs(d).max()))
+        # the chain of calls in the fixture is the oracle's own: ut after call n is ut_in of call n + 1
+        if call < 2:
+            assert np.array_equal(f["ut_%d" % call], f["ut_in_%d" % (call + 1)])
+
+
+def test_stage_fixtures_are_what_the_oracle_produces_now():
+    """tools/gen_golden.py is deterministic: regenerating one fixture in memory gives the committed bytes' values
+    (guards against an oracle edit that silently changes results without regenerating / re-pinning)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_golden", os.path.join(root, "tools", "gen_golden.py"))
+    gg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gg)
+    import tempfile
+    keep = gg.GOLDEN
+    with tempfile.TemporaryDirectory() as tmp:
+        gg.GOLDEN = tmp
+        try:
+            out = gg.generate("yaml_omni_K10_T50")
+        finally:
+            gg.GOLDEN = keep
+    f = _load_stage_fixture(os.path.join(keep, "stages_yaml_omni_K10_T50.npz"))
+    for k in ("phik", "traj_0", "ck_1", "rhot_2", "ut_2", "u0_2"):
+        assert np.array_equal(out[k], f[k]), k
