@@ -61,8 +61,11 @@ def parse():
     ap.add_argument("--no-latency", action="store_true", help="skip the B = 1 dependent-call leg")
     ap.add_argument("--no-phik", action="store_true", help="skip the phi_k legs (roofline_phik)")
     ap.add_argument("--phik-grid", type=int, default=16384, help="side of the square fp64 grid of the phi_k leg")
-    ap.add_argument("--agent-groups", type=int, default=1,
-                    help="split the rank's agents into this many groups, each launched on its own HIP stream")
+    ap.add_argument("--agent-groups", type=int, default=2,
+                    help="split the rank's agents into this many contiguous groups, each stepped by its own "
+                         "eea_control_batch call on its own HIP stream: agents are independent, and the head of one "
+                         "group's launch (loading the controls) overlaps the body of the other's (measured: "
+                         "profiles/r02_ablation.txt); 1 = one launch per pass")
     return ap.parse_args()
 
 
@@ -422,8 +425,9 @@ def main():
         flops_per_opt = 2 * K * K * N + 4 * K * K * T + (4 * K + 140) * T  # SURVEY.md 8(d) "W"
         launch_s = pass_ms * 1e-3
         Bl = gb[1] - gb[0]   # agents per launch (group 0, whose stream carries the events)
-        hbm_gbs = bytes_per_opt * Bl / launch_s / 1e9
-        tflops = flops_per_opt * Bl / launch_s / 1e12
+        # G launches (one per agent group) run concurrently, each taking launch_s: chip-level rate = G x per-launch
+        hbm_gbs = G * bytes_per_opt * Bl / launch_s / 1e9
+        tflops = G * flops_per_opt * Bl / launch_s / 1e12
         traffic, traffic_source = None, None
         for name in ("r02_control_pmc.json", "r01_control_pmc.json"):
             pmc = os.path.join(ROOT, "profiles", name)
@@ -432,9 +436,9 @@ def main():
             try:
                 with open(pmc) as f:
                     rec = json.load(f)
-                if (rec.get("agents") == Bl and rec.get("T") == T and rec.get("K") == K
+                if (rec.get("agents") == B and rec.get("T") == T and rec.get("K") == K
                         and rec.get("precision") == args.precision):
-                    traffic = rec.get("hbm_bytes_per_launch")
+                    traffic = rec.get("hbm_bytes_per_launch") * Bl / B  # per launch of Bl of the B agents
                     traffic_source = ("profiles/%s (separate rocprofv3 --pmc passes of this command; NOT measured "
                                       "in this run)" % name)
                     break
@@ -462,13 +466,14 @@ def main():
                          "achieved": tflops, "peak": vpeak, "unit": "TFLOP/s", "frac": tflops / vpeak,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "flops_per_launch": flops_per_opt * Bl, "launch_ms": pass_ms, "agents_per_launch": Bl,
-                         "concurrent_launches": G,
+                         "concurrent_launches": G, "achieved_per_launch": tflops / G,
                          "note": "the control kernel is vector-ALU / transcendental bound, not HBM bound (SURVEY.md "
                                  "8(d)); W = 2K^2N + 4K^2T + (4K+140)T flop per optimisation (reference formulation)"},
             "roofline_hbm": {"bound": "hbm", "kernel": "control kernel", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic,
                              "traffic_source": traffic_source, "bytes_per_launch": bytes_per_opt * Bl,
-                             "launch_ms": pass_ms},
+                             "launch_ms": pass_ms, "agents_per_launch": Bl, "concurrent_launches": G,
+                             "achieved_per_launch": hbm_gbs / G},
         }
         if exchange is not None:
             out["exchange"] = exchange

@@ -649,6 +649,9 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_k
   }
   R r2[kMaxS], cth[kMaxS], sth[kMaxS];
   {
+    // opaque copy of the controls' address: the compiler must not recognise (and keep alive) the earlier loads
+    const R* ut_again = ut;
+    asm volatile("" : "+v"(ut_again));
     R s2 = R(0);
 #pragma unroll
     for (int j = kMaxS - 1; j >= 0; --j) {
@@ -657,13 +660,23 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_k
       if (j < S) {
         cth[j] = s_cp[j * kWave + lane];
         sth[j] = s_sp[j * kWave + lane];
+        // the (shifted) controls of this step again, from L2: carried in registers since the load they would
+        // be spilled to scratch through the contraction and the gradient (20 MB of HBM traffic per launch)
+        R vxj = R(0), vyj = R(0);
+        {
+          const int src = i0 + j + 1;
+          if (src < T) {
+            vxj = ut_again[3 * src + 0];
+            if (MODEL == kModelOmni) vyj = ut_again[3 * src + 1];
+          }
+        }
         R a02, a12;
         if (MODEL == kModelOmni) {
-          a02 = -vx[j] * sth[j] - vy[j] * cth[j];
-          a12 = vx[j] * cth[j] - vy[j] * sth[j];
+          a02 = -vxj * sth[j] - vyj * cth[j];
+          a12 = vxj * cth[j] - vyj * sth[j];
         } else {
-          a02 = -vx[j] * sth[j];
-          a12 = vx[j] * cth[j];
+          a02 = -vxj * sth[j];
+          a12 = vxj * cth[j];
         }
         // rho_{i+1} = rho_i - dt g_i (rows 0,1)
         const R sE = a02 * (r0[j] - dt * g0[j]) + a12 * (r1[j] - dt * g1[j]);

@@ -395,7 +395,9 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
     const char* v = std::getenv("EEA_CONTROL_PATH");
     return v != nullptr && std::strcmp(v, "workgroup") == 0;
   }();
-  bool use_wave = !force_workgroup && eea::control_wave_eligible<R>(p, rollout_only);
+  // the single-agent entry (eea_control / eea_opt_traj: one agent, latency) keeps four wavefronts per agent;
+  // batches take the throughput kernel
+  bool use_wave = !force_workgroup && e->mail_done == nullptr && eea::control_wave_eligible<R>(p, rollout_only);
 #ifdef EEA_AB_BUILD
   if (e->impl_v1) use_wave = false;
   if (d_stamps != nullptr && !use_wave && sizeof(R) != 8) return fail(EEA_ERR_UNSUPPORTED, "phase timing is built for fp64 only");

@@ -1,0 +1,167 @@
+// AgentBatch<ModelT>: N independent ErgodicControl<ModelT> agents of one rank, resident on one GPU, stepped with
+// ONE eea_control_batch launch per receding-horizon step (or two half-batch launches on two HIP streams, whose
+// launches overlap: agents are independent), plus the exchange steps of a multi-GPU agent batch.
+//
+// No counterpart in the single-agent reference: every agent is exactly one reference controller
+// (include/ergodic_exploration/ergodic_control.hpp:72-185) with the same constructor parameters; the sharding
+// (one process per GPU, contiguous agent blocks) and the c_k exchange follow the decentralised ergodic control
+// the reference cites (README.md:225-227).  Everything goes through the C ABI (include/ergodic_amd.h); the
+// RCCL communicator is the C ABI's eea_comm (no Python, no torch).
+#pragma once
+
+#include <memory>
+#include <stdexcept>
+#include <vector>
+
+#include <ergodic_exploration/ergodic_control.hpp>
+
+namespace ergodic_exploration
+{
+template <class ModelT>
+class AgentBatch
+{
+public:
+  // the constructor arguments of ErgodicControl (minus the host-side replay buffer sizes) + the agent count of
+  // THIS rank; comm == nullptr: single GPU
+  AgentBatch(unsigned int n_agents, double dt, double horizon, double resolution, double exploration_weight,
+             unsigned int num_basis, const mat& Rinv, const vec& umin, const vec& umax, eea_comm* comm = nullptr,
+             unsigned int groups = 2)
+    : n_(n_agents), comm_(comm), groups_(groups < 1 ? 1 : (groups > 2 ? 2 : groups))
+  {
+    eea_config cfg{};
+    cfg.model = device_model<ModelT>::value;
+    cfg.precision = EEA_PREC_F64;
+    cfg.device = device_ordinal();
+    cfg.dt = dt;
+    cfg.horizon = horizon;
+    cfg.resolution = resolution;
+    cfg.expl_weight = exploration_weight;
+    cfg.num_basis = num_basis;
+    for (int i = 0; i < 9; ++i) cfg.Rinv[i] = Rinv.memptr()[i];
+    for (int i = 0; i < 3; ++i) {
+      cfg.umin[i] = umin(i);
+      cfg.umax[i] = umax(i);
+    }
+    eea_engine* e = nullptr;
+    throw_on_error(eea_create(&cfg, &e));
+    engine_ = std::shared_ptr<eea_engine>(e, eea_destroy);
+    steps_ = eea_steps(e);
+    modes_ = eea_num_modes(e);
+    hip_check(hipSetDevice(device_ordinal()));
+    alloc(d_pose_, sizeof(double) * 3 * n_);
+    alloc(d_ut_, sizeof(double) * 3 * steps_ * n_);
+    alloc(d_u0_, sizeof(double) * 3 * n_);
+    alloc(d_ck_, sizeof(double) * modes_ * n_);
+    alloc(d_cbar_, sizeof(double) * modes_);
+    hip_check(hipMemset(d_ut_.get(), 0, sizeof(double) * 3 * steps_ * n_));  // ut_ starts at zero (:201)
+    for (unsigned int g = 0; g < groups_; ++g) {
+      hipStream_t s = nullptr;
+      hip_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+      streams_.push_back(s);
+    }
+    if (comm_ == nullptr) {  // local communicator: the consensus is the mean over this rank's agents
+      eea_comm* c = nullptr;
+      throw_on_error(eea_comm_create(device_ordinal(), 1, 0, nullptr, &c));
+      own_comm_ = std::shared_ptr<eea_comm>(c, eea_comm_destroy);
+      comm_ = c;
+    }
+  }
+  ~AgentBatch()
+  {
+    for (hipStream_t s : streams_) {
+      (void)hipStreamSynchronize(s);
+      (void)hipStreamDestroy(s);
+    }
+  }
+  AgentBatch(const AgentBatch&) = delete;
+  AgentBatch& operator=(const AgentBatch&) = delete;
+
+  void setTarget(const Target& target)
+  {
+    std::vector<double> mu, sg;
+    target.flatten(mu, sg);
+    throw_on_error(eea_set_target_gaussians(engine_.get(), static_cast<unsigned>(mu.size() / 2), mu.data(), sg.data()));
+  }
+  void configTarget(const GridMap& grid)
+  {
+    sync();
+    throw_on_error(eea_config_domain(engine_.get(), grid.xmin(), grid.xmax(), grid.ymin(), grid.ymax(), nullptr,
+                                     streams_[0]));
+  }
+  // poses: 3 x n_agents (column per agent, map frame)
+  void setPoses(const mat& poses)
+  {
+    if (poses.n_rows() != 3 || poses.n_cols() != n_) throw std::invalid_argument("poses must be 3 x n_agents");
+    sync();
+    hip_check(hipMemcpy(d_pose_.get(), poses.memptr(), sizeof(double) * 3 * n_, hipMemcpyHostToDevice));
+  }
+  // One receding-horizon optimisation of every agent (ErgodicControl::control per agent).  consensus: the
+  // gradient uses the mean c_k of ALL agents of all ranks from the previous step (decentralised ergodic control;
+  // one all-reduce of K^2 + 1 reals per step on its own ordering, overlapped with nothing here: latency ~ 10 us)
+  void control(bool consensus = false)
+  {
+    const void* shared = (consensus && have_cbar_) ? d_cbar_.get() : nullptr;
+    for (unsigned int g = 0; g < groups_; ++g) {
+      const unsigned int first = (n_ * g) / groups_, last = (n_ * (g + 1)) / groups_;
+      if (last == first) continue;
+      eea_batch_io io{};
+      io.d_pose = static_cast<const double*>(d_pose_.get()) + 3 * first;
+      io.d_ut = static_cast<double*>(d_ut_.get()) + static_cast<size_t>(3) * steps_ * first;
+      io.d_u0 = static_cast<double*>(d_u0_.get()) + 3 * first;
+      io.d_ck = static_cast<double*>(d_ck_.get()) + static_cast<size_t>(modes_) * first;
+      io.d_ck_shared = shared;
+      throw_on_error(eea_control_batch(engine_.get(), last - first, &io, streams_[g]));
+    }
+    if (consensus) {
+      sync();  // every group's c_k is complete
+      throw_on_error(eea_comm_consensus_ck(engine_.get(), comm_, n_, d_ck_.get(), d_cbar_.get(), streams_[0]));
+      have_cbar_ = true;
+    }
+  }
+  // first twists of the updated control signals, 3 x n_agents
+  mat controls()
+  {
+    sync();
+    mat u(3, n_);
+    hip_check(hipMemcpy(u.memptr(), d_u0_.get(), sizeof(double) * 3 * n_, hipMemcpyDeviceToHost));
+    return u;
+  }
+  // all agents' c_k of all ranks, K^2 x (nranks * n_agents), rank order (equal shards): one ncclAllGather
+  mat gatherTrajCoeff()
+  {
+    sync();
+    const unsigned int world = static_cast<unsigned int>(eea_comm_nranks(comm_));
+    Dev all;
+    alloc(all, sizeof(double) * modes_ * n_ * world);
+    throw_on_error(eea_comm_allgather_ck(engine_.get(), comm_, n_, d_ck_.get(), all.get(), streams_[0]));
+    hip_check(hipStreamSynchronize(streams_[0]));
+    mat ck(modes_, n_ * world);
+    hip_check(hipMemcpy(ck.memptr(), all.get(), sizeof(double) * modes_ * n_ * world, hipMemcpyDeviceToHost));
+    return ck;
+  }
+  void sync()
+  {
+    for (hipStream_t s : streams_) hip_check(hipStreamSynchronize(s));
+  }
+  unsigned int agents() const { return n_; }
+  unsigned int steps() const { return steps_; }
+  eea_engine* engine() const { return engine_.get(); }
+
+private:
+  using Dev = std::shared_ptr<void>;
+  static void alloc(Dev& d, size_t bytes)
+  {
+    void* p = nullptr;
+    hip_check(hipMalloc(&p, bytes ? bytes : 1));
+    d = Dev(p, [](void* q) { (void)hipFree(q); });
+  }
+  unsigned int n_, steps_ = 0, modes_ = 0;
+  eea_comm* comm_;
+  std::shared_ptr<eea_comm> own_comm_;
+  unsigned int groups_;
+  std::shared_ptr<eea_engine> engine_;
+  Dev d_pose_, d_ut_, d_u0_, d_ck_, d_cbar_;
+  bool have_cbar_ = false;
+  std::vector<hipStream_t> streams_;
+};
+}  // namespace ergodic_exploration

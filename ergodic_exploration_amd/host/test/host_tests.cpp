@@ -10,6 +10,7 @@
 #include <string>
 
 #include <ergodic_exploration/dynamic_window.hpp>
+#include <ergodic_exploration/agent_batch.hpp>
 #include <ergodic_exploration/ergodic_control.hpp>
 
 using namespace ergodic_exploration;
@@ -389,6 +390,52 @@ static void test_ergodic_control()
   CHECK(threw);
 }
 
+// AgentBatch: every agent of a batched step equals a single-agent ErgodicControl run from the same state;
+// the exchange steps on a local communicator; the consensus input changes the controls
+static void test_agent_batch()
+{
+  const unsigned int N = 37;
+  mat Rinv(3, 3);
+  Rinv(0, 0) = 1.0;
+  Rinv(1, 1) = 1.0;
+  Rinv(2, 2) = 2.0;
+  const vec umin{ -1.0, -1.0, -2.0 }, umax{ 1.0, 1.0, 2.0 };
+  const GridMap grid(-1.0, 11.0, -1.0, 5.0, 0.05, GridData(240 * 120, 0));
+  const Target target({ Gaussian({ 2.5, 2.5 }, { 1.5, 1.5 }), Gaussian({ 8.5, 2.5 }, { 1.5, 1.5 }) });
+  AgentBatch<models::Omni> batch(N, 0.1, 5.0, 0.1, 1.0, 10, Rinv, umin, umax);
+  batch.setTarget(target);
+  batch.configTarget(grid);
+  mat poses(3, N);
+  for (unsigned int a = 0; a < N; ++a) {
+    poses(0, a) = 0.3 + 0.25 * a;
+    poses(1, a) = 0.5 + 0.1 * (a % 30);
+    poses(2, a) = -3.0 + 0.16 * a;
+  }
+  batch.setPoses(poses);
+  batch.control();
+  batch.control();
+  const mat u = batch.controls();
+  for (unsigned int a : { 0u, 5u, 36u }) {
+    ErgodicControl<models::Omni> ec(models::Omni(), Collision(0.7, 1.0, 0.2, 0.8), 0.1, 5.0, 0.1, 1.0, 10, 1000000,
+                                    100, Rinv, umin, umax);
+    ec.setTarget(target);
+    const vec x{ poses(0, a), poses(1, a), poses(2, a) };
+    ec.control(grid, x);
+    const vec ua = ec.control(grid, x);
+    for (int r = 0; r < 3; ++r) CHECK_NEAR(u(r, a), ua(r), 1e-12);
+  }
+  const mat ck = batch.gatherTrajCoeff();
+  CHECK(ck.n_rows() == 100 && ck.n_cols() == N);
+  CHECK_NEAR(ck(0, 3), 1.0, 1e-14);  // mode (0,0) of every agent's c_k is the mean of ones
+  batch.control(true);               // produces the consensus of this step ...
+  const mat u_own = batch.controls();
+  batch.control(true);               // ... which the next step's gradient uses
+  const mat u_cons = batch.controls();
+  double diff = 0.0;
+  for (unsigned int a = 0; a < N; ++a) diff += std::fabs(u_cons(0, a) - u_own(0, a)) + std::fabs(u_cons(2, a) - u_own(2, a));
+  CHECK(diff > 1e-6);
+}
+
 int main(int argc, char** argv)
 {
   const std::string mode = argc > 1 ? argv[1] : "cpu";
@@ -399,6 +446,7 @@ int main(int argc, char** argv)
   if (mode == "gpu") {
     test_device_ops();
     test_ergodic_control();
+    test_agent_batch();
   }
   std::printf("%s: %d checks, %d failures\n", mode.c_str(), g_checks, g_fail);
   return g_fail ? 1 : 0;
