@@ -292,37 +292,65 @@ def main():
     exchange_backend = "local (1 rank)"
     if use_dist and not args.no_exchange or args.force_exchange:
         if backend == "nccl" or not use_dist:
-            # the C ABI's own RCCL communicator: rank 0 creates the id, torch.distributed only carries it
-            uid = [capi.comm_unique_id() if rank == 0 else None]
+            # the C ABI's own RCCL communicator: rank 0 creates the id, torch.distributed only carries it.  If that
+            # fails on some rank, every rank falls back to torch.distributed's collectives (the run must not die
+            # with a secondary leg)
+            ok = 1
+            try:
+                uid = [capi.comm_unique_id() if rank == 0 else None]
+                if use_dist:
+                    dist.broadcast_object_list(uid, src=0)
+                comm = capi.Comm(device, world, rank, uid[0])
+            except Exception as exc:  # noqa: BLE001
+                sys.stderr.write("rank %d: eea_comm_create failed (%r); torch.distributed collectives instead\n" % (rank, exc))
+                ok = 0
             if use_dist:
-                dist.broadcast_object_list(uid, src=0)
-            comm = capi.Comm(device, world, rank, uid[0])
-            exchange_backend = "rccl through the C ABI (eea_comm_*)"
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                ok = int(flag.item())
+            if ok:
+                exchange_backend = "rccl through the C ABI (eea_comm_*)"
+            else:
+                if comm is not None:
+                    comm.close()
+                comm = None
+                exchange_backend = "rccl through torch.distributed (eea_comm_create failed)"
         else:
             exchange_backend = "gloo, staged through the host (ranks share a GPU: plumbing run)"
     if comm is None:
         comm_local = capi.Comm(device, 1, 0, None)
     d_all = None
 
+    cabi_comm = comm if comm is not None else (None if use_dist else comm_local)
+
     def exchange_consensus(slot):
-        """c_bar of pass `slot`'s c_k over ALL agents of all ranks -> d_cbar[slot], on the exchange stream"""
+        """c_bar of pass `slot`'s c_k over ALL agents of all ranks -> d_cbar[slot], beside the compute stream"""
+        if cabi_comm is not None:
+            # one call: the communicator's own stream waits for the pass, runs eea_ck_sum + all-reduce + divide
+            cabi_comm.consensus_ck_async(eng, B, d_ck[slot], d_cbar[slot], compute.cuda_stream, slot)
+            return
         xstream.wait_event(ev_ck[slot])
-        if comm is not None:
-            comm.consensus_ck(eng, B, d_ck[slot], d_cbar[slot], stream=xstream.cuda_stream)
+        if use_dist and backend == "nccl":
+            with torch.cuda.stream(xstream):
+                sums = torch.cat([d_ck[slot].sum(0), torch.tensor([float(B)], dtype=tdt, device="cuda")])
+                dist.all_reduce(sums)
+                d_cbar[slot].copy_(sums[:-1] / sums[-1])
         elif use_dist:
             with torch.cuda.stream(xstream):
                 sums = torch.cat([d_ck[slot].sum(0), torch.tensor([float(B)], dtype=tdt, device="cuda")]).cpu()
             dist.all_reduce(sums)
             with torch.cuda.stream(xstream):
                 d_cbar[slot].copy_((sums[:-1] / sums[-1]).cuda(), non_blocking=False)
-        else:
-            comm_local.consensus_ck(eng, B, d_ck[slot], d_cbar[slot], stream=xstream.cuda_stream)
         ev_x[slot].record(xstream)
 
     def exchange_allgather(slot):
-        xstream.wait_event(ev_ck[slot])
         if comm is not None:
-            comm.allgather_ck(eng, B, d_ck[slot], d_all[slot % 2], stream=xstream.cuda_stream)
+            comm.allgather_ck_async(eng, B, d_ck[slot], d_all[slot % 2], compute.cuda_stream, slot)
+            return
+        xstream.wait_event(ev_ck[slot])
+        if backend == "nccl":
+            with torch.cuda.stream(xstream):
+                dist.all_gather_into_tensor(d_all[slot % 2], d_ck[slot])
         else:
             with torch.cuda.stream(xstream):
                 h = d_ck[slot].cpu()
@@ -344,15 +372,23 @@ def main():
                                   mem_stride=args.n_mem, stream=a["stream"])
             return
         shared = None
+        in_c = (cabi_comm is not None) if leg == "consensus" else (comm is not None)  # events live in the C ABI
         if leg == "consensus" and i >= args.consensus_lag:
             src = (i - args.consensus_lag) % NB
-            compute.wait_event(ev_x[src])      # the consensus of pass i - lag has arrived
+            if in_c:
+                cabi_comm.wait(src, compute.cuda_stream)   # the consensus of pass i - lag has arrived
+            else:
+                compute.wait_event(ev_x[src])
             shared = d_cbar[src]
         if leg == "allgather" and i >= 2:
-            compute.wait_event(ev_x[(i - 2) % NB])  # the gather that read this slot's predecessor is done
+            if in_c:
+                comm.wait((i - 2) % NB, compute.cuda_stream)  # the gather that read this slot's predecessor is done
+            else:
+                compute.wait_event(ev_x[(i - 2) % NB])
         eng.control_batch(B, d_pose, d_ut, d_u0, mem_cols=d_mem, n_mem=d_nmem, mem_stride=args.n_mem,
                           ck=d_ck[slot], ck_shared=shared, stream=compute.cuda_stream)
-        ev_ck[slot].record(compute)
+        if not in_c:
+            ev_ck[slot].record(compute)
         if leg == "consensus":
             exchange_consensus(slot)
         else:

@@ -129,6 +129,9 @@ def lib():
         L.eea_comm_allgather_ck.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
         L.eea_comm_consensus_ck.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
         L.eea_comm_allreduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
+        L.eea_comm_consensus_ck_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.eea_comm_allgather_ck_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.eea_comm_wait.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.eea_rollout_batch.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]
         L.eea_control.argtypes = [C.c_void_p] + [C.c_double] * 4 + [C.c_void_p, C.c_void_p, C.c_uint,
@@ -430,6 +433,17 @@ class Comm:
     def consensus_ck(self, eng, B_local, ck_local, ck_shared, stream=None):
         check(lib().eea_comm_consensus_ck(eng.h, self.h, B_local, _ptr(ck_local), _ptr(ck_shared),
                                           C.c_void_p(stream or 0)))
+
+    def consensus_ck_async(self, eng, B_local, ck_local, ck_shared, compute_stream, slot):
+        check(lib().eea_comm_consensus_ck_async(eng.h, self.h, B_local, _ptr(ck_local), _ptr(ck_shared),
+                                                C.c_void_p(compute_stream or 0), slot))
+
+    def allgather_ck_async(self, eng, B_local, ck_local, ck_all, compute_stream, slot):
+        check(lib().eea_comm_allgather_ck_async(eng.h, self.h, B_local, _ptr(ck_local), _ptr(ck_all),
+                                                C.c_void_p(compute_stream or 0), slot))
+
+    def wait(self, slot, stream=None):
+        check(lib().eea_comm_wait(self.h, slot, C.c_void_p(stream or 0)))
 
     def allreduce_sum(self, eng, buf, n, stream=None):
         check(lib().eea_comm_allreduce_sum(eng.h, self.h, _ptr(buf), n, C.c_void_p(stream or 0)))

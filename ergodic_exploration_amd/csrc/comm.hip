@@ -119,6 +119,10 @@ struct eea_comm
   int device = 0, nranks = 1, rank = 0;
   void* d_sums = nullptr;  // K^2 + 1 reals of scratch for the consensus reduction
   size_t sums_cap = 0;
+  // asynchronous form: an exchange stream of its own beside the caller's compute stream, completion per slot
+  hipStream_t xstream = nullptr;
+  hipEvent_t ev_in = nullptr;
+  hipEvent_t ev_done[EEA_COMM_SLOTS] = {};
 };
 
 namespace
@@ -187,6 +191,14 @@ void eea_comm_destroy(eea_comm* c)
 {
   if (c == nullptr) return;
   (void)hipSetDevice(c->device);
+  if (c->xstream) {
+    (void)hipStreamSynchronize(c->xstream);
+    (void)hipStreamDestroy(c->xstream);
+  }
+  if (c->ev_in) (void)hipEventDestroy(c->ev_in);
+  for (hipEvent_t ev : c->ev_done) {
+    if (ev) (void)hipEventDestroy(ev);
+  }
   if (c->comm != nullptr && rccl().ok) (void)rccl().CommDestroy(c->comm);
   if (c->d_sums) (void)hipFree(c->d_sums);
   delete c;
@@ -246,6 +258,58 @@ eea_status eea_comm_consensus_ck(eea_engine* e, eea_comm* c, unsigned B_local, c
   if (st != EEA_OK) return st;
   if (rs == 4) EEA_HIP(launch_ck_mean<float>(c->d_sums, K2, d_ck_shared, s));
   else EEA_HIP(launch_ck_mean<double>(c->d_sums, K2, d_ck_shared, s));
+  return EEA_OK;
+}
+
+}  // extern "C"
+
+namespace
+{
+eea_status async_begin(eea_comm* c, void* compute_stream, int slot)
+{
+  if (c == nullptr || slot < 0 || slot >= EEA_COMM_SLOTS) return fail(EEA_ERR_INVALID_ARGUMENT, "bad communicator / slot");
+  EEA_HIP(hipSetDevice(c->device));
+  if (c->xstream == nullptr) {
+    EEA_HIP(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+    EEA_HIP(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+  }
+  if (c->ev_done[slot] == nullptr) EEA_HIP(hipEventCreateWithFlags(&c->ev_done[slot], hipEventDisableTiming));
+  // everything enqueued on the compute stream so far (the pass that produced c_k) comes first
+  EEA_HIP(hipEventRecord(c->ev_in, static_cast<hipStream_t>(compute_stream)));
+  EEA_HIP(hipStreamWaitEvent(c->xstream, c->ev_in, 0));
+  return EEA_OK;
+}
+}  // namespace
+
+extern "C" {
+
+eea_status eea_comm_consensus_ck_async(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_local,
+                                       void* d_ck_shared, void* compute_stream, int slot)
+{
+  eea_status st = async_begin(c, compute_stream, slot);
+  if (st != EEA_OK) return st;
+  st = eea_comm_consensus_ck(e, c, B_local, d_ck_local, d_ck_shared, c->xstream);
+  if (st != EEA_OK) return st;
+  EEA_HIP(hipEventRecord(c->ev_done[slot], c->xstream));
+  return EEA_OK;
+}
+
+eea_status eea_comm_allgather_ck_async(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_local,
+                                       void* d_ck_all, void* compute_stream, int slot)
+{
+  eea_status st = async_begin(c, compute_stream, slot);
+  if (st != EEA_OK) return st;
+  st = eea_comm_allgather_ck(e, c, B_local, d_ck_local, d_ck_all, c->xstream);
+  if (st != EEA_OK) return st;
+  EEA_HIP(hipEventRecord(c->ev_done[slot], c->xstream));
+  return EEA_OK;
+}
+
+eea_status eea_comm_wait(eea_comm* c, int slot, void* stream)
+{
+  if (c == nullptr || slot < 0 || slot >= EEA_COMM_SLOTS) return fail(EEA_ERR_INVALID_ARGUMENT, "bad communicator / slot");
+  if (c->ev_done[slot] == nullptr) return EEA_OK;  // nothing was ever started in this slot
+  EEA_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), c->ev_done[slot], 0));
   return EEA_OK;
 }
 

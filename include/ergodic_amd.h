@@ -201,6 +201,16 @@ eea_status eea_comm_allgather_ck(eea_engine* e, eea_comm* c, unsigned B_local, c
  * eea_batch_io::d_ck_shared */
 eea_status eea_comm_consensus_ck(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_local,
                                  void* d_ck_shared, void* stream);
+/* Asynchronous forms: the exchange runs on a stream the communicator owns, ordered after everything enqueued on
+ * `compute_stream` so far (the pass that produced c_k), so that the next pass on the compute stream overlaps it;
+ * eea_comm_wait makes a stream wait for the exchange started in `slot` (0 .. EEA_COMM_SLOTS - 1; the caller
+ * rotates slots together with its c_k / result buffers). */
+#define EEA_COMM_SLOTS 4
+eea_status eea_comm_consensus_ck_async(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_local,
+                                       void* d_ck_shared, void* compute_stream, int slot);
+eea_status eea_comm_allgather_ck_async(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_local,
+                                       void* d_ck_all, void* compute_stream, int slot);
+eea_status eea_comm_wait(eea_comm* c, int slot, void* stream);
 /* in-place ncclAllReduce(sum) of n reals: the K^2 partial sums of a grid-tiled phi_k
  * (eea_spatial_coeff_rows / eea_spatial_coeff_occupancy_rows) */
 eea_status eea_comm_allreduce_sum(eea_engine* e, eea_comm* c, void* d_buf, unsigned n, void* stream);

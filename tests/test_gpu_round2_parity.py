@@ -107,6 +107,21 @@ def test_exchange_steps_on_single_rank_rccl():
     assert torch.equal(allc, ck)
     assert torch.equal(buf, ck[0])
     assert np.abs(cbar.cpu().numpy() - ck.cpu().numpy().mean(0)).max() < 1e-14
+    # asynchronous forms: ordered after the compute stream, completion per slot
+    cbar2 = torch.zeros((K2,), dtype=torch.float64, device="cuda")
+    all2 = torch.zeros((B, K2), dtype=torch.float64, device="cuda")
+    with torch.cuda.stream(s):
+        ck2 = ck * 2.0          # produced on the compute stream right before the exchange starts
+    comm.consensus_ck_async(eng, B, ck2, cbar2, s.cuda_stream, 1)
+    comm.allgather_ck_async(eng, B, ck2, all2, s.cuda_stream, 2)
+    comm.wait(1, s.cuda_stream)
+    comm.wait(2, s.cuda_stream)
+    comm.wait(3, s.cuda_stream)   # never started: no-op
+    with torch.cuda.stream(s):
+        got = cbar2.clone()
+    torch.cuda.synchronize()
+    assert np.abs(got.cpu().numpy() - 2.0 * ck.cpu().numpy().mean(0)).max() < 1e-13
+    assert torch.equal(all2, ck2)
     # fp32 engine: same entry points on float buffers
     e32, _ = make_pair("omni", 10, 2.0, n_oracles=0, precision=capi.PREC_F32)
     ck32 = ck.float()
