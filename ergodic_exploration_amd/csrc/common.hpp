@@ -63,7 +63,7 @@ template <typename R>
 hipError_t launch_control(const ControlParams<R>& p, unsigned B, int model, int n_mem_max,
                           bool rollout_only, hipStream_t stream);
 
-// Wavefront-per-agent control kernel (control_wave_impl.hpp): horizons of at most 256 steps, K <= 16.
+// Wavefront-per-agent control kernel (control_wave_impl.hpp): horizons of at most 256 steps, K <= 16 or K = 20.
 // launch_control_wave needs control_wave_eligible.
 template <typename R>
 bool control_wave_eligible(const ControlParams<R>& p, bool rollout_only);

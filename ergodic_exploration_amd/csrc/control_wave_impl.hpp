@@ -54,8 +54,9 @@ __host__ __device__ constexpr int park_elems() { return 2 * kMaxS * kWave; }
 __host__ __device__ constexpr int d_elems(int K) { return (K * K + 3) & ~3; }
 __host__ __device__ constexpr int tile_elems(int K)
 {
-  // the tiles of the contraction; afterwards D [K^2] and the parked barrier gradient [2][kMaxS][64]
-  const int t = 2 * kStageRows * tab_stride(K) + 16;
+  // the tiles of the contraction (+ the pad the last row's operand reads run into: one or two 16-mode tiles);
+  // afterwards D [K^2] and the parked barrier gradient [2][kMaxS][64]
+  const int t = 2 * kStageRows * tab_stride(K) + (K > 16 ? 32 : 16);
   const int d = d_elems(K) + 2 * kMaxS * kWave;
   return ((t > d ? t : d) + 3) & ~3;
 }
@@ -124,14 +125,16 @@ __device__ __forceinline__ R wrap_pi_fast(R rad)
   return rad - pi;
 }
 
-// waves per SIMD the kernel is compiled for: 4 (128 registers) for the exact-K instances
-constexpr int waves_per_simd(int KC) { return KC <= 10 ? 4 : 3; }
+// waves per SIMD the kernel is compiled for: 4 (128 registers) for K <= 10 and for fp32
+constexpr int waves_per_simd(int KC, int real_size) { return (KC <= 10 || real_size == 4) ? 4 : 3; }
+// k1 block of the gradient: cosine and G arrays of this many modes are in registers at a time
+constexpr int grad_block(int KC) { return KC <= 12 ? KC : (KC == 16 ? 8 : 10); }
 
-// KC: compile-time K (5, 10) or 16 = any K <= 16 at run time (loops unrolled to 16, guarded).
+// KC: compile-time K (5, 10, 20) or 16 = any K <= 16 at run time (loops unrolled to 16, guarded).
 // STAGES: the optional per-stage outputs (traj, edx, bdx, rhot) are compiled in.
 // WPB: wavefronts (= agents) per workgroup; they share nothing.
 template <typename R, int MODEL, int KC, bool STAGES, int WPB>
-__global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_kernel(
+__global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void control_wave_kernel(
     const ControlParams<R> p, const unsigned B, const int S, const int rollout_only)
 {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -141,7 +144,13 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_k
   if (b >= B) return;  // wavefront-uniform
 
   const int T = p.T;
-  const int K = (KC == 16) ? p.K : KC;
+  // kGenericK: any K <= 16 at run time (modes beyond K are masked to zero).  kRowGuard: the rows of the gradient
+  // (and the table stores) are guarded by a comparison with the run-time K also for K = 20, where the guard is
+  // always true: without it the compiler flattens the fully static loops into one block, hoists the LDS loads
+  // of all rows above the arithmetic and spills them (1.4 KB of scratch per lane in fp32)
+  constexpr bool kGenericK = (KC == 16);
+  constexpr bool kRowGuard = (KC == 16 || KC == 20);
+  const int K = kRowGuard ? p.K : KC;
   const int K2 = K * K;
   constexpr int KS = (KC == 16) ? 16 : tab_stride(KC);
 
@@ -300,19 +309,24 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_k
   const int N = T + nmem;
   using M = Mfma<R>;
   using acc_t = typename M::acc_t;
-  acc_t acc0 = acc_t{ R(0), R(0), R(0), R(0) }, acc1 = acc0;
+  constexpr int NT = (KC > 16) ? 2 : 1;  // 16-mode tiles per axis
+  acc_t acc0 = acc_t{ R(0), R(0), R(0), R(0) }, acc1 = acc0;  // NT = 1: two chains on the one tile
+  acc_t acc2 = acc0, acc3 = acc0;                              // NT = 2: tiles (0,0) (0,1) (1,0) (1,1)
   const int mk = lane >> 4, mi = lane & 15;  // matrix-instruction operand coordinates of this lane
   // lambda_k, phi_k of this lane's accumulator entries (mode = k2 * K + k1, k2 = mi, k1 = the accumulator row
   // of register r).  Loaded after the contraction: issued earlier (before it, or during its last pass) they
   // hold 16 registers through the pipelined passes and cost 7 % of the launch (profiles/r02_ablation.txt)
-  R lam[4], phi[4];
+  R lam[NT * NT][4], phi[NT * NT][4];
   auto load_lam_phi = [&]() {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int k1 = M::row(lane, r);
-      const bool ok = k1 < K && mi < K;
-      lam[r] = ok ? p.lamdak[mi * K + k1] : R(0);
-      phi[r] = ok ? p.phik[mi * K + k1] : R(0);
+    for (int t = 0; t < NT * NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k1 = 16 * (t / NT) + M::row(lane, r), k2 = 16 * (t % NT) + mi;
+        const bool ok = k1 < K && k2 < K;
+        lam[t][r] = ok ? p.lamdak[k2 * K + k1] : R(0);
+        phi[t][r] = ok ? p.phik[k2 * K + k1] : R(0);
+      }
     }
   };
 
@@ -360,27 +374,42 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_k
       Tab t = tab_init(ca, cb, valid);
 #pragma unroll
       for (int q = 0; q < kPairs; ++q) {
-        if (KC == 16 && 2 * q >= K) break;
-        tab_store(t, 2 * q);
-        tab_step(t);
+        if (!kRowGuard || 2 * q < K) {
+          tab_store(t, 2 * q);
+          tab_step(t);
+        }
       }
     }
     lds_fence();
+    if (NT == 1) {
 #pragma unroll
-    for (int m = 0; m < kStageRows / 4; m += 2) {
-      if (4 * m < rows_valid) {  // wavefront-uniform
-        const int off = (4 * m + mk) * KS + mi;
-        acc0 = M::run(tabx[off], taby[off], acc0);
+      for (int m = 0; m < kStageRows / 4; m += 2) {
+        if (4 * m < rows_valid) {  // wavefront-uniform
+          const int off = (4 * m + mk) * KS + mi;
+          acc0 = M::run(tabx[off], taby[off], acc0);
+        }
+        if (4 * (m + 1) < rows_valid) {
+          const int off = (4 * (m + 1) + mk) * KS + mi;
+          acc1 = M::run(tabx[off], taby[off], acc1);
+        }
       }
-      if (4 * (m + 1) < rows_valid) {
-        const int off = (4 * (m + 1) + mk) * KS + mi;
-        acc1 = M::run(tabx[off], taby[off], acc1);
+    } else {
+#pragma unroll
+      for (int m = 0; m < kStageRows / 4; ++m) {
+        if (4 * m < rows_valid) {  // wavefront-uniform
+          const int off = (4 * m + mk) * KS + mi;
+          const R a0 = tabx[off], a1 = tabx[off + 16], b0 = taby[off], b1 = taby[off + 16];
+          acc0 = M::run(a0, b0, acc0);
+          acc1 = M::run(a0, b1, acc1);
+          acc2 = M::run(a1, b0, acc2);
+          acc3 = M::run(a1, b1, acc3);
+        }
       }
     }
     lds_fence();
   };
 
-  if (KC != 16) {
+  if (KC != 16 && NT == 1) {
     // Rollout points, software-pipelined: the 8 matrix instructions of a pass take 65 cycles of the matrix pipe
     // each; the table recurrence and the LDS stores of the NEXT pass are issued in between them (in program
     // order, pinned with scheduling barriers), so that only the operand reads wait.  Branch-free: passes beyond
@@ -487,17 +516,21 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_k
   // D = lambda (c - phi), fourier_diff of ergodic_control.hpp:422, in both orientations
   {
     const R invN = R(1) / static_cast<R>(N);
+    if (NT == 1) acc0 = acc0 + acc1;
+    const acc_t* const accs[4] = { &acc0, &acc1, &acc2, &acc3 };
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int k1 = M::row(lane, r);
-      const int k2 = mi;
-      if (k1 < K && k2 < K) {
-        R c = invN * (acc0[r] + acc1[r]);
-        if (p.ck != nullptr) p.ck[static_cast<size_t>(b) * K2 + k2 * K + k1] = c;
-        // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
-        if (p.ck_shared != nullptr) c = p.ck_shared[k2 * K + k1];
-        const R d = lam[r] * (c - phi[r]);
-        s_D[k2 * K + k1] = d;
+    for (int t = 0; t < NT * NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k1 = 16 * (t / NT) + M::row(lane, r);
+        const int k2 = 16 * (t % NT) + mi;
+        if (k1 < K && k2 < K) {
+          R c = invN * (*accs[t])[r];
+          if (p.ck != nullptr) p.ck[static_cast<size_t>(b) * K2 + k2 * K + k1] = c;
+          // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
+          if (p.ck_shared != nullptr) c = p.ck_shared[k2 * K + k1];
+          s_D[k2 * K + k1] = lam[t][r] * (c - phi[t][r]);
+        }
       }
     }
     lds_fence();
@@ -529,59 +562,72 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_wave_k
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     if (j < S) {
-      // one pass over D: G(k1) accumulates over the rows, H(k2) is complete at the end of row k2
-      R cxa[KA], G[KA];
-      cxa[0] = R(1);
-      if (KA > 1) cxa[1] = c1x[j];
-      {
-        const R two = c1x[j] + c1x[j];
+      // Pass(es) over D, one per block of KB x-modes k1: G(k1) accumulates over the rows, the block's part of
+      // H(k2) is complete at the end of row k2.  The Chebyshev pairs of the x angle run on across the blocks.
+      constexpr int KB = grad_block(KC);
+      R accx = R(0), accy = R(0);
+      const R twox = c1x[j] + c1x[j], twoy = c1y[j] + c1y[j];
+      R ta = R(1), tb = c1x[j];   // T_k, T_{k+1} of the x angle at the block's first mode
+      R ua = R(0), ub = R(1);     // U_{k-1}, U_k
 #pragma unroll
-        for (int k = 2; k < KA; ++k) cxa[k] = two * cxa[k - 1] - cxa[k - 2];
-      }
-      // row k2 = 0: cos(0 y) = 1 and k2 sin(0) = 0: only G takes part
-      {
-        const R* const row = s_D;
-#pragma unroll
-        for (int k1 = 1; k1 < KA; ++k1) G[k1] = (KC == 16 && k1 >= K) ? R(0) : row[k1];
-        G[0] = R(0);
-      }
-      const R twoy = c1y[j] + c1y[j];
-      R um = R(0), u0 = R(1);         // U_{k2-2}, U_{k2-1} of the y angle
-      R tm = R(1), t0 = c1y[j];       // T_{k2-1}, T_{k2}
-      R accy = R(0);
-#pragma unroll
-      for (int k2 = 1; k2 < KA; ++k2) {
-        if (KC == 16 && k2 >= K) break;
-        const R* const row = s_D + k2 * K;
-        R ha = row[0], hb = R(0);     // cxa[0] = 1
-#pragma unroll
-        for (int k1 = 1; k1 < KA; ++k1) {
-          if (KC == 16 && k1 >= K) break;
-          const R d = row[k1];
-          G[k1] += d * t0;
-          if (k1 & 1) hb += d * cxa[k1];
-          else ha += d * cxa[k1];
+      for (int kb0 = 0; kb0 < KA; kb0 += KB) {
+        if (kb0 > 0) {  // one block at a time (registers), like the steps
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_sched_barrier(0);
         }
-        accy = fma_k(u0 * (ha + hb), k2, accy);
-        const R un = twoy * u0 - um;
-        um = u0;
-        u0 = un;
-        const R tn = twoy * t0 - tm;
-        tm = t0;
-        t0 = tn;
-      }
-      // edx_x: sum_k1 k1 U_{k1-1}(cos a x) G(k1)
-      R accx = R(0);
-      {
-        const R twox = c1x[j] + c1x[j];
-        R vm = R(0), v0 = R(1);
+        R cxa[KB], G[KB];
 #pragma unroll
-        for (int k1 = 1; k1 < KA; ++k1) {
-          if (KC == 16 && k1 >= K) break;
-          accx = fma_k(v0 * G[k1], k1, accx);
-          const R vn = twox * v0 - vm;
-          vm = v0;
-          v0 = vn;
+        for (int i = 0; i < KB; ++i) {
+          cxa[i] = ta;
+          const R tn = twox * tb - ta;
+          ta = tb;
+          tb = tn;
+        }
+        // row k2 = 0: cos(0 y) = 1 and k2 sin(0) = 0: only G takes part (G(0) is never used: k1 sin(0) = 0)
+        {
+          const R* const row = s_D + kb0;
+#pragma unroll
+          for (int i = 0; i < KB; ++i) {
+            const int k1 = kb0 + i;
+            G[i] = (k1 == 0 || k1 >= KA) ? R(0) : ((kGenericK && k1 >= K) ? R(0) : row[i]);
+          }
+        }
+        R um = R(0), u0 = R(1);         // U_{k2-2}, U_{k2-1} of the y angle
+        R tm = R(1), t0 = c1y[j];       // T_{k2-1}, T_{k2}
+#pragma unroll
+        for (int k2 = 1; k2 < KA; ++k2) {
+          if (!kRowGuard || k2 < K) {  // wavefront-uniform
+            const R* const row = s_D + k2 * K + kb0;
+            R ha = R(0), hb = R(0);
+#pragma unroll
+            for (int i = 0; i < KB; ++i) {
+              const int k1 = kb0 + i;
+              if (k1 < KA) {  // compile time
+                // generic instance: modes beyond K read the next row's entries (inside D) and are masked
+                const R d = (kGenericK && k1 >= K) ? R(0) : row[i];
+                if (k1 > 0) G[i] += d * t0;
+                if (k1 == 0) ha = d;  // cos(0 x) = 1
+                else if (i & 1) hb += d * cxa[i];
+                else ha += d * cxa[i];
+              }
+            }
+            accy = fma_k(u0 * (ha + hb), k2, accy);
+            const R un = twoy * u0 - um;
+            um = u0;
+            u0 = un;
+            const R tn = twoy * t0 - tm;
+            tm = t0;
+            t0 = tn;
+          }
+        }
+        // edx_x: sum_k1 k1 U_{k1-1}(cos a x) G(k1) over this block
+#pragma unroll
+        for (int i = 0; i < KB; ++i) {
+          const int k1 = kb0 + i;
+          if (k1 > 0 && k1 < KA) accx = fma_k(ua * G[i], k1, accx);  // G(k1 >= K) = 0 in the generic instance
+          const R un = twox * ub - ua;
+          ua = ub;
+          ub = un;
         }
       }
       const R exj = (-p.pi_lx * s1x[j] * accx) * p.expl_weight;

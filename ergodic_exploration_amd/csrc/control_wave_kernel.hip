@@ -35,6 +35,8 @@ hipError_t launch_wave_k(const ControlParams<R>& p, unsigned B, bool rollout_onl
       return launch_wave_one<R, MODEL, 5, STAGES>(p, B, rollout_only, stream);
     case 10:
       return launch_wave_one<R, MODEL, 10, STAGES>(p, B, rollout_only, stream);
+    case 20:
+      return launch_wave_one<R, MODEL, 20, STAGES>(p, B, rollout_only, stream);
     default:
       return launch_wave_one<R, MODEL, 16, STAGES>(p, B, rollout_only, stream);
   }
@@ -45,7 +47,7 @@ template <typename R>
 bool control_wave_eligible(const ControlParams<R>& p, bool rollout_only)
 {
   (void)rollout_only;
-  return p.T >= 1 && p.T <= wave::kMaxS * kWave && p.K >= 1 && p.K <= 16;
+  return p.T >= 1 && p.T <= wave::kMaxS * kWave && p.K >= 1 && (p.K <= 16 || p.K == 20);
 }
 
 template <typename R>

@@ -389,7 +389,7 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
   p.done = e->mail_done;
   p.done_seq = e->mail_seq;
   const int n_mem_max = rollout_only ? 0 : static_cast<int>(p.mem_stride);
-  // two kernels ship: one wavefront per agent (horizons <= 256 steps, K <= 16) and one workgroup per agent
+  // two kernels ship: one wavefront per agent (horizons <= 256 steps, K <= 16 or K = 20) and one workgroup per agent
   // (everything else, and the rollout-only entry).  EEA_CONTROL_PATH=workgroup forces the second.
   static const bool force_workgroup = [] {
     const char* v = std::getenv("EEA_CONTROL_PATH");
