@@ -3,6 +3,8 @@
 # available on the pool): the host mirror's own test driver (reference KATs on the C++ classes), the
 # map_server loader on a map file given as $1 (optional), and the C oracle through one closed-loop case.
 set -e
+set -o pipefail
+export UBSAN_OPTIONS=halt_on_error=1:print_stacktrace=1
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${TMPDIR:-/tmp}/eea_asan
 mkdir -p "$OUT"
