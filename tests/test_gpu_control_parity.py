@@ -111,6 +111,18 @@ def test_wavefronts_per_agent_boundaries(steps):
     run_batch_vs_oracle("simple_cart", 6, steps * 0.125, 0.125, B=2, n_mem=0, calls=2, seed=22)
 
 
+@pytest.mark.parametrize("steps", [191, 192, 193, 255, 256, 257])
+def test_steps_per_lane_boundaries(steps):
+    """The wavefront-per-agent kernel gives a lane ceil(T / 64) <= 4 consecutive steps: horizons around the
+    3 -> 4 steps-per-lane boundary, the last eligible horizon (256) and the first one that falls back to the
+    workgroup kernel (257); both models, with replay memory longer than one 64-point pass; K = 16 / 17 straddle
+    the one- / two-tile contraction and the eligibility rule (K <= 16 or K = 20)."""
+    run_batch_vs_oracle("omni", 10, steps * 0.125, 0.125, B=5, n_mem=70, calls=2, seed=41)
+    run_batch_vs_oracle("simple_cart", 16, steps * 0.125, 0.125, B=2, n_mem=0, calls=2, seed=42)
+    run_batch_vs_oracle("omni", 17, steps * 0.125, 0.125, B=2, n_mem=3, calls=1, seed=43)
+    run_batch_vs_oracle("omni", 20, steps * 0.125, 0.125, B=2, n_mem=65, calls=2, seed=44)
+
+
 @pytest.mark.parametrize("block", ["64", "128"])
 def test_forced_threads_per_agent_long_horizon(block):
     """EEA_BLOCK forces fewer threads per agent than horizon steps: several steps per lane through
@@ -121,7 +133,7 @@ def test_forced_threads_per_agent_long_horizon(block):
     code = ("from tests import test_gpu_control_parity as t; "
             "t.run_batch_vs_oracle('simple_cart', 10, 20.0, 0.1, B=3, n_mem=40, calls=2, seed=31); "
             "t.run_batch_vs_oracle('omni', 7, 30.0, 0.1, B=2, n_mem=0, calls=2, seed=32)")
-    env = dict(os.environ, EEA_BLOCK=block)
+    env = dict(os.environ, EEA_BLOCK=block, EEA_CONTROL_PATH="workgroup")  # the knob is the workgroup kernel's
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True,
                        timeout=600)
