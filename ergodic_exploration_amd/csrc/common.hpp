@@ -228,17 +228,34 @@ __device__ __forceinline__ double fma_sc(double a, double b, double coeff)
   asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(coeff));
   return d;
 }
+__device__ __forceinline__ double mul_sc(double a, double coeff)
+{
+  double d;
+  asm("v_mul_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(coeff));
+  return d;
+}
+__device__ __forceinline__ double add_sc(double a, double coeff)
+{
+  double d;
+  asm("v_add_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(coeff));
+  return d;
+}
 template <>
 __device__ __forceinline__ void sincospi_r<double>(double t, double* s, double* c)
 {
   if (__builtin_expect(!(fabs(t) < 0x1p50), 0)) t = 2.0 * __builtin_amdgcn_fract(0.5 * t);
+  // every constant comes from a scalar register pair (one per instruction is what the encoding allows): the
+  // compiler's own lowering copies 64-bit literals into vector registers first (6 v_mov per evaluation)
   const double magic = 0x1.8p52;
-  const double nb = fma(t, 2.0, magic);
+  double nb;
+  asm("v_fma_f64 %0, %1, 2.0, %2" : "=v"(nb) : "v"(t), "s"(magic));
   const int q = __double2loint(nb);
-  const double n = nb - magic;
+  const double n = add_sc(nb, -magic);
   const double r = fma(n, -0.5, t);
   const double z = r * r;
-  double ps = fma(z, -0x1.6fadb9f155744p-16, 0x1.e8f434d018d63p-12);
+  // top Horner step as multiply + add (two scalar-register constants cannot share one instruction); its terms
+  // are below 1e-5 of the result, so the extra rounding is invisible
+  double ps = add_sc(mul_sc(z, -0x1.6fadb9f155744p-16), 0x1.e8f434d018d63p-12);
   ps = fma_sc(ps, z, -0x1.e3074fde8871fp-8);
   ps = fma_sc(ps, z, 0x1.50783487ee782p-4);
   ps = fma_sc(ps, z, -0x1.32d2cce62bd86p-1);
@@ -246,7 +263,7 @@ __device__ __forceinline__ void sincospi_r<double>(double t, double* s, double* 
   ps = fma_sc(ps, z, -0x1.4abbce625be53p+2);
   ps = fma_sc(ps, z, 0x1.921fb54442d18p+1);
   const double sv = ps * r;
-  double pc = fma(z, 4.3030695870329473e-06, -0.0001046381049248457);
+  double pc = add_sc(mul_sc(z, 4.3030695870329473e-06), -0.0001046381049248457);
   pc = fma_sc(pc, z, 0.0019295743094039231);
   pc = fma_sc(pc, z, -0.025806891390014061);
   pc = fma_sc(pc, z, 0.23533063035889321);
