@@ -669,6 +669,28 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   // ergodic_control.hpp:203); row 2:
   //   rho2_i = rho2_{i+1} + dt (S_i(rho_{i+1}) + dt/2 S_i(g_i)), S_i(v) = A(0,2) v0 + A(1,2) v1,
   //   A = fdx(x_i, u_i) (omni.hpp:194-197, cart.hpp:183-186); then u_i = clamp(-Rinv B^T rho_i)
+  // The (shifted) controls of the lane's steps again, from L2, issued here so that their latency runs under the
+  // scans: carried in registers since the first load they were spilled to scratch through the contraction and the
+  // gradient (20 MB of HBM traffic per launch).  Branch-free: out-of-range steps read element 0 and select zero.
+  R vxr[kMaxS], vyr[kMaxS];
+  {
+    size_t opaque = 0;  // the compiler must not recognise (and keep alive) the earlier loads of the same words
+    asm volatile("" : "+v"(opaque));
+    const R* const ut_again = ut + opaque;
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      const int src = i0 + j + 1;
+      const bool ok = j < S && src < T;
+      const int idx = ok ? 3 * src : 0;
+      const R a = ut_again[idx];
+      vxr[j] = ok ? a : R(0);
+      vyr[j] = R(0);
+      if (MODEL == kModelOmni) {
+        const R bq = ut_again[idx + 1];
+        vyr[j] = ok ? bq : R(0);
+      }
+    }
+  }
   R r0[kMaxS], r1[kMaxS];  // inclusive suffix within the lane, then the co-state after step j
   {
     R s0 = R(0), s1 = R(0);
@@ -695,40 +717,24 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   }
   R r2[kMaxS], cth[kMaxS], sth[kMaxS];
   {
-    // opaque copy of the controls' address: the compiler must not recognise (and keep alive) the earlier loads
-    const R* ut_again = ut;
-    asm volatile("" : "+v"(ut_again));
     R s2 = R(0);
 #pragma unroll
     for (int j = kMaxS - 1; j >= 0; --j) {
-      R qv = R(0);
-      cth[j] = sth[j] = R(0);
-      if (j < S) {
-        cth[j] = s_cp[j * kWave + lane];
-        sth[j] = s_sp[j * kWave + lane];
-        // the (shifted) controls of this step again, from L2: carried in registers since the load they would
-        // be spilled to scratch through the contraction and the gradient (20 MB of HBM traffic per launch)
-        R vxj = R(0), vyj = R(0);
-        {
-          const int src = i0 + j + 1;
-          if (src < T) {
-            vxj = ut_again[3 * src + 0];
-            if (MODEL == kModelOmni) vyj = ut_again[3 * src + 1];
-          }
-        }
-        R a02, a12;
-        if (MODEL == kModelOmni) {
-          a02 = -vxj * sth[j] - vyj * cth[j];
-          a12 = vxj * cth[j] - vyj * sth[j];
-        } else {
-          a02 = -vxj * sth[j];
-          a12 = vxj * cth[j];
-        }
-        // rho_{i+1} = rho_i - dt g_i (rows 0,1)
-        const R sE = a02 * (r0[j] - dt * g0[j]) + a12 * (r1[j] - dt * g1[j]);
-        const R sG = a02 * g0[j] + a12 * g1[j];
-        qv = (i0 + j < T) ? dt * (sE + p.half_dt * sG) : R(0);
+      // post-step heading parked by the forward half (slots beyond S hold nothing that is used: qv = 0 there)
+      cth[j] = s_cp[j * kWave + lane];
+      sth[j] = s_sp[j * kWave + lane];
+      R a02, a12;
+      if (MODEL == kModelOmni) {
+        a02 = -vxr[j] * sth[j] - vyr[j] * cth[j];
+        a12 = vxr[j] * cth[j] - vyr[j] * sth[j];
+      } else {
+        a02 = -vxr[j] * sth[j];
+        a12 = vxr[j] * cth[j];
       }
+      // rho_{i+1} = rho_i - dt g_i (rows 0,1)
+      const R sE = a02 * (r0[j] - dt * g0[j]) + a12 * (r1[j] - dt * g1[j]);
+      const R sG = a02 * g0[j] + a12 * g1[j];
+      const R qv = (j < S && i0 + j < T) ? dt * (sE + p.half_dt * sG) : R(0);
       s2 += qv;
       r2[j] = s2;
     }
