@@ -14,15 +14,17 @@
 //     gradient's multiply-add chains of different steps interleave, so one wavefront keeps the vector pipe
 //     busy where the one-step-per-lane kernel waited on its own dependency chains;
 //   * c_k = (1/N) Cx Cy^T on the matrix cores, fed through a wavefront-private LDS tile of 32 points
-//     [point][k]: the accumulator of v_mfma_f64_16x16x4_f64 already holds the COMPLETE sums of the agent, so
-//     D = lambda (c - phi) is formed in registers and written once (both orientations) for the gradient;
+//     [point][k], software-pipelined (the next pass's table recurrence and stores are issued between the
+//     matrix instructions): the accumulator of v_mfma_f64_16x16x4_f64 already holds the COMPLETE sums of the
+//     agent, so D = lambda (c - phi) is formed in registers and written once for the gradient;
 //   * cos(k a), sin(k a) by the Chebyshev three-term recurrences (T_{k+1} = 2c T_k - T_{k-1}, sin(k a) =
 //     sin(a) U_{k-1}): one multiply-add per table entry instead of the four of the rotation recurrence;
-//   * the gradient makes two passes over D (rows of D and of D^T from LDS, wavefront-uniform broadcast reads)
-//     with a K-entry cosine array of ONE step in registers at a time: 128 registers, 4 wavefronts per SIMD,
-//     9.3 KB of LDS per agent -- the 4096-agent batch is resident on the 1024 SIMDs in one round.
+//   * the gradient makes ONE pass over D per step (rows from LDS, wavefront-uniform broadcast reads: the LDS
+//     return path, 4 cycles per 16-byte row read and wavefront, is what bounded a two-pass form) with the
+//     cosine array and the G accumulators of ONE step in registers at a time: 128 registers, 4 wavefronts per
+//     SIMD, 9.3 KB of LDS per agent -- the 4096-agent batch is resident on the 1024 SIMDs in one round.
 //
-// Steps beyond 256 and bases beyond K = 16 stay on the workgroup-per-agent kernel
+// Steps beyond 256 and bases beyond K = 16 (other than 20) stay on the workgroup-per-agent kernel
 // (control_kernel_impl.hpp); the engine picks.  rollout_only (optTraj / path) stops after the forward half,
 // so a rollout and the trajectory a control call reports are bitwise the same function of (pose, controls).
 #pragma once
@@ -48,8 +50,9 @@ constexpr int kMaxS = 4;        // steps per lane
 constexpr int kStageRows = 32;  // points staged per matrix-core pass (8 MFMAs)
 
 __host__ __device__ constexpr int tab_stride(int K) { return (K + 1) & ~1; }  // even: 16-byte rows
-// LDS carve per wavefront, in elements: heading park [2][kMaxS][64], tiles x / y (32 rows each) + the pad
-// the last rows' operand reads run into; D and D^T alias the tiles (written after the last operand read)
+// LDS carve per wavefront, in elements: heading park [2][kMaxS][64], then the region of the contraction's tiles
+// (x / y, 32 rows each, + the pad the last rows' operand reads run into), which D and the parked barrier
+// gradient take over once the last operand has been read
 __host__ __device__ constexpr int park_elems() { return 2 * kMaxS * kWave; }
 __host__ __device__ constexpr int d_elems(int K) { return (K * K + 3) & ~3; }
 __host__ __device__ constexpr int tile_elems(int K)
