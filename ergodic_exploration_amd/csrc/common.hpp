@@ -280,6 +280,26 @@ __device__ __forceinline__ void sincospi_r<double>(double t, double* s, double* 
   *s = __hiloint2double(__double2hiint(s1) ^ ssign, __double2loint(s1));
   *c = __hiloint2double(__double2hiint(c1) ^ csign, __double2loint(c1));
 }
+// sin(pi r), cos(pi r) for |r| <= 1/16 (increments of a heading or of a basis angle over one step): no argument
+// reduction, Taylor series in r^2 with 6 + 7 terms (truncation < 1e-19), 16 instructions instead of ~40
+__device__ __forceinline__ void sincospi_small(double r, double* s, double* c)
+{
+  const double z = r * r;
+  double ps = add_sc(mul_sc(z, -0.007370430945714351), 0.08214588661112823);
+  ps = fma_sc(ps, z, -0.5992645293207921);
+  ps = fma_sc(ps, z, 2.550164039877345);
+  ps = fma_sc(ps, z, -5.16771278004997);
+  ps = fma_sc(ps, z, 3.141592653589793);
+  *s = ps * r;
+  double pc = add_sc(mul_sc(z, 0.0019295743094039231), -0.02580689139001406);
+  pc = fma_sc(pc, z, 0.2353306303588935);
+  pc = fma_sc(pc, z, -1.3352627688545893);
+  pc = fma_sc(pc, z, 4.058712126416768);
+  pc = fma_sc(pc, z, -4.934802200544679);
+  *c = fma(pc, z, 1.0);
+}
+__device__ __forceinline__ void sincospi_small(float r, float* s, float* c) { sincospif(r, s, c); }
+
 template <>
 __device__ __forceinline__ void sincospi_r<float>(float t, float* s, float* c)
 {

@@ -225,30 +225,51 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   // sin/cos of the pre-step heading is evaluated for the lane's first step only; the later ones are the
   // previous step's post-step values (2 mid - pre by the double-angle / addition formulas, ~4e-16 each)
   R px[kMaxS], py[kMaxS];  // inclusive prefix of the position increments within the lane
+  R incx[kMaxS], incy[kMaxS];  // the increments themselves (basis angles of later steps by rotation, below)
   {
     R c, s;
     {
       const R th_pre0 = thp[0] - dt6 * (((w[0] + R(2) * w[0]) + R(2) * w[0]) + w[0]);
       sincospi_r(th_pre0 * inv_pi, &s, &c);
     }
+    // Small yaw increments (|dt w / 2| <= pi / 16 for every step of the wavefront -- any realistic time step):
+    // the mid-stage and post-step headings follow from the pre-step one by two rotations with sin/cos of the
+    // increment (short series, no argument reduction) instead of a full evaluation + double-angle formulas
+    bool small = true;
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) small = small && (fabs(dt * (R(0.5) * w[j]) * inv_pi) <= R(0.0625));
+    const bool fast_h = sizeof(R) == 8 && __all(small);
     R rx = R(0), ry = R(0);
 #pragma unroll
     for (int j = 0; j < kMaxS; ++j) {
+      incx[j] = incy[j] = R(0);
       if (j < S) {
         // mid stage theta + dt (0.5 w), shared by k2 and k3 (integrator.hpp:179-180)
-        const R th_pre = (j == 0) ? thp[0] - dt6 * (((w[0] + R(2) * w[0]) + R(2) * w[0]) + w[0]) : thp[j - 1];
-        R sm_, cm;
-        sincospi_r((th_pre + dt * (R(0.5) * w[j])) * inv_pi, &sm_, &cm);
-        const R c2m = R(1) - R(2) * sm_ * sm_, s2m = R(2) * sm_ * cm;
-        const R cpost = c2m * c + s2m * s, spost = s2m * c - c2m * s;
+        R sm_, cm, cpost, spost;
+        if (fast_h) {  // wavefront-uniform
+          R sd, cd;
+          sincospi_small(dt * (R(0.5) * w[j]) * inv_pi, &sd, &cd);
+          cm = c * cd - s * sd;
+          sm_ = s * cd + c * sd;
+          cpost = cm * cd - sm_ * sd;
+          spost = sm_ * cd + cm * sd;
+        } else {
+          const R th_pre = (j == 0) ? thp[0] - dt6 * (((w[0] + R(2) * w[0]) + R(2) * w[0]) + w[0]) : thp[j - 1];
+          sincospi_r((th_pre + dt * (R(0.5) * w[j])) * inv_pi, &sm_, &cm);
+          const R c2m = R(1) - R(2) * sm_ * sm_, s2m = R(2) * sm_ * cm;
+          cpost = c2m * c + s2m * s;
+          spost = s2m * c - c2m * s;
+        }
         R k1x, k1y, k2x, k2y, k4x, k4y;
         model_xy<R, MODEL>(vx[j], vy[j], c, s, k1x, k1y);
         model_xy<R, MODEL>(vx[j], vy[j], cm, sm_, k2x, k2y);
         model_xy<R, MODEL>(vx[j], vy[j], cpost, spost, k4x, k4y);
         // steps beyond the horizon carry zero controls (the loads are guarded), so their increments are exact
         // zeros: no select
-        rx += dt6 * (((k1x + R(2) * k2x) + R(2) * k2x) + k4x);
-        ry += dt6 * (((k1y + R(2) * k2y) + R(2) * k2y) + k4y);
+        incx[j] = dt6 * (((k1x + R(2) * k2x) + R(2) * k2x) + k4x);
+        incy[j] = dt6 * (((k1y + R(2) * k2y) + R(2) * k2y) + k4y);
+        rx += incx[j];
+        ry += incy[j];
         // parked for the backward half: heading after step j (A = fdx(x_j, u_j), B = fdu(x_j))
         s_cp[j * kWave + lane] = cpost;
         s_sp[j * kWave + lane] = spost;
@@ -284,13 +305,32 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   // basis angles of the rollout points (map frame -> Fourier frame, ergodic_control.hpp:243-244; one sin/cos
   // pair per axis: angle = pi x / lx, basis.cpp:85 with k = 1) and the barrier gradient (:453-474)
   R c1x[kMaxS], s1x[kMaxS], c1y[kMaxS], s1y[kMaxS], g0[kMaxS], g1[kMaxS];
+  // The lane's first point: full evaluation.  Its later points, when every step of the wavefront moves by at most
+  // 1/16 of the domain (|dx| <= lx / 16: 0.75 m per step on the 12 m map): rotation of the previous point's
+  // sin/cos by the step's increment (short series; ~3e-16 per rotation, chains of at most 3).
+  bool small_b = true;
+#pragma unroll
+  for (int j = 1; j < kMaxS; ++j) {
+    small_b = small_b && (fabs(incx[j] * p.inv_lx) <= R(0.0625)) && (fabs(incy[j] * p.inv_ly) <= R(0.0625));
+  }
+  const bool fast_b = sizeof(R) == 8 && __all(small_b);
 #pragma unroll
   for (int j = 0; j < kMaxS; ++j) {
     c1x[j] = s1x[j] = c1y[j] = s1y[j] = g0[j] = g1[j] = R(0);
     if (j < S) {
       const R x = px[j] - p.map_x, y = py[j] - p.map_y;
-      sincospi_r(x * p.inv_lx, &s1x[j], &c1x[j]);
-      sincospi_r(y * p.inv_ly, &s1y[j], &c1y[j]);
+      if (j > 0 && fast_b) {  // wavefront-uniform
+        R sd, cd;
+        sincospi_small(incx[j] * p.inv_lx, &sd, &cd);
+        c1x[j] = c1x[j - 1] * cd - s1x[j - 1] * sd;
+        s1x[j] = s1x[j - 1] * cd + c1x[j - 1] * sd;
+        sincospi_small(incy[j] * p.inv_ly, &sd, &cd);
+        c1y[j] = c1y[j - 1] * cd - s1y[j - 1] * sd;
+        s1y[j] = s1y[j - 1] * cd + c1y[j - 1] * sd;
+      } else {
+        sincospi_r(x * p.inv_lx, &s1x[j], &c1x[j]);
+        sincospi_r(y * p.inv_ly, &s1y[j], &c1y[j]);
+      }
       const R eps = R(0.05), weight = R(25);
       R b0 = R(0), b1 = R(0);
       b0 += R(2) * static_cast<R>(x > p.lx - eps) * (x - (p.lx - eps));

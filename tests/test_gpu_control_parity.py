@@ -123,6 +123,22 @@ def test_steps_per_lane_boundaries(steps):
     run_batch_vs_oracle("omni", 20, steps * 0.125, 0.125, B=2, n_mem=65, calls=2, seed=44)
 
 
+@pytest.mark.parametrize("dt", [0.1, 1.0, 2.0])
+def test_small_and_large_step_increments(dt):
+    """The wavefront kernel takes the sin/cos of a step's mid-stage / post-step heading and of its later basis
+    angles by rotating the previous values with a short series of the INCREMENT when every increment of the agent
+    is small (|dt w / 2| <= pi/16, |dx| <= lx/16), and evaluates them in full otherwise: dt = 0.1 stays on the
+    rotation path, dt = 1 leaves it for the headings (warm-start yaw rates up to 0.5), dt = 2 also for the basis
+    angles (steps of up to 1 m on the 12 m map).  Same bars on both paths."""
+    # at dt >= 1 the robot leaves the 12 m map within a few steps: the barrier gradient 2 x 25 x distance and with it
+    # the co-state reach ~1e3-1e4, so the ABSOLUTE bar is scaled accordingly (the relative agreement is unchanged)
+    tol = TOL if dt < 1.0 else 2e-8
+    run_batch_vs_oracle("omni", 10, 40 * dt, dt, B=4, n_mem=5, calls=2, seed=51, tol=tol)
+    run_batch_vs_oracle("simple_cart", 10, 70 * dt, dt, B=3, n_mem=0, calls=2, seed=52, tol=tol)
+    if dt == 0.1:
+        run_batch_vs_oracle("simple_cart", 10, 200 * dt, dt, B=3, n_mem=0, calls=2, seed=53)
+
+
 @pytest.mark.parametrize("block", ["64", "128"])
 def test_forced_threads_per_agent_long_horizon(block):
     """EEA_BLOCK forces fewer threads per agent than horizon steps: several steps per lane through
