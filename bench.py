@@ -207,10 +207,34 @@ def phik_legs(args, torch, capi, np):
     return out
 
 
+def dry_run(args):
+    """EEA_BENCH_DRYRUN=1: the launch plumbing without a GPU (CPU test of `--gpus N`): the ranks rendezvous over
+    gloo, take the max over ranks of a dummy time like the real legs do, and rank 0 prints one JSON line."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        dist.barrier()
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        assert int(t.item()) == world
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        os.write(1, (json.dumps({"dryrun": True, "n_gpus": world, "gpus_arg": args.gpus, "steps": args.steps,
+                                 "warmup": args.warmup}) + "\n").encode())
+
+
 def main():
     args = parse()
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args))
+
+    if os.environ.get("EEA_BENCH_DRYRUN"):
+        return dry_run(args)
 
     import numpy as np
     import torch

@@ -173,3 +173,28 @@ def test_occupancy_tiled_phik_world2_gloo():
     full = po.spatial_coeff((nx - 1) * res, (ny - 1) * res, K, ent / ent.sum(), po.phi_grid(nx, ny, res))
     assert np.abs(pk - full).max() < 1e-13
     assert abs(pk[0] - 1.0) < 1e-15
+
+
+def test_bench_starts_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2 --steps K --warmup W` with no launcher around it (what the driver types): the
+    parent -- which must not touch the GPU -- starts two ranks through torch.distributed.run and exits with their
+    return code; EEA_BENCH_DRYRUN keeps the ranks off the device so that the plumbing is testable here.  (The
+    real thing runs on the GPU box: tests/test_gpu_round2_parity.py::test_bench_self_launches_its_ranks.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EEA_BENCH_DRYRUN="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec == {"dryrun": True, "n_gpus": 2, "gpus_arg": 2, "steps": 3, "warmup": 1}
+    # a failing rank must surface as a non-zero exit code of the parent
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--bogus-flag"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
