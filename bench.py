@@ -320,10 +320,17 @@ def main():
             # fails on some rank, every rank falls back to torch.distributed's collectives (the run must not die
             # with a secondary leg)
             ok = 1
+            uid = [None]
+            if rank == 0:
+                try:
+                    uid = [capi.comm_unique_id()]
+                except Exception as exc:  # noqa: BLE001
+                    sys.stderr.write("rank 0: eea_comm_get_unique_id failed (%r)\n" % (exc,))
+            if use_dist:
+                dist.broadcast_object_list(uid, src=0)   # every rank takes part, also when rank 0 has nothing to send
             try:
-                uid = [capi.comm_unique_id() if rank == 0 else None]
-                if use_dist:
-                    dist.broadcast_object_list(uid, src=0)
+                if uid[0] is None:
+                    raise RuntimeError("no RCCL id")
                 comm = capi.Comm(device, world, rank, uid[0])
             except Exception as exc:  # noqa: BLE001
                 sys.stderr.write("rank %d: eea_comm_create failed (%r); torch.distributed collectives instead\n" % (rank, exc))
