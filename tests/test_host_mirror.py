@@ -26,6 +26,24 @@ def test_reference_kats_against_host_classes():
 
 
 @pytest.mark.gpu
+def test_cpp_agent_batch_entry_point():
+    """agent_batch: the C++-only agent-batched loop (AgentBatch + eea_comm_* through the C ABI).  One rank is all
+    a 1-GPU box can hold; with and without the consensus exchange, both models; the checksum of the controls is
+    the same for the same agents whatever the step grouping."""
+    exe = os.path.join(BUILD, "agent_batch")
+    outs = []
+    for extra in ([], ["--consensus"], ["--model", "omni"]):
+        r = subprocess.run([exe, "--ranks", "1", "--agents", "300", "--steps", "4", "--horizon", "5.0"] + extra,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert "rank 0 of 1: 300 agents x 4 steps" in r.stdout
+        outs.append(r.stdout.strip().split("checksum")[-1])
+    assert outs[0] != outs[1]          # the consensus input changes the controls
+    r = subprocess.run([exe, "--bogus"], capture_output=True, text=True)
+    assert r.returncode == 2
+
+
+@pytest.mark.gpu
 def test_device_backed_classes_and_anchors():
     _build()
     out = subprocess.run([os.path.join(BUILD, "host_tests"), "gpu"], capture_output=True, text=True)
