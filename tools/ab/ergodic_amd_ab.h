@@ -7,9 +7,11 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
-/* same as eea_control_batch for an fp64, K = 10 engine, through an instrumented build of the
- * workgroup-per-agent control kernel that records the shader clock of every wavefront at 12 phase
- * boundaries: d_stamps [B][4][16] int64 (tools/phase_timing.py).
+/* same as eea_control_batch for an fp64 engine, through the instrumented builds of the control kernels, which
+ * record the shader clock at the phase boundaries (tools/phase_timing.py):
+ *   wavefront-per-agent kernel (default path): lane 0 of the agent's wavefront, 10 stamps, d_stamps [B][16] int64;
+ *   workgroup-per-agent kernel (EEA_CONTROL_PATH=workgroup, K = 10 only): every wavefront, 12 stamps,
+ *   d_stamps [B][4][16] int64.
  * Environment knobs of the A/B library: EEA_CONTROL_IMPL=v1 (first control kernel),
  * EEA_PHIK_IMPL=valu (per-column phi_k pass). */
 eea_status eea_debug_phase_timing(eea_engine* e, unsigned B, const eea_batch_io* io, void* stream,
