@@ -38,8 +38,24 @@
   do {                                                                                                  \
     if (p.dbg != nullptr && lane == 0) p.dbg[static_cast<size_t>(b) * 16 + (n)] = static_cast<long long>(__builtin_readcyclecounter()); \
   } while (0)
+// slots 10 / 11: the constant 100 MHz counter at the wavefront's start / end; 12: HW_ID (which SIMD it ran on)
+#define EEA_WSTAMP_RT(n)                                                                                \
+  do {                                                                                                  \
+    if (p.dbg != nullptr && lane == 0) p.dbg[static_cast<size_t>(b) * 16 + (n)] = static_cast<long long>(__builtin_amdgcn_s_memrealtime()); \
+  } while (0)
+#define EEA_WSTAMP_HWID(n)                                                                              \
+  do {                                                                                                  \
+    if (p.dbg != nullptr && lane == 0) {                                                                \
+      unsigned hw_, xcc_;                                                                               \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                 \
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                               \
+      p.dbg[static_cast<size_t>(b) * 16 + (n)] = static_cast<long long>(hw_) | (static_cast<long long>(xcc_) << 32); \
+    }                                                                                                   \
+  } while (0)
 #else
 #define EEA_WSTAMP(n) do { } while (0)
+#define EEA_WSTAMP_RT(n) do { } while (0)
+#define EEA_WSTAMP_HWID(n) do { } while (0)
 #endif
 
 namespace eea
@@ -169,6 +185,8 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   const R* const pose = p.pose + 3 * static_cast<size_t>(b);
   R* const ut = p.ut + 3 * static_cast<size_t>(T) * b;
 
+  EEA_WSTAMP_RT(10);
+  EEA_WSTAMP_HWID(12);
   EEA_WSTAMP(0);
   // ---- controls: shift left by one column, last column zero (ergodic_control.hpp:233-234) ------------
   R vx[kMaxS], vy[kMaxS], w[kMaxS];
@@ -834,6 +852,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
     }
   }
   EEA_WSTAMP(9);
+  EEA_WSTAMP_RT(11);
 }
 
 }  // namespace wave

@@ -45,6 +45,48 @@ def main():
     else:
         s = stamps.cpu().numpy().reshape(-1)[:B * 16].reshape(B, 1, 16)[:, :, :10].astype(np.float64)
         names = PHASES_WAVE
+    if not wg:
+        raw = stamps.cpu().numpy().reshape(-1)[:B * 16].reshape(B, 16)
+        rt = raw[:, 10:12].astype(np.float64) * 10.0  # 100 MHz counter -> ns
+        life_ns = rt[:, 1] - rt[:, 0]
+        cyc = (raw[:, 9] - raw[:, 0]).astype(np.float64)
+        print("shader clock while the wavefronts ran: %.2f GHz (mean of cycles / lifetime); launch span %.2f us, "
+              "wave lifetime %.2f us mean" % ((cyc / life_ns).mean(), (rt[:, 1].max() - rt[:, 0].min()) * 1e-3,
+                                              life_ns.mean() * 1e-3))
+        hw = raw[:, 12]
+        key = (hw >> 32 << 16) | (((hw >> 13) & 7) << 12) | (((hw >> 12) & 1) << 11) | (((hw >> 8) & 15) << 4) | ((hw >> 4) & 3)
+        order = {}
+        for a in range(B):
+            order.setdefault(int(key[a]), []).append(a)
+        per = np.array([len(v) for v in order.values()])
+        print("SIMDs used %d; wavefronts per SIMD min %d mean %.2f max %d" % (len(order), per.min(), per.mean(), per.max()))
+        # finishing order within a SIMD (shader clock of one XCD: comparable within the SIMD)
+        rows = []
+        both = {"mfma": 0.0, "grad": 0.0, "span": 0.0}
+        for v in order.values():
+            if len(v) != 4:
+                continue
+            st = raw[v][:, :10].astype(np.float64)
+            t0 = st[:, 0].min()
+            fin = np.sort(st[:, 9] - t0)
+            rows.append(fin)
+            # time with >= 2 wavefronts of the SIMD inside the same exclusive phase
+            for name, (a, b_) in (("mfma", (4, 5)), ("grad", (6, 7))):
+                ev = sorted([(x, 1) for x in st[:, a]] + [(x, -1) for x in st[:, b_]])
+                n, last, acc = 0, 0.0, 0.0
+                for x, dn in ev:
+                    if n >= 2:
+                        acc += x - last
+                    n += dn
+                    last = x
+                both[name] += acc
+            both["span"] += st[:, 9].max() - t0
+        if rows:
+            rows = np.array(rows)
+            print("SIMDs with 4 wavefronts: %d; finish times after the SIMD's first start (cycles): %s" %
+                  (len(rows), " / ".join("%.0f" % x for x in rows.mean(0))))
+            print("  share of the SIMD's span with >= 2 wavefronts inside the contraction: %.1f %%, inside the gradient: "
+                  "%.1f %%" % (100 * both["mfma"] / both["span"], 100 * both["grad"] / both["span"]))
     d = np.diff(s, axis=2)
     total = s[:, :, -1] - s[:, :, 0]
     print("agents %d: wave lifetime mean %.0f cycles (min %.0f max %.0f); launch span %.0f cycles; first start "
