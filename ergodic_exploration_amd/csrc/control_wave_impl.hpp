@@ -503,13 +503,21 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
         lds_fence();
         read_operands();  // rows of lanes 0..31, step j
         lds_fence();      // operands in registers: the tile is free
-        // pass (j, lower half) on the matrix pipe; meanwhile lanes 32..63 store their rows of step j
+        // pass (j, lower half) on the matrix pipe; meanwhile lanes 32..63 store their rows of step j.
+        // Row groups past the horizon (all-zero rows) are skipped where no store is interleaved with them
+        // (m >= kPairs): fp64 matrix instructions hold the vector pipe of the whole SIMD for their 64 cycles
+        // (profiles/r02_ubench_coissue.txt), so at T = 200 the 3 empty groups of every upper pass are 19 % of the
+        // contraction's pipe time
+        const int nl = (T - j + S - 1) / S;                       // lanes l with S l + j < T
+        const int n_lo = ((nl < 32 ? nl : 32) + 3) >> 2, n_up = (nl - 32 + 3) >> 2;  // row groups with a valid row
         {
           Tab u = t;
 #pragma unroll
           for (int m = 0; m < kStageRows / 4; ++m) {
-            if (m & 1) acc1 = M::run(oa[m], ob[m], acc1);
-            else acc0 = M::run(oa[m], ob[m], acc0);
+            if (m < kPairs || m < n_lo) {  // wavefront-uniform
+              if (m & 1) acc1 = M::run(oa[m], ob[m], acc1);
+              else acc0 = M::run(oa[m], ob[m], acc0);
+            }
             if (m < kPairs) {
               if (!lo) tab_store(u, 2 * m);
               tab_step(u);
@@ -527,8 +535,10 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
           Tab u = t;
 #pragma unroll
           for (int m = 0; m < kStageRows / 4; ++m) {
-            if (m & 1) acc1 = M::run(oa[m], ob[m], acc1);
-            else acc0 = M::run(oa[m], ob[m], acc0);
+            if (m < kPairs || m < n_up) {  // wavefront-uniform
+              if (m & 1) acc1 = M::run(oa[m], ob[m], acc1);
+              else acc0 = M::run(oa[m], ob[m], acc0);
+            }
             if (m < kPairs) {
               if (lo) tab_store(u, 2 * m);
               tab_step(u);

@@ -34,7 +34,7 @@ def main():
     d_pose = torch.as_tensor(poses).cuda()
     d_ut = torch.zeros((B, T, 3), dtype=torch.float64, device="cuda")
     d_u0 = torch.empty((B, 3), dtype=torch.float64, device="cuda")
-    for _ in range(5):
+    for _ in range(int(os.environ.get("EEA_PHASE_WARMUP", "5"))):  # a long warm-up = the clock under sustained load
         eng.control_batch(B, d_pose, d_ut, d_u0)
     stamps = torch.zeros((B, 4, 16), dtype=torch.int64, device="cuda")
     eng.debug_phase_timing(B, d_pose, d_ut, d_u0, stamps)
