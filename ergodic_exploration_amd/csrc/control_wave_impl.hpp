@@ -119,6 +119,24 @@ __device__ __forceinline__ double fma_k<double>(double v, int k, double acc)
   return d;
 }
 
+// v_permlane32_swap (gfx950): from_lower = v of lane l - 32 in the upper 32 lanes, from_upper = v of lane l + 32 in the
+// lower 32 lanes (probed: the builtin returns { [a.lower, b.lower], [a.upper, b.upper] })
+__device__ __forceinline__ void half_swap(double v, double& from_lower, double& from_upper)
+{
+  const unsigned lo = static_cast<unsigned>(__double2loint(v)), hi = static_cast<unsigned>(__double2hiint(v));
+  const auto rl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto rh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  from_lower = __hiloint2double(static_cast<int>(rh[0]), static_cast<int>(rl[0]));
+  from_upper = __hiloint2double(static_cast<int>(rh[1]), static_cast<int>(rl[1]));
+}
+__device__ __forceinline__ void half_swap(float v, float& from_lower, float& from_upper)
+{
+  const unsigned u = static_cast<unsigned>(__float_as_int(v));
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  from_lower = __int_as_float(static_cast<int>(r[0]));
+  from_upper = __int_as_float(static_cast<int>(r[1]));
+}
+
 template <typename R, int MODEL>
 __device__ __forceinline__ void model_xy(R vx, R vy, R c, R s, R& fx, R& fy)
 {
@@ -485,16 +503,54 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
         ob[m] = taby[off];
       }
     };
+    // Staging, one axis per lane: the tile of a pass (32 points) is written by ALL 64 lanes -- for the points of
+    // lanes 0..31 the lower lanes run the x recurrence of their own point and the upper lanes the y recurrence of
+    // the point of lane l - 32 (its cos b comes over v_permlane32_swap), for the points of lanes 32..63 the other way
+    // round.  An LDS write costs its 6 / 13 cycles (b64 / b128) per instruction whatever the number of active lanes
+    // (profiles/r02_ubench_coissue.txt), and one LDS serves the four SIMDs: 5 full stores per pass instead of 10
+    // half-masked ones, and 2 instead of 4 multiply-adds per stored pair.
     const bool lo = lane < 32;
-    Tab t = tab_init(c1x[0], c1y[0], i0 < T);
+    const int row = lane & 31;
+    R* const st_lower = (lo ? tabx : taby) + row * KS;  // staging the tile of the points of lanes 0..31
+    R* const st_upper = (lo ? taby : tabx) + row * KS;  // ... of lanes 32..63
+    struct Tab1
     {
-      Tab u = t;
-      if (lo) {
+      R a, b, two;  // T_k, T_{k+1}, 2 cos
+    };
+    auto tab1_init = [&](R c, bool valid) {
+      Tab1 t;
+      t.a = valid ? R(1) : R(0);
+      t.b = valid ? c : R(0);
+      t.two = c + c;
+      return t;
+    };
+    auto tab1_store = [&](const Tab1& t, R* dst, int k) {
+      if (sizeof(R) == 8) {
+        *reinterpret_cast<double2*>(dst + k) = double2{ static_cast<double>(t.a), static_cast<double>(t.b) };
+      } else {
+        *reinterpret_cast<float2*>(dst + k) = float2{ static_cast<float>(t.a), static_cast<float>(t.b) };
+      }
+    };
+    auto tab1_step = [&](Tab1& t) {
+      const R c = t.two * t.b - t.a, d = t.two * c - t.b;
+      t.a = c;
+      t.b = d;
+    };
+    // cos of this lane's axis for the two tiles of step j (jj: a compile-time index after unrolling)
+    auto stage_cos = [&](int jj, R& c_lower, R& c_upper) {
+      R from_lower, from_upper;  // c1y of lane l - 32 (valid in the upper lanes), of lane l + 32 (in the lower ones)
+      half_swap(c1y[jj], from_lower, from_upper);
+      c_lower = lo ? c1x[jj] : from_lower;
+      c_upper = lo ? from_upper : c1x[jj];
+    };
+    R cl, cu;
+    stage_cos(0, cl, cu);
+    {
+      Tab1 u = tab1_init(cl, S * row < T);
 #pragma unroll
-        for (int q = 0; q < kPairs; ++q) {
-          tab_store(u, 2 * q);
-          tab_step(u);
-        }
+      for (int q = 0; q < kPairs; ++q) {
+        tab1_store(u, st_lower, 2 * q);
+        tab1_step(u);
       }
     }
 #pragma unroll
@@ -503,7 +559,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
         lds_fence();
         read_operands();  // rows of lanes 0..31, step j
         lds_fence();      // operands in registers: the tile is free
-        // pass (j, lower half) on the matrix pipe; meanwhile lanes 32..63 store their rows of step j.
+        // pass (j, lower half) on the matrix pipe; meanwhile the tile of the points of lanes 32..63 of step j.
         // Row groups past the horizon (all-zero rows) are skipped where no store is interleaved with them
         // (m >= kPairs): fp64 matrix instructions hold the vector pipe of the whole SIMD for their 64 cycles
         // (profiles/r02_ubench_coissue.txt), so at T = 200 the 3 empty groups of every upper pass are 19 % of the
@@ -511,7 +567,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
         const int nl = (T - j + S - 1) / S;                       // lanes l with S l + j < T
         const int n_lo = ((nl < 32 ? nl : 32) + 3) >> 2, n_up = (nl - 32 + 3) >> 2;  // row groups with a valid row
         {
-          Tab u = t;
+          Tab1 u = tab1_init(cu, S * (row + 32) + j < T);
 #pragma unroll
           for (int m = 0; m < kStageRows / 4; ++m) {
             if (m < kPairs || m < n_lo) {  // wavefront-uniform
@@ -519,8 +575,8 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
               else acc0 = M::run(oa[m], ob[m], acc0);
             }
             if (m < kPairs) {
-              if (!lo) tab_store(u, 2 * m);
-              tab_step(u);
+              tab1_store(u, st_upper, 2 * m);
+              tab1_step(u);
             }
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -528,11 +584,11 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
         lds_fence();
         read_operands();  // rows of lanes 32..63, step j
         lds_fence();
-        // pass (j, upper half); meanwhile the tables of step j + 1 and the stores of lanes 0..31
+        // pass (j, upper half); meanwhile the tile of the points of lanes 0..31 of step j + 1
         {
           const int jn = (j + 1 < kMaxS) ? j + 1 : j;
-          t = tab_init(c1x[jn], c1y[jn], (j + 1 < S) && (i0 + j + 1 < T));
-          Tab u = t;
+          stage_cos(jn, cl, cu);
+          Tab1 u = tab1_init(cl, (j + 1 < S) && (S * row + j + 1 < T));
 #pragma unroll
           for (int m = 0; m < kStageRows / 4; ++m) {
             if (m < kPairs || m < n_up) {  // wavefront-uniform
@@ -540,8 +596,8 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
               else acc0 = M::run(oa[m], ob[m], acc0);
             }
             if (m < kPairs) {
-              if (lo) tab_store(u, 2 * m);
-              tab_step(u);
+              tab1_store(u, st_lower, 2 * m);
+              tab1_step(u);
             }
             __builtin_amdgcn_sched_barrier(0);
           }
