@@ -354,25 +354,25 @@ def main():
 
     cabi_comm = comm if comm is not None else (None if use_dist else comm_local)
 
-    def exchange_consensus(slot):
-        """c_bar of pass `slot`'s c_k over ALL agents of all ranks -> d_cbar[slot], beside the compute stream"""
+    def exchange_consensus(slot, xslot):
+        """c_bar of the c_k in d_ck[slot] over ALL agents of all ranks -> d_cbar[xslot], beside the compute stream"""
         if cabi_comm is not None:
             # one call: the communicator's own stream waits for the pass, runs eea_ck_sum + all-reduce + divide
-            cabi_comm.consensus_ck_async(eng, B, d_ck[slot], d_cbar[slot], compute.cuda_stream, slot)
+            cabi_comm.consensus_ck_async(eng, B, d_ck[slot], d_cbar[xslot], compute.cuda_stream, xslot)
             return
         xstream.wait_event(ev_ck[slot])
         if use_dist and backend == "nccl":
             with torch.cuda.stream(xstream):
                 sums = torch.cat([d_ck[slot].sum(0), torch.tensor([float(B)], dtype=tdt, device="cuda")])
                 dist.all_reduce(sums)
-                d_cbar[slot].copy_(sums[:-1] / sums[-1])
+                d_cbar[xslot].copy_(sums[:-1] / sums[-1])
         elif use_dist:
             with torch.cuda.stream(xstream):
                 sums = torch.cat([d_ck[slot].sum(0), torch.tensor([float(B)], dtype=tdt, device="cuda")]).cpu()
             dist.all_reduce(sums)
             with torch.cuda.stream(xstream):
-                d_cbar[slot].copy_((sums[:-1] / sums[-1]).cuda(), non_blocking=False)
-        ev_x[slot].record(xstream)
+                d_cbar[xslot].copy_((sums[:-1] / sums[-1]).cuda(), non_blocking=False)
+        ev_x[xslot].record(xstream)
 
     def exchange_allgather(slot):
         if comm is not None:
@@ -392,41 +392,56 @@ def main():
         ev_x[slot].record(xstream)
 
     state = {"i": 0, "every": 1}
+    # eea_batch_io structs are built once per distinct buffer set, a pass is one ctypes call
+    shard_calls = [eng.prepared_batch(a["B"], a["pose"], a["ut"], a["u0"], mem_cols=a["mem_cols"], n_mem=a["n_mem"],
+                                      mem_stride=args.n_mem, stream=a["stream"]) for a in gargs]
+    exch_calls = {}
 
     def one_pass(leg):
         i = state["i"]
         state["i"] = i + 1
         slot = i % NB
         if leg == "shard":
-            for a in gargs:
-                eng.control_batch(a["B"], a["pose"], a["ut"], a["u0"], mem_cols=a["mem_cols"], n_mem=a["n_mem"],
-                                  mem_stride=args.n_mem, stream=a["stream"])
+            for call in shard_calls:
+                call()
             return
-        shared = None
+        shared, src = None, None
         in_c = (cabi_comm is not None) if leg == "consensus" else (comm is not None)  # events live in the C ABI
-        if leg == "consensus" and i >= args.consensus_lag:
-            if state["every"] == 1:
-                src = (i - args.consensus_lag) % NB
-            else:
-                src = state.get("last", 0)   # the most recent exchange (started at least one pass ago)
-            if in_c:
-                cabi_comm.wait(src, compute.cuda_stream)   # the consensus of pass i - lag has arrived
-            else:
-                compute.wait_event(ev_x[src])
-            shared = d_cbar[src]
+        if leg == "consensus":
+            # exchange number x is started after pass x * every; a pass consumes the consensus of exchange i - lag
+            # (every pass) or of the exchange BEFORE the most recent one (every n-th pass: the most recent may still
+            # be in flight, and a control kernel holds every SIMD, so waiting for it would stall the pass)
+            every = state["every"]
+            x = (i - args.consensus_lag) if every == 1 else (i // every - 1)
+            if x >= 0:
+                src = x % NB
+                if in_c:
+                    cabi_comm.wait(src, compute.cuda_stream)
+                else:
+                    compute.wait_event(ev_x[src])
+                shared = d_cbar[src]
         if leg == "allgather" and i >= 2:
             if in_c:
                 comm.wait((i - 2) % NB, compute.cuda_stream)  # the gather that read this slot's predecessor is done
             else:
                 compute.wait_event(ev_x[(i - 2) % NB])
-        eng.control_batch(B, d_pose, d_ut, d_u0, mem_cols=d_mem, n_mem=d_nmem, mem_stride=args.n_mem,
-                          ck=d_ck[slot], ck_shared=shared, stream=compute.cuda_stream)
+        # c_k leaves the kernel only on the passes that feed an exchange (every n-th pass: into the buffer of that
+        # exchange, which its predecessor of NB exchanges ago has long finished reading)
+        feeds = leg != "consensus" or i % state["every"] == 0
+        if leg == "consensus" and state["every"] > 1:
+            slot = (i // state["every"]) % NB
+        key = (slot if feeds else None, None if shared is None else src)
+        call = exch_calls.get(key)
+        if call is None:
+            call = exch_calls[key] = eng.prepared_batch(B, d_pose, d_ut, d_u0, mem_cols=d_mem, n_mem=d_nmem,
+                                                        mem_stride=args.n_mem, ck=d_ck[slot] if feeds else None,
+                                                        ck_shared=shared, stream=compute.cuda_stream)
+        call()
         if not in_c:
             ev_ck[slot].record(compute)
         if leg == "consensus":
-            if i % state["every"] == 0:   # exchange every n-th pass; the passes in between reuse the last consensus
-                exchange_consensus(slot)
-                state["last"] = slot
+            if feeds:   # exchange every n-th pass; the passes in between reuse an earlier consensus
+                exchange_consensus(slot, (i // state["every"]) % NB)
         else:
             exchange_allgather(slot)
 
@@ -434,7 +449,6 @@ def main():
         """EXACTLY `steps` steps between barrier + synchronize on both sides; max over ranks"""
         state["i"] = 0
         state["every"] = every
-        state.pop("last", None)
         d_ut.zero_()
         for _ in range(warmup * R):
             one_pass(leg)
@@ -471,15 +485,17 @@ def main():
     exchange = None
     if not args.no_exchange:
         exchange = {"backend": exchange_backend, "consumer": "eea_batch_io::d_ck_shared (gradient uses c_bar)"}
-        e_s, p_ms, _ = timed("consensus", args.steps, args.warmup)
+        e_s, p_ms, q_s = timed("consensus", args.steps, args.warmup)
         exchange["consensus_allreduce"] = {
+            "host_enqueue_us_per_pass": 1e6 * q_s / (args.steps * R),
             "value": world * B * R * args.steps / e_s, "unit": "optimisations/s", "ms_per_step": 1e3 * e_s / args.steps,
             "pass_ms": p_ms, "lag_passes": args.consensus_lag,
             "bytes_per_rank_per_pass": rs * (K2 + 1),
             "note": "every pass: eea_ck_sum + ncclAllReduce(K^2+1 reals) + divide on a second stream; pass i uses the "
                     "consensus of pass i - lag"}
-        e_s, p_ms, _ = timed("consensus", args.steps, args.warmup, every=8)
+        e_s, p_ms, q_s = timed("consensus", args.steps, args.warmup, every=8)
         exchange["consensus_allreduce_every_8_passes"] = {
+            "host_enqueue_us_per_pass": 1e6 * q_s / (args.steps * R),
             "value": world * B * R * args.steps / e_s, "unit": "optimisations/s", "ms_per_step": 1e3 * e_s / args.steps,
             "pass_ms": p_ms, "note": "the same exchange on every 8th pass; the passes in between use the last consensus"}
         if use_dist or args.force_exchange:

@@ -275,6 +275,25 @@ class Engine:
         io.d_rhot, io.d_status = _ptr(rhot), _ptr(status)
         check(lib().eea_control_batch(self.h, B, C.byref(io), C.c_void_p(stream or 0)))
 
+    def prepared_batch(self, B, pose, ut, u0, mem_cols=None, n_mem=None, mem_stride=0, ck=None, ck_shared=None,
+                       stream=None):
+        """A callable that issues eea_control_batch with these (fixed) device buffers: one ctypes call per pass, the
+        eea_batch_io is built once (a pass of 4096 agents takes ~30 us on the device; building the struct from
+        tensors every pass costs about as much on the host)."""
+        io = BatchIO()
+        io.d_ck_shared = _ptr(ck_shared)
+        io.d_pose, io.d_ut, io.d_u0 = _ptr(pose), _ptr(ut), _ptr(u0)
+        io.d_mem_cols, io.d_n_mem, io.mem_stride = _ptr(mem_cols), _ptr(n_mem), mem_stride
+        io.d_ck = _ptr(ck)
+        fn, h, ref, st = lib().eea_control_batch, self.h, C.byref(io), C.c_void_p(stream or 0)
+        keep = (io, pose, ut, u0, mem_cols, n_mem, ck, ck_shared)
+
+        def call(_keep=keep):
+            rc = fn(h, B, ref, st)
+            if rc != 0:
+                check(rc)
+        return call
+
     def ck_sum(self, B, ck, sums, stream=None):
         """sums[:K2] = sum over the B agents of ck, sums[K2] = B (device tensors)"""
         check(lib().eea_ck_sum(self.h, B, _ptr(ck), _ptr(sums), C.c_void_p(stream or 0)))

@@ -543,6 +543,8 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
       c_lower = lo ? c1x[jj] : from_lower;
       c_upper = lo ? from_upper : c1x[jj];
     };
+    // lanes l with S l + j < T: floor((T - 1 - j) / S) + 1 = q + (j <= rem), one division for all steps
+    const int nl_q = (T - 1) / S, nl_rem = (T - 1) - S * nl_q;
     R cl, cu;
     stage_cos(0, cl, cu);
     {
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
         // (m >= kPairs): fp64 matrix instructions hold the vector pipe of the whole SIMD for their 64 cycles
         // (profiles/r02_ubench_coissue.txt), so at T = 200 the 3 empty groups of every upper pass are 19 % of the
         // contraction's pipe time
-        const int nl = (T - j + S - 1) / S;                       // lanes l with S l + j < T
+        const int nl = nl_q + (j <= nl_rem ? 1 : 0);              // lanes l with S l + j < T
         const int n_lo = ((nl < 32 ? nl : 32) + 3) >> 2, n_up = (nl - 32 + 3) >> 2;  // row groups with a valid row
         {
           Tab1 u = tab1_init(cu, S * (row + 32) + j < T);
