@@ -410,56 +410,65 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
     }
   };
 
-  // Tiles: 32 rows [point][k] per axis.  One pass of 8 matrix instructions consumes the 32 rows staged by one
-  // half of the wavefront (lanes [32 h, 32 h + 32): one point each, zero rows for invalid points).
-  // cos(k a) = T_k(cos a) by the Chebyshev recurrence, two entries (one 16-byte store per axis) per step.
-  struct Tab
+  // Tiles: 32 rows [point][k] per axis.  One pass of up to 8 matrix instructions consumes the 32 points of one half
+  // of the wavefront (lanes [32 h, 32 h + 32); zero rows for invalid points).
+  // cos(k a) = T_k(cos a) by the Chebyshev recurrence, two entries (one 16-byte store) per step.
+  // Staging, one axis per lane: the tile of a pass is written by ALL 64 lanes -- for the points of lanes 0..31 the
+  // lower lanes run the x recurrence of their own point and the upper lanes the y recurrence of the point of lane
+  // l - 32 (its cos b comes over v_permlane32_swap), for the points of lanes 32..63 the other way round.  An LDS
+  // write costs its 6 / 13 cycles (b64 / b128) per instruction whatever the number of active lanes
+  // (profiles/r02_ubench_coissue.txt), and one LDS serves the four SIMDs: per pass one full store per mode pair
+  // instead of two half-masked ones, and 2 instead of 4 multiply-adds.
+  const bool lo = lane < 32;
+  const int row = lane & 31;
+  R* const st_lower = (lo ? tabx : taby) + row * KS;  // staging the tile of the points of lanes 0..31
+  R* const st_upper = (lo ? taby : tabx) + row * KS;  // ... of lanes 32..63
+  struct Tab1
   {
-    R xa, xb, ya, yb, twoa, twob;
+    R a, b, two;  // T_k, T_{k+1}, 2 cos
   };
-  auto tab_init = [&](R ca, R cb, bool valid) {
-    Tab t;
-    const R one = valid ? R(1) : R(0);
-    t.xa = one;
-    t.xb = valid ? ca : R(0);
-    t.ya = one;
-    t.yb = valid ? cb : R(0);
-    t.twoa = ca + ca;
-    t.twob = cb + cb;
+  auto tab1_init = [&](R c, bool valid) {
+    Tab1 t;
+    t.a = valid ? R(1) : R(0);
+    t.b = valid ? c : R(0);
+    t.two = c + c;
     return t;
   };
-  auto tab_store = [&](const Tab& t, int k) {  // entries k, k + 1 of this lane's row
-    R* const tx = tabx + (lane & 31) * KS + k;
-    R* const ty = taby + (lane & 31) * KS + k;
+  auto tab1_store = [&](const Tab1& t, R* dst, int k) {  // entries k, k + 1 of the row
     if (sizeof(R) == 8) {
-      *reinterpret_cast<double2*>(tx) = double2{ static_cast<double>(t.xa), static_cast<double>(t.xb) };
-      *reinterpret_cast<double2*>(ty) = double2{ static_cast<double>(t.ya), static_cast<double>(t.yb) };
+      *reinterpret_cast<double2*>(dst + k) = double2{ static_cast<double>(t.a), static_cast<double>(t.b) };
     } else {
-      *reinterpret_cast<float2*>(tx) = float2{ static_cast<float>(t.xa), static_cast<float>(t.xb) };
-      *reinterpret_cast<float2*>(ty) = float2{ static_cast<float>(t.ya), static_cast<float>(t.yb) };
+      *reinterpret_cast<float2*>(dst + k) = float2{ static_cast<float>(t.a), static_cast<float>(t.b) };
     }
   };
-  auto tab_step = [&](Tab& t) {
-    const R xc = t.twoa * t.xb - t.xa, xd = t.twoa * xc - t.xb;
-    const R yc = t.twob * t.yb - t.ya, yd = t.twob * yc - t.yb;
-    t.xa = xc;
-    t.xb = xd;
-    t.ya = yc;
-    t.yb = yd;
+  auto tab1_step = [&](Tab1& t) {
+    const R c = t.two * t.b - t.a, d = t.two * c - t.b;
+    t.a = c;
+    t.b = d;
   };
-  constexpr int kPairs = KS / 2;  // 16-byte stores per row and axis
-  // plain (not software-pipelined) half pass: the replay-memory columns and the generic-K instance
-  auto stage_and_mma = [&](R ca, R cb, bool valid, int h, int rows_valid) {
-    if ((lane >> 5) == h) {
-      Tab t = tab_init(ca, cb, valid);
+  // cos of this lane's axis for the two tiles of 64 points (ca, cb: cos of the x / y angle of this lane's point)
+  auto stage_cos = [&](R ca, R cb, R& c_lower, R& c_upper) {
+    R from_lower, from_upper;  // cb of lane l - 32 (valid in the upper lanes), of lane l + 32 (in the lower ones)
+    half_swap(cb, from_lower, from_upper);
+    c_lower = lo ? ca : from_lower;
+    c_upper = lo ? from_upper : ca;
+  };
+  constexpr int kPairs = KS / 2;  // 16-byte stores per row
+  // plain (not software-pipelined) pass over the points of half h of the wavefront, of which the first nl_valid
+  // lanes of the wavefront hold a valid point: the replay-memory columns and the generic-K / K = 20 instances
+  auto stage_and_mma = [&](R c_axis, int h, int nl_valid) {
+    {
+      Tab1 t = tab1_init(c_axis, 32 * h + row < nl_valid);
+      R* const dst = h ? st_upper : st_lower;
 #pragma unroll
       for (int q = 0; q < kPairs; ++q) {
         if (!kRowGuard || 2 * q < K) {
-          tab_store(t, 2 * q);
-          tab_step(t);
+          tab1_store(t, dst, 2 * q);
+          tab1_step(t);
         }
       }
     }
+    const int rows_valid = nl_valid - 32 * h;  // > 0 (the caller skips empty halves)
     lds_fence();
     if (NT == 1) {
 #pragma unroll
@@ -503,50 +512,10 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
         ob[m] = taby[off];
       }
     };
-    // Staging, one axis per lane: the tile of a pass (32 points) is written by ALL 64 lanes -- for the points of
-    // lanes 0..31 the lower lanes run the x recurrence of their own point and the upper lanes the y recurrence of
-    // the point of lane l - 32 (its cos b comes over v_permlane32_swap), for the points of lanes 32..63 the other way
-    // round.  An LDS write costs its 6 / 13 cycles (b64 / b128) per instruction whatever the number of active lanes
-    // (profiles/r02_ubench_coissue.txt), and one LDS serves the four SIMDs: 5 full stores per pass instead of 10
-    // half-masked ones, and 2 instead of 4 multiply-adds per stored pair.
-    const bool lo = lane < 32;
-    const int row = lane & 31;
-    R* const st_lower = (lo ? tabx : taby) + row * KS;  // staging the tile of the points of lanes 0..31
-    R* const st_upper = (lo ? taby : tabx) + row * KS;  // ... of lanes 32..63
-    struct Tab1
-    {
-      R a, b, two;  // T_k, T_{k+1}, 2 cos
-    };
-    auto tab1_init = [&](R c, bool valid) {
-      Tab1 t;
-      t.a = valid ? R(1) : R(0);
-      t.b = valid ? c : R(0);
-      t.two = c + c;
-      return t;
-    };
-    auto tab1_store = [&](const Tab1& t, R* dst, int k) {
-      if (sizeof(R) == 8) {
-        *reinterpret_cast<double2*>(dst + k) = double2{ static_cast<double>(t.a), static_cast<double>(t.b) };
-      } else {
-        *reinterpret_cast<float2*>(dst + k) = float2{ static_cast<float>(t.a), static_cast<float>(t.b) };
-      }
-    };
-    auto tab1_step = [&](Tab1& t) {
-      const R c = t.two * t.b - t.a, d = t.two * c - t.b;
-      t.a = c;
-      t.b = d;
-    };
-    // cos of this lane's axis for the two tiles of step j (jj: a compile-time index after unrolling)
-    auto stage_cos = [&](int jj, R& c_lower, R& c_upper) {
-      R from_lower, from_upper;  // c1y of lane l - 32 (valid in the upper lanes), of lane l + 32 (in the lower ones)
-      half_swap(c1y[jj], from_lower, from_upper);
-      c_lower = lo ? c1x[jj] : from_lower;
-      c_upper = lo ? from_upper : c1x[jj];
-    };
     // lanes l with S l + j < T: floor((T - 1 - j) / S) + 1 = q + (j <= rem), one division for all steps
     const int nl_q = (T - 1) / S, nl_rem = (T - 1) - S * nl_q;
     R cl, cu;
-    stage_cos(0, cl, cu);
+    stage_cos(c1x[0], c1y[0], cl, cu);
     {
       Tab1 u = tab1_init(cl, S * row < T);
 #pragma unroll
@@ -589,7 +558,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
         // pass (j, upper half); meanwhile the tile of the points of lanes 0..31 of step j + 1
         {
           const int jn = (j + 1 < kMaxS) ? j + 1 : j;
-          stage_cos(jn, cl, cu);
+          stage_cos(c1x[jn], c1y[jn], cl, cu);
           Tab1 u = tab1_init(cl, (j + 1 < S) && (S * row + j + 1 < T));
 #pragma unroll
           for (int m = 0; m < kStageRows / 4; ++m) {
@@ -613,12 +582,10 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
       if (j < S) {
         // lanes l with S l + j < T  <=>  l < ceil((T - j) / S)
         const int nl = (T - j + S - 1) / S;
-        const bool valid = i0 + j < T;
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int rows = nl - 32 * h;
-          if (rows > 0) stage_and_mma(c1x[j], c1y[j], valid, h, rows > 32 ? 32 : rows);
-        }
+        R cl, cu;
+        stage_cos(c1x[j], c1y[j], cl, cu);
+        stage_and_mma(cl, 0, nl);
+        if (nl > 32) stage_and_mma(cu, 1, nl);
       }
     }
   }
@@ -632,12 +599,11 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
         sincospi_r((mem[3 * q + 0] - p.map_x) * p.inv_lx, &sa, &ca);
         sincospi_r((mem[3 * q + 1] - p.map_y) * p.inv_ly, &sb, &cb);
       }
-      const int nl = nmem - c0;
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int rows = nl - 32 * h;
-        if (rows > 0) stage_and_mma(ca, cb, valid, h, rows > 32 ? 32 : rows);
-      }
+      const int nl = nmem - c0;  // > 0
+      R cl, cu;
+      stage_cos(ca, cb, cl, cu);
+      stage_and_mma(cl, 0, nl);
+      if (nl > 32) stage_and_mma(cu, 1, nl);
     }
   }
 
