@@ -102,12 +102,13 @@ __global__ __launch_bounds__(kBlock) void axis_tables_kernel(const R* __restrict
 }
 
 // Target::fill without the normalisation, Gaussians passed by value (no upload, no synchronisation):
-// kFillPerThread grid points per thread, one partial sum of phi per workgroup (fixed order).  The workgroups
+// per_thread grid points per thread (target_fill_per_thread), one partial sum of phi per workgroup (fixed order).  The workgroups
 // beyond fill_blocks compute the two axis tables of the rebuild (axis_tables_kernel's job) in the same launch.
 template <typename R>
 __global__ __launch_bounds__(kBlock) void target_fill_args_kernel(const R* __restrict__ coord, int nx, int ny,
                                                                   const GaussArgs<R> ga, R* __restrict__ phi,
-                                                                  R* __restrict__ partials, int fill_blocks, int K,
+                                                                  R* __restrict__ partials, int fill_blocks, int per_thread,
+                                                                  int K,
                                                                   R pi_lx, R pi_ly, R* __restrict__ cx,
                                                                   R* __restrict__ cy)
 {
@@ -126,10 +127,10 @@ __global__ __launch_bounds__(kBlock) void target_fill_args_kernel(const R* __res
     return;
   }
   const size_t P = static_cast<size_t>(nx) * ny;
-  const size_t base = static_cast<size_t>(blockIdx.x) * (kBlock * kFillPerThread);
+  const size_t base = static_cast<size_t>(blockIdx.x) * (static_cast<size_t>(kBlock) * per_thread);
   R acc = R(0);
 #pragma unroll 4
-  for (int r = 0; r < kFillPerThread; ++r) {
+  for (int r = 0; r < per_thread; ++r) {
     const size_t q = base + static_cast<size_t>(r) * kBlock + threadIdx.x;
     if (q < P) {
       const int iy = static_cast<int>(q / nx), ix = static_cast<int>(q - static_cast<size_t>(iy) * nx);
@@ -617,7 +618,14 @@ hipError_t launch_axis_tables(const R* d_coord, int nx, int ny, int K, R pi_lx, 
   return hipGetLastError();
 }
 
-int target_fill_blocks(size_t P) { return static_cast<int>((P + kBlock * kFillPerThread - 1) / (kBlock * kFillPerThread)); }
+// grid points per thread of the fill kernel: 16 on large grids (fewer partial sums, enough workgroups anyway), 1 on
+// small ones -- at 121 x 61 sixteen points per thread are two workgroups running 32 serial exp() each (12 us)
+int target_fill_per_thread(size_t P) { return P >= (static_cast<size_t>(1) << 22) ? kFillPerThread : (P >= (static_cast<size_t>(1) << 18) ? 4 : 1); }
+int target_fill_blocks(size_t P)
+{
+  const size_t per_block = static_cast<size_t>(kBlock) * target_fill_per_thread(P);
+  return static_cast<int>((P + per_block - 1) / per_block);
+}
 
 template <typename R>
 hipError_t launch_target_fill_args(const R* d_coord, int nx, int ny, const GaussArgs<R>& ga, R* d_phi,
@@ -628,7 +636,7 @@ hipError_t launch_target_fill_args(const R* d_coord, int nx, int ny, const Gauss
   // d_cx == nullptr: the tables are current, fill only
   const int tab_blocks = d_cx != nullptr ? ((nx + ny) * K + kBlock - 1) / kBlock : 0;
   hipLaunchKernelGGL(target_fill_args_kernel<R>, dim3(fill_blocks + tab_blocks), dim3(kBlock), 0, s, d_coord, nx,
-                     ny, ga, d_phi, d_partials, fill_blocks, K, pi_lx, pi_ly, d_cx, d_cy);
+                     ny, ga, d_phi, d_partials, fill_blocks, target_fill_per_thread(P), K, pi_lx, pi_ly, d_cx, d_cy);
   return hipGetLastError();
 }
 
