@@ -247,7 +247,9 @@ __global__ __launch_bounds__(kBlock) void spatial_stream_kernel(const IN* __rest
                                                                 const R* __restrict__ cx,
                                                                 const R* __restrict__ cy,
                                                                 const R* __restrict__ lut,
-                                                                R* __restrict__ partials)
+                                                                R* __restrict__ partials,
+                                                                R* __restrict__ phik_direct,
+                                                                R* __restrict__ mass_out)
 {
   constexpr bool kCells = !std::is_same<IN, R>::value;
   // columns per lane and load: 16 bytes of values; 8 (one 8-byte load) or 4 occupancy cells
@@ -457,6 +459,21 @@ __global__ __launch_bounds__(kBlock) void spatial_stream_kernel(const IN* __rest
         if (k2 < K && k1 < K) s_red[wave * K2 + k2 * K + k1] = macc[a][b][r];  // col = k2*K + k1
       }
   __syncthreads();
+  if (phik_direct != nullptr) {
+    // the only workgroup of a small grid: its sums are final.  Normalisation of target.cpp:87 folded in: mode (0,0)
+    // of the un-normalised sums is the mass of the grid (cos 0 = 1); no second launch
+    R mass = R(0);
+#pragma unroll
+    for (int w = 0; w < kBlock / kWave; ++w) mass += s_red[w * K2];
+    for (int m = tid; m < K2; m += kBlock) {
+      R t = R(0);
+#pragma unroll
+      for (int w = 0; w < kBlock / kWave; ++w) t += s_red[w * K2 + m];
+      phik_direct[m] = t / mass;
+    }
+    if (tid == 0) mass_out[0] = mass;
+    return;
+  }
   R* const out = partials + (static_cast<size_t>(blockIdx.y) * gridDim.x + blockIdx.x) * K2;
   for (int m = tid; m < K2; m += kBlock) {
     R t = R(0);
@@ -774,15 +791,19 @@ hipError_t launch_spatial_generic(const IN* d_in, int nx, int ny, int K, const R
     if (elems < static_cast<size_t>(4) * K2) elems = static_cast<size_t>(4) * K2;
     const size_t lds = elems * sizeof(R);
     const dim3 grid(col_tiles, row_tiles);
+    // one tile and the normalised form asked for: the streaming kernel finishes the job itself
+    const bool direct = d_mass_partials != nullptr && col_tiles * row_tiles == 1;
+    R* const d_direct = direct ? d_phik : nullptr;
+    R* const d_direct_mass = direct ? d_mass : nullptr;
     if (NT == 1) {
       hipLaunchKernelGGL((spatial_stream_kernel<R, 1, IN>), grid, dim3(kBlock), lds, s, d_in, nx, ny, K, rpt,
-                         d_cx, d_cy, d_lut, d_work);
+                         d_cx, d_cy, d_lut, d_work, d_direct, d_direct_mass);
     } else {
       hipLaunchKernelGGL((spatial_stream_kernel<R, 2, IN>), grid, dim3(kBlock), lds, s, d_in, nx, ny, K, rpt,
-                         d_cx, d_cy, d_lut, d_work);
+                         d_cx, d_cy, d_lut, d_work, d_direct, d_direct_mass);
     }
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || direct) return e;
     if (d_mass_partials != nullptr) {
       hipLaunchKernelGGL(sum_partials_norm_kernel<R>, dim3((K2 + kModesPerSumBlock - 1) / kModesPerSumBlock),
                          dim3(kBlock), 0, s, d_work, col_tiles * row_tiles, K2, d_mass_partials, n_mass, d_phik,
