@@ -123,6 +123,22 @@ def test_steps_per_lane_boundaries(steps):
     run_batch_vs_oracle("omni", 20, steps * 0.125, 0.125, B=2, n_mem=65, calls=2, seed=44)
 
 
+@pytest.mark.parametrize("steps", [2, 3, 4, 29, 32, 33, 36, 37, 66, 72, 73, 125, 129, 140, 141, 217])
+def test_contraction_row_group_boundaries(steps):
+    """The contraction of the wavefront kernel stages a pass of 32 points with ALL 64 lanes (one axis per lane, the
+    partner point's cosine over v_permlane32_swap) and skips row groups of 4 points past the horizon: horizons whose
+    number of valid lanes ceil((T - j) / S) sits at / next to 32 and to multiples of 4 (one, two and four steps per
+    lane; the two-step minimum of the reference; the replay-memory pass with fewer than 32 / more than 32 columns), K = 10 and 5
+    (software-pipelined pass), K = 12 (generic instance), fp64; K = 10 again in fp32."""
+    run_batch_vs_oracle("simple_cart", 10, steps * 0.125, 0.125, B=3, n_mem=0, calls=2, seed=61)
+    run_batch_vs_oracle("omni", 5, steps * 0.125, 0.125, B=2, n_mem=30, calls=2, seed=62)
+    run_batch_vs_oracle("omni", 12, steps * 0.125, 0.125, B=2, n_mem=35, calls=1, seed=63)
+    # fp32 against the fp64 oracle: with dt = 0.125 the longer horizons leave the 12 m map, the barrier gradient
+    # (2 x 25 x distance) and with it the co-state reach 1e2-1e3: absolute bar scaled accordingly (relative ~1e-5)
+    run_batch_vs_oracle("omni", 10, steps * 0.125, 0.125, B=2, n_mem=33, calls=2, seed=64, precision=capi.PREC_F32,
+                        tol=5e-4 if steps <= 40 else 1e-2, tol_ck=1e-5)
+
+
 @pytest.mark.parametrize("dt", [0.1, 1.0, 2.0])
 def test_small_and_large_step_increments(dt):
     """The wavefront kernel takes the sin/cos of a step's mid-stage / post-step heading and of its later basis
