@@ -1,4 +1,4 @@
-// Diagnostic build of the fused control kernel with phase stamps (EEA_TIMING): K = 10, fp64 only.
+// Diagnostic build of the fused control kernel with phase stamps (EEA_TIMING): K = 10 and 30, fp64 only.
 // Not used by the product path; reached through eea_debug_phase_timing.
 #define EEA_TIMING 1
 #include "control_kernel_impl.hpp"
@@ -9,9 +9,13 @@ hipError_t launch_control_timing(const ControlParams<double>& p, unsigned B, int
                                  hipStream_t stream)
 {
   if (B == 0) return hipSuccess;
-  if (p.K != 10) return hipErrorInvalidValue;
+  if (p.K != 10 && p.K != 30) return hipErrorInvalidValue;
   const int Nmax = p.T + n_mem_max;
   const size_t lds = static_cast<size_t>(lds_layout(p.T, Nmax, p.K, 4).total) * sizeof(double);
+  if (p.K == 30) {  // the BASELINE config 5 shape
+    if (model == kModelOmni) return launch_one<double, kModelOmni, 30, 256>(p, B, Nmax, false, lds, stream);
+    return launch_one<double, kModelSimpleCart, 30, 256>(p, B, Nmax, false, lds, stream);
+  }
   if (model == kModelOmni) return launch_one<double, kModelOmni, 10, 256>(p, B, Nmax, false, lds, stream);
   return launch_one<double, kModelSimpleCart, 10, 256>(p, B, Nmax, false, lds, stream);
 }

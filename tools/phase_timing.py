@@ -22,10 +22,13 @@ PHASES_WAVE = ["load+shift controls", "heading scan", "heading sincos + position
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    wg = os.environ.get("EEA_CONTROL_PATH") == "workgroup"
+    wg = os.environ.get("EEA_CONTROL_PATH") == "workgroup" or int(os.environ.get("EEA_PHASE_K", "10")) > 20 or \
+        float(os.environ.get("EEA_PHASE_HORIZON", "20.0")) > 25.6
     model = capi.MODEL_SIMPLE_CART
     lim = np.array([1.0, 0.0, 2.0])
-    eng = capi.Engine(capi.make_config(model, 0.1, 20.0, 0.1, 1.0, 10, np.diag([1.0, 0.0, 2.0]), -lim, lim))
+    K = int(os.environ.get("EEA_PHASE_K", "10"))
+    horizon = float(os.environ.get("EEA_PHASE_HORIZON", "20.0"))  # dt = 0.1
+    eng = capi.Engine(capi.make_config(model, 0.1, horizon, 0.1, 1.0, K, np.diag([1.0, 0.0, 2.0]), -lim, lim))
     eng.set_target_gaussians([[2.5, 2.5], [8.5, 2.5]], [[1.5, 1.5], [1.5, 1.5]])
     eng.config_domain((-1.0, 11.0, -1.0, 5.0))
     T, K2 = eng.T, eng.K2
