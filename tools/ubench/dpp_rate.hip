@@ -54,14 +54,23 @@ int main()
   (void)hipMalloc(&out, sizeof(double) * 1024 * cus);
   (void)hipMalloc(&cyc, sizeof(long long) * 16 * cus);
   std::vector<long long> h(16 * cus);
-  const int iters = 2000;
+  const int iters = 200000;
   for (int NTHR = 256; NTHR <= 1024; NTHR *= 2)
   for (int dpp = 0; dpp < 2; ++dpp) {
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    float ms = 0;
     for (int r = 0; r < 2; ++r) {
+      (void)hipEventRecord(e0, 0);
       if (dpp) hipLaunchKernelGGL(rate<1>, dim3(cus), dim3(NTHR), 0, 0, out, cyc, iters, 1.0);
       else hipLaunchKernelGGL(rate<0>, dim3(cus), dim3(NTHR), 0, 0, out, cyc, iters, 1.0);
+      (void)hipEventRecord(e1, 0);
+      (void)hipDeviceSynchronize();
+      (void)hipEventElapsedTime(&ms, e0, e1);
     }
-    (void)hipDeviceSynchronize();
+    printf("  wall %.3f ms -> %.1f TFLOP/s fp64 (2 flop per lane and instruction)\n", ms,
+           2.0 * 64 * 16.0 * iters * (NTHR / 64) * cus / (ms * 1e-3) / 1e12);
     const int nw = NTHR / 64 * cus;
     (void)hipMemcpy(h.data(), cyc, sizeof(long long) * nw, hipMemcpyDeviceToHost);
     double s = 0;
