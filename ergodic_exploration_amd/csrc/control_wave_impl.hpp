@@ -14,15 +14,20 @@
 //     gradient's multiply-add chains of different steps interleave, so one wavefront keeps the vector pipe
 //     busy where the one-step-per-lane kernel waited on its own dependency chains;
 //   * c_k = (1/N) Cx Cy^T on the matrix cores, fed through a wavefront-private LDS tile of 32 points
-//     [point][k], software-pipelined (the next pass's table recurrence and stores are issued between the
-//     matrix instructions): the accumulator of v_mfma_f64_16x16x4_f64 already holds the COMPLETE sums of the
-//     agent, so D = lambda (c - phi) is formed in registers and written once for the gradient;
+//     [point][k] that all 64 lanes stage (one axis per lane, the partner point's cosine over
+//     v_permlane32_swap), software-pipelined (the next pass's table recurrence and stores are issued between
+//     the matrix instructions): the accumulator of v_mfma_f64_16x16x4_f64 already holds the COMPLETE sums of
+//     the agent, so D = lambda (c - phi) is formed in registers and written once for the gradient;
 //   * cos(k a), sin(k a) by the Chebyshev three-term recurrences (T_{k+1} = 2c T_k - T_{k-1}, sin(k a) =
 //     sin(a) U_{k-1}): one multiply-add per table entry instead of the four of the rotation recurrence;
 //   * the gradient makes ONE pass over D per step (rows from LDS, wavefront-uniform broadcast reads: the LDS
 //     return path, 4 cycles per 16-byte row read and wavefront, is what bounded a two-pass form) with the
-//     cosine array and the G accumulators of ONE step in registers at a time: 128 registers, 4 wavefronts per
-//     SIMD, 9.3 KB of LDS per agent -- the 4096-agent batch is resident on the 1024 SIMDs in one round.
+//     cosine array and the G accumulators of ONE step in registers at a time: <= 128 registers, 4 wavefronts
+//     per SIMD, 9.3 KB of LDS per agent -- the 4096-agent batch is resident on the 1024 SIMDs in one round.
+//
+// What bounds it (profiles/r02_ubench_coissue.txt): fp64 matrix instructions run on the
+// vector pipe's own multipliers and hold it for their 64 cycles, so the pipe time of an agent is the SUM of its
+// vector and matrix instructions; LDS writes cost 13 cycles per 16-byte instruction whatever the lane mask.
 //
 // Steps beyond 256 and bases beyond K = 16 (other than 20) stay on the workgroup-per-agent kernel
 // (control_kernel_impl.hpp); the engine picks.  rollout_only (optTraj / path) stops after the forward half,
