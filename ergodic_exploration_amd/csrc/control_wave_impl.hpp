@@ -372,14 +372,13 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
         sincospi_r(x * p.inv_lx, &s1x[j], &c1x[j]);
         sincospi_r(y * p.inv_ly, &s1y[j], &c1y[j]);
       }
-      const R eps = R(0.05), weight = R(25);
-      R b0 = R(0), b1 = R(0);
-      b0 += R(2) * static_cast<R>(x > p.lx - eps) * (x - (p.lx - eps));
-      b1 += R(2) * static_cast<R>(y > p.ly - eps) * (y - (p.ly - eps));
-      b0 += R(2) * static_cast<R>(x < eps) * (x - eps);
-      b1 += R(2) * static_cast<R>(y < eps) * (y - eps);
-      g0[j] = b0 * weight;
-      g1[j] = b1 * weight;
+      // gradBarrier (:453-474): 25 * (2 [x > lx - eps] (x - (lx - eps)) + 2 [x < eps] (x - eps)) per axis.  The
+      // indicator times the difference is max(difference, 0) / min(difference, 0) (x > a <=> x - a > 0 in IEEE
+      // arithmetic), at most one of the two is non-zero on any domain wider than 2 eps, and 2 * 25 is exact: the same
+      // value from 6 instead of ~11 instructions per axis
+      const R eps = R(0.05), weight2 = R(50);
+      g0[j] = (fmax(x - (p.lx - eps), R(0)) + fmin(x - eps, R(0))) * weight2;
+      g1[j] = (fmax(y - (p.ly - eps), R(0)) + fmin(y - eps, R(0))) * weight2;
     }
   }
 
