@@ -23,6 +23,7 @@ import os
 import socket
 import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -312,47 +313,13 @@ def main():
     d_cbar = [torch.zeros((K2,), dtype=tdt, device="cuda") for _ in range(NB)]
     ev_ck = [torch.cuda.Event() for _ in range(NB)]
     ev_x = [torch.cuda.Event() for _ in range(NB)]
+    # the communicator is created AFTER the headline leg, under a watchdog (setup_exchange below): a collective
+    # library that cannot start on some node must not take the driver-timed line with it
     comm = None
+    comm_local = None
+    cabi_comm = None
     exchange_backend = "local (1 rank)"
-    if use_dist and not args.no_exchange or args.force_exchange:
-        if backend == "nccl" or not use_dist:
-            # the C ABI's own RCCL communicator: rank 0 creates the id, torch.distributed only carries it.  If that
-            # fails on some rank, every rank falls back to torch.distributed's collectives (the run must not die
-            # with a secondary leg)
-            ok = 1
-            uid = [None]
-            if rank == 0:
-                try:
-                    uid = [capi.comm_unique_id()]
-                except Exception as exc:  # noqa: BLE001
-                    sys.stderr.write("rank 0: eea_comm_get_unique_id failed (%r)\n" % (exc,))
-            if use_dist:
-                dist.broadcast_object_list(uid, src=0)   # every rank takes part, also when rank 0 has nothing to send
-            try:
-                if uid[0] is None:
-                    raise RuntimeError("no RCCL id")
-                comm = capi.Comm(device, world, rank, uid[0])
-            except Exception as exc:  # noqa: BLE001
-                sys.stderr.write("rank %d: eea_comm_create failed (%r); torch.distributed collectives instead\n" % (rank, exc))
-                ok = 0
-            if use_dist:
-                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                ok = int(flag.item())
-            if ok:
-                exchange_backend = "rccl through the C ABI (eea_comm_*)"
-            else:
-                if comm is not None:
-                    comm.close()
-                comm = None
-                exchange_backend = "rccl through torch.distributed (eea_comm_create failed)"
-        else:
-            exchange_backend = "gloo, staged through the host (ranks share a GPU: plumbing run)"
-    if comm is None:
-        comm_local = capi.Comm(device, 1, 0, None)
     d_all = None
-
-    cabi_comm = comm if comm is not None else (None if use_dist else comm_local)
 
     def exchange_consensus(slot, xslot):
         """c_bar of the c_k in d_ck[slot] over ALL agents of all ranks -> d_cbar[xslot], beside the compute stream"""
@@ -390,6 +357,47 @@ def main():
             with torch.cuda.stream(xstream):
                 d_all[slot % 2].copy_(hall)
         ev_x[slot].record(xstream)
+
+    def setup_exchange():
+        nonlocal comm, comm_local, cabi_comm, exchange_backend
+        if use_dist and not args.no_exchange or args.force_exchange:
+            if backend == "nccl" or not use_dist:
+                # the C ABI's own RCCL communicator: rank 0 creates the id, torch.distributed only carries it.  If that
+                # fails on some rank, every rank falls back to torch.distributed's collectives (the run must not die
+                # with a secondary leg)
+                ok = 1
+                uid = [None]
+                if rank == 0:
+                    try:
+                        uid = [capi.comm_unique_id()]
+                    except Exception as exc:  # noqa: BLE001
+                        sys.stderr.write("rank 0: eea_comm_get_unique_id failed (%r)\n" % (exc,))
+                if use_dist:
+                    dist.broadcast_object_list(uid, src=0)   # every rank takes part, also when rank 0 has nothing to send
+                try:
+                    if uid[0] is None:
+                        raise RuntimeError("no RCCL id")
+                    comm = capi.Comm(device, world, rank, uid[0])
+                except Exception as exc:  # noqa: BLE001
+                    sys.stderr.write("rank %d: eea_comm_create failed (%r); torch.distributed collectives instead\n" % (rank, exc))
+                    ok = 0
+                if use_dist:
+                    flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                    ok = int(flag.item())
+                if ok:
+                    exchange_backend = "rccl through the C ABI (eea_comm_*)"
+                else:
+                    if comm is not None:
+                        comm.close()
+                    comm = None
+                    exchange_backend = "rccl through torch.distributed (eea_comm_create failed)"
+            else:
+                exchange_backend = "gloo, staged through the host (ranks share a GPU: plumbing run)"
+        if comm is None:
+            comm_local = capi.Comm(device, 1, 0, None)
+        cabi_comm = comm if comm is not None else (None if use_dist else comm_local)
+
 
     state = {"i": 0, "every": 1}
     # eea_batch_io structs are built once per distinct buffer set, a pass is one ctypes call
@@ -482,33 +490,7 @@ def main():
 
     elapsed, pass_ms, enqueue_s = timed("shard", args.steps, args.warmup)
 
-    exchange = None
-    if not args.no_exchange:
-        exchange = {"backend": exchange_backend, "consumer": "eea_batch_io::d_ck_shared (gradient uses c_bar)"}
-        e_s, p_ms, q_s = timed("consensus", args.steps, args.warmup)
-        exchange["consensus_allreduce"] = {
-            "host_enqueue_us_per_pass": 1e6 * q_s / (args.steps * R),
-            "value": world * B * R * args.steps / e_s, "unit": "optimisations/s", "ms_per_step": 1e3 * e_s / args.steps,
-            "pass_ms": p_ms, "lag_passes": args.consensus_lag,
-            "bytes_per_rank_per_pass": rs * (K2 + 1),
-            "note": "every pass: eea_ck_sum + ncclAllReduce(K^2+1 reals) + divide on a second stream; pass i uses the "
-                    "consensus of pass i - lag"}
-        e_s, p_ms, q_s = timed("consensus", args.steps, args.warmup, every=8)
-        exchange["consensus_allreduce_every_8_passes"] = {
-            "host_enqueue_us_per_pass": 1e6 * q_s / (args.steps * R),
-            "value": world * B * R * args.steps / e_s, "unit": "optimisations/s", "ms_per_step": 1e3 * e_s / args.steps,
-            "pass_ms": p_ms, "note": "the same exchange on every 8th pass; the passes in between use the last consensus"}
-        if use_dist or args.force_exchange:
-            d_all = [torch.empty((world * B, K2), dtype=tdt, device="cuda") for _ in range(2)]
-            e_s, p_ms, _ = timed("allgather", args.steps, args.warmup)
-            exchange["allgather_ck"] = {
-                "value": world * B * R * args.steps / e_s, "unit": "optimisations/s",
-                "ms_per_step": 1e3 * e_s / args.steps, "pass_ms": p_ms,
-                "bytes_received_per_rank_per_pass": rs * K2 * B * world,
-                "note": "every pass: one ncclAllGather of all agents' c_k (north_star's exchange); nothing on the "
-                        "control path consumes the gathered matrix -- the consensus leg is the consuming form"}
-
-    result_line = None
+    out = None
     if rank == 0:
         N = T + args.n_mem
         K = args.num_basis
@@ -569,8 +551,6 @@ def main():
                              "launch_ms": pass_ms, "agents_per_launch": Bl, "concurrent_launches": G,
                              "achieved_per_launch": hbm_gbs / G},
         }
-        if exchange is not None:
-            out["exchange"] = exchange
         if world == 1 and args.cpu_seconds > 0:
             one, allc = cpu_baseline(args, args.cpu_seconds)
             out["cpu_baseline"] = one
@@ -591,22 +571,78 @@ def main():
                 out.update(phik_legs(args, torch, capi, np))
             except Exception as exc:  # the headline line must not die with a secondary leg
                 out["roofline_phik"] = {"error": repr(exc)}
-        result_line = json.dumps(out)
+
+    emitted = threading.Lock()
+
+    def emit():
+        """the ONE JSON line, written in one piece after every C-level stdio buffer (collective library banners) has
+        been flushed; at most once per process"""
+        if not emitted.acquire(blocking=False):
+            return
+        if rank == 0:
+            import ctypes
+            sys.stdout.flush()
+            try:
+                ctypes.CDLL(None).fflush(None)
+            except OSError:
+                pass
+            os.write(1, (json.dumps(out) + "\n").encode())
+
+    # ---- exchange legs: last, and under a watchdog.  They are the only part of this program that has never run on
+    # more than one GPU; if a collective never returns, every rank gives up after the timeout, rank 0 still prints
+    # the line (with the reason in "exchange") and the processes exit without waiting for the library
+    if not args.no_exchange:
+        limit = float(os.environ.get("EEA_BENCH_EXCHANGE_TIMEOUT", "300"))
+        finished = threading.Event()
+
+        def watchdog():
+            if finished.wait(limit):
+                return
+            if rank == 0:
+                out["exchange"] = {"error": "exchange legs did not finish within %g s; headline leg unaffected" % limit}
+            emit()
+            os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
+        try:
+            setup_exchange()
+            exchange = {"backend": exchange_backend, "consumer": "eea_batch_io::d_ck_shared (gradient uses c_bar)"}
+            e_s, p_ms, q_s = timed("consensus", args.steps, args.warmup)
+            exchange["consensus_allreduce"] = {
+                "host_enqueue_us_per_pass": 1e6 * q_s / (args.steps * R),
+                "value": world * B * R * args.steps / e_s, "unit": "optimisations/s", "ms_per_step": 1e3 * e_s / args.steps,
+                "pass_ms": p_ms, "lag_passes": args.consensus_lag,
+                "bytes_per_rank_per_pass": rs * (K2 + 1),
+                "note": "every pass: eea_ck_sum + ncclAllReduce(K^2+1 reals) + divide on a second stream; pass i uses the "
+                        "consensus of pass i - lag"}
+            e_s, p_ms, q_s = timed("consensus", args.steps, args.warmup, every=8)
+            exchange["consensus_allreduce_every_8_passes"] = {
+                "host_enqueue_us_per_pass": 1e6 * q_s / (args.steps * R),
+                "value": world * B * R * args.steps / e_s, "unit": "optimisations/s", "ms_per_step": 1e3 * e_s / args.steps,
+                "pass_ms": p_ms, "note": "the same exchange on every 8th pass; the passes in between use the last consensus"}
+            if use_dist or args.force_exchange:
+                d_all = [torch.empty((world * B, K2), dtype=tdt, device="cuda") for _ in range(2)]
+                e_s, p_ms, _ = timed("allgather", args.steps, args.warmup)
+                exchange["allgather_ck"] = {
+                    "value": world * B * R * args.steps / e_s, "unit": "optimisations/s",
+                    "ms_per_step": 1e3 * e_s / args.steps, "pass_ms": p_ms,
+                    "bytes_received_per_rank_per_pass": rs * K2 * B * world,
+                    "note": "every pass: one ncclAllGather of all agents' c_k (north_star's exchange); nothing on the "
+                            "control path consumes the gathered matrix -- the consensus leg is the consuming form"}
+
+        except Exception as exc:  # noqa: BLE001 -- the headline line must not die with a secondary leg
+            exchange = {"error": repr(exc)}
+        finished.set()
+        if rank == 0:
+            out["exchange"] = exchange
     if comm is not None:
         comm.close()
+    if comm_local is not None:
+        comm_local.close()
     eng.close()
     if use_dist:
         dist.destroy_process_group()
-    if rank == 0:
-        # last thing on stdout: the ONE JSON line, written in one piece after every C-level
-        # stdio buffer (collective library banners) has been flushed
-        import ctypes
-        sys.stdout.flush()
-        try:
-            ctypes.CDLL(None).fflush(None)
-        except OSError:
-            pass
-        os.write(1, (result_line + "\n").encode())
+    emit()
 
 
 if __name__ == "__main__":

@@ -262,3 +262,23 @@ def test_bench_self_launches_its_ranks(extra):
     else:
         assert rec["exchange"]["consensus_allreduce"]["value"] > 0
         assert rec["exchange"]["allgather_ck"]["value"] > 0
+
+
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_bench_headline_survives_a_stuck_exchange(gpus):
+    """The exchange legs run last and under a watchdog: if they do not finish in time (here: a limit no run can meet;
+    on a node whose collective library never returns it would be the 300 s default), every rank exits cleanly and
+    rank 0 still prints the ONE line with the headline value and the reason under "exchange"."""
+    env = dict(os.environ, EEA_BENCH_EXCHANGE_TIMEOUT="0.001")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "2", "--warmup", "1",
+           "--passes-per-step", "3", "--agents", "256", "--cpu-seconds", "0", "--no-latency", "--no-phik"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == gpus and rec["value"] > 0 and "roofline" in rec
+    assert "did not finish" in rec["exchange"]["error"]
+
