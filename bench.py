@@ -259,7 +259,10 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+            # host tensors over gloo, device tensors over RCCL, and no device_id: the RCCL communicator is created by
+            # the first DEVICE collective -- which only the exchange legs issue.  The barriers and the max-over-ranks
+            # of the timed region are host collectives, so the headline leg does not depend on RCCL starting up
+            dist.init_process_group("cpu:gloo,cuda:nccl")
         else:
             dist.init_process_group(backend)
 
@@ -373,7 +376,7 @@ def main():
                     except Exception as exc:  # noqa: BLE001
                         sys.stderr.write("rank 0: eea_comm_get_unique_id failed (%r)\n" % (exc,))
                 if use_dist:
-                    dist.broadcast_object_list(uid, src=0)   # every rank takes part, also when rank 0 has nothing to send
+                    dist.broadcast_object_list(uid, src=0, device=torch.device("cpu"))   # every rank takes part (over gloo)
                 try:
                     if uid[0] is None:
                         raise RuntimeError("no RCCL id")
@@ -382,7 +385,7 @@ def main():
                     sys.stderr.write("rank %d: eea_comm_create failed (%r); torch.distributed collectives instead\n" % (rank, exc))
                     ok = 0
                 if use_dist:
-                    flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                    flag = torch.tensor([ok], dtype=torch.int32)  # host tensor: gloo
                     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
                     ok = int(flag.item())
                 if ok:
@@ -453,6 +456,10 @@ def main():
         else:
             exchange_allgather(slot)
 
+    def host_barrier():
+        """a barrier every rank leaves together, as a host collective (gloo): independent of the device library"""
+        dist.all_reduce(torch.zeros(1, dtype=torch.float64))
+
     def timed(leg, steps, warmup, every=1):
         """EXACTLY `steps` steps between barrier + synchronize on both sides; max over ranks"""
         state["i"] = 0
@@ -462,7 +469,7 @@ def main():
             one_pass(leg)
         torch.cuda.synchronize()
         if use_dist:
-            dist.barrier()
+            host_barrier()
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
@@ -473,18 +480,13 @@ def main():
         enqueue_s = time.perf_counter() - t0
         torch.cuda.synchronize()  # all streams of the device
         if use_dist:
-            dist.barrier()
+            host_barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         pass_ms = ev0.elapsed_time(ev1) / (steps * R)  # HIP events on the kernel's own stream
         if use_dist:
-            t = torch.tensor([elapsed, pass_ms], dtype=torch.float64, device="cuda")
-            if backend == "nccl":
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            else:
-                th = t.cpu()
-                dist.all_reduce(th, op=dist.ReduceOp.MAX)
-                t = th
+            t = torch.tensor([elapsed, pass_ms], dtype=torch.float64)  # host tensor: gloo
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed, pass_ms = float(t[0]), float(t[1])
         return elapsed, pass_ms, enqueue_s
 
@@ -534,7 +536,8 @@ def main():
                        "agents_per_gpu": B, "num_basis": K, "horizon_steps": T, "kinematics": args.model,
                        "passes_per_step": R, "optimisations_per_step": world * B * R,
                        "agent_groups": G, "parallelism": "agent-batch x%d" % world,
-                       "dist_backend": backend if use_dist else None},
+                       "dist_backend": ("gloo (host collectives: barriers, timing) + nccl (device collectives: exchange legs)"
+                                        if backend == "nccl" else backend) if use_dist else None},
             "timed_region_s": elapsed, "ms_per_pass": 1e3 * elapsed / (args.steps * R),
             "host_enqueue_us_per_pass": 1e6 * enqueue_s / (args.steps * R),
             "parity_tol": PARITY_TOL[args.precision],
