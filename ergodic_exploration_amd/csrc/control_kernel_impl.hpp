@@ -439,7 +439,7 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
   }
   // point q of the contraction is this thread's own rollout point when nothing is prepended and the
   // horizon is one chunk; the other threads' points are first read after the reduction's barrier
-  const bool own_points = (nmem == 0) && !multi_chunk;
+  const bool own_points = (nmem == 0) && !multi_chunk && KC != 30;  // K = 30 stages cooperatively (below): LDS
   if (!own_points) __syncthreads();
   EEA_STAMP(5);
 
@@ -482,9 +482,11 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
         }
       }
 
-      constexpr int KA = KC > 0 ? KC : 1;
+      // K = 30 (the BASELINE config 5 shape) stages a pass with ALL 64 lanes: see stage30 below
+      constexpr bool kCoop = (KC == 30);
+      constexpr int KA = (KC > 0 && !kCoop) ? KC : 1;
       R cxr[KA], cyr[KA];
-      if (KC > 0) {
+      if (KC > 0 && !kCoop) {
         // cos(k a) for k < K by the angle-addition recurrence; zero rows for padding points
         R ck = have ? R(1) : R(0), sk = R(0), dk = have ? R(1) : R(0), ek = R(0);
 #pragma unroll
@@ -526,6 +528,45 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
           }
         }
       };
+      // K = 30: a pass is 8 points x 2 axes x 30 modes = 480 table entries.  Written by the 8 lanes that own the
+      // points they are 60 LDS stores of 8 active lanes each -- and an LDS write costs its 6 / 13 cycles per
+      // instruction whatever the mask (profiles/r02_ubench_coissue.txt): 47k LDS cycles per CU in this phase, its
+      // bottleneck.  Instead all 64 lanes stage: lane = (point l % 8, axis (l / 8) % 2, mode group l / 16): it reads
+      // the point's cos / sin of that axis from LDS, reaches cos / sin of 8, 16, 24 times the angle by doubling,
+      // takes its group's first two modes by one rotation and the other six by the Chebyshev recurrence, and
+      // writes its 8 (last group: 6) consecutive entries: 4 full 16-byte stores per pass.
+      auto stage30 = [&](int s) {
+        const int pt = lane & 7, ax = (lane >> 3) & 1, mg = lane >> 4;
+        const int qq = c0 + wave * kWave + s * kSub + pt;
+        const bool hv = qq < N;
+        const int qc = hv ? qq : 0;
+        const R c = ax ? s_c1y[qc] : s_c1x[qc];
+        const R sn = ax ? s_s1y[qc] : s_s1x[qc];
+        const R c2 = (c + c) * c - R(1), s2 = (sn + sn) * c;
+        const R c4 = (c2 + c2) * c2 - R(1), s4 = (s2 + s2) * c2;
+        const R c8 = (c4 + c4) * c4 - R(1), s8 = (s4 + s4) * c4;
+        const R c16 = (c8 + c8) * c8 - R(1), s16 = (s8 + s8) * c8;
+        const R c24 = c16 * c8 - s16 * s8, s24 = s16 * c8 + c16 * s8;
+        R cs = (mg == 0) ? R(1) : (mg == 1 ? c8 : (mg == 2 ? c16 : c24));
+        R ss = (mg == 0) ? R(0) : (mg == 1 ? s8 : (mg == 2 ? s16 : s24));
+        R a = hv ? cs : R(0);                         // T_{8 mg}; zero rows for padding points
+        R bq = hv ? (cs * c - ss * sn) : R(0);        // T_{8 mg + 1}
+        const R two = c + c;
+        R* const dst = (ax ? taby : tabx) + pt * KS + 8 * mg;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (i < 3 || mg < 3) {  // modes 30, 31 do not exist (row stride 30)
+            if (sizeof(R) == 8) {
+              *reinterpret_cast<double2*>(dst + 2 * i) = double2{ static_cast<double>(a), static_cast<double>(bq) };
+            } else {
+              *reinterpret_cast<float2*>(dst + 2 * i) = float2{ static_cast<float>(a), static_cast<float>(bq) };
+            }
+          }
+          const R n0 = two * bq - a, n1 = two * n0 - bq;
+          a = n0;
+          bq = n1;
+        }
+      };
       // four points per matrix instruction: operand of lane l = element (4g + l/16) * KS + l%16
       auto mma_group = [&](int g) {
         const int off = (4 * g + mk) * KS + mi;
@@ -546,7 +587,8 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
         // full wavefront (the common case): no bounds tests, everything unrolled
 #pragma unroll
         for (int s = 0; s < kWave / kSub; ++s) {
-          stage(s);
+          if (kCoop) stage30(s);
+          else stage(s);
           wave_lds_fence();
 #pragma unroll
           for (int g = 0; g < kSub / 4; ++g) mma_group(g);
@@ -555,7 +597,8 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
       } else {
         for (int s = 0; s < kWave / kSub; ++s) {
           if (s * kSub >= nvalid) break;  // wave-uniform
-          stage(s);
+          if (kCoop) stage30(s);
+          else stage(s);
           wave_lds_fence();
 #pragma unroll
           for (int g = 0; g < kSub / 4; ++g) {
