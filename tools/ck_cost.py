@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Cost of the optional c_k output / shared c_k input / exchange waits of eea_control_batch at the metric point
+(4096 agents, one launch per pass): none of them moves the pass time (profiles/r02_ablation.txt)."""
 import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
