@@ -240,6 +240,40 @@ def test_config5_end_to_end_against_oracle():
     eng.close()
 
 
+def test_prepared_batch_is_the_same_call():
+    """Engine.prepared_batch (bench.py's per-pass call: the eea_batch_io built once) issues exactly eea_control_batch:
+    bitwise the same controls, first twists and c_k as control_batch on the same inputs, over consecutive passes, with
+    replay memory, a shared c_k and a caller stream."""
+    rng = np.random.default_rng(7)
+    B, K, n_mem = 9, 10, 12
+    eng, _ = make_pair("omni", K, 20.0, n_oracles=0)
+    T, K2 = eng.T, eng.K2
+    poses = random_poses(rng, B)
+    ut0 = rng.uniform(-0.5, 0.5, (B, T, 3))
+    mem = random_poses(rng, B * n_mem).reshape(B, n_mem, 3)
+    cbar = rng.uniform(-0.1, 0.1, K2)
+    stream = torch.cuda.Stream()
+    res = []
+    for prepared in (False, True):
+        d_pose, d_ut, d_mem, d_cbar = dev(poses), dev(ut0), dev(mem), dev(cbar)
+        d_nmem = torch.full((B,), n_mem, dtype=torch.int32, device="cuda")
+        d_u0 = torch.empty((B, 3), dtype=torch.float64, device="cuda")
+        d_ck = torch.empty((B, K2), dtype=torch.float64, device="cuda")
+        torch.cuda.synchronize()
+        kw = dict(mem_cols=d_mem, n_mem=d_nmem, mem_stride=n_mem, ck=d_ck, ck_shared=d_cbar, stream=stream.cuda_stream)
+        call = eng.prepared_batch(B, d_pose, d_ut, d_u0, **kw) if prepared else None
+        for _ in range(3):
+            if prepared:
+                call()
+            else:
+                eng.control_batch(B, d_pose, d_ut, d_u0, **kw)
+        torch.cuda.synchronize()
+        res.append([t.cpu().numpy().copy() for t in (d_ut, d_u0, d_ck)])
+    eng.close()
+    for a, b in zip(*res):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("extra", [["--no-exchange"], []])
 def test_bench_self_launches_its_ranks(extra):
     """`python bench.py --gpus 2` exactly as the driver would type it for N > 1 without a launcher: the
