@@ -50,6 +50,30 @@ def test_phik_matches_oracle(K, bounds, means, sigmas):
     eng.close()
 
 
+@pytest.mark.parametrize("res,bounds,K", [
+    (0.1, (0.0, 12.0, 0.0, 6.0), 10),       # 121 x 61: 1 grid point per thread of the fill kernel, one-tile direct finish
+    (0.02, (0.0, 11.98, 0.0, 9.98), 6),     # 600 x 500 = 3.0e5 >= 2^18 points: 4 per thread
+    (0.01, (-1.0, 20.0, 2.0, 23.0), 5),     # 2101 x 2101 = 4.4e6 >= 2^22 points: 16 per thread
+])
+def test_fill_kernel_regimes(res, bounds, K):
+    """Target::fill takes 1 / 4 / 16 grid points per thread by grid size (and a grid of one tile is normalised by the
+    streaming kernel itself): phi_k and the normalised grid against the oracle in each regime."""
+    means, sigmas = [[2.5, 3.5], [8.5, 6.5]], [[1.5, 1.0], [0.8, 2.0]]
+    eng = _engine(K, res)
+    eng.set_target_gaussians(means, sigmas)
+    assert eng.config_domain(bounds) is True
+    o = _oracle_phik(K, bounds, means, sigmas, res)
+    d = np.abs(eng.phik() - o.phik)
+    # mode (0,0) is the mass ratio: the oracle adds the 4.4e6 values in one sequential chain (1e-11 of rounding there)
+    assert d[1:].max() < 1e-11 and d[0] < 1e-10
+    pv, nx, ny = eng.target_grid()
+    lx, ly = bounds[1] - bounds[0], bounds[3] - bounds[2]
+    assert nx == po.lib().eo_axis_length(0.0, lx, res) + 1 and ny == po.lib().eo_axis_length(0.0, ly, res) + 1
+    ref = po.target_fill(means, sigmas, [bounds[0], bounds[2]], po.phi_grid(nx, ny, res))
+    assert np.abs(pv - ref).max() < 1e-14
+    eng.close()
+
+
 def test_phik_anchor_from_reference(anchors):
     a = anchors["phik_K10_121x61_trans0"]
     eng = _engine(a["num_basis"], a["resolution"])
