@@ -828,10 +828,11 @@ eea_status eea_debug_phase_timing(eea_engine* e, unsigned B, const eea_batch_io*
     return fail(EEA_ERR_INVALID_ARGUMENT, "d_pose, d_ut, d_u0 and d_stamps are required");
   }
   if (!e->have_phik) return fail(EEA_ERR_NO_TARGET, "no phi_k");
-  if (e->f32) return fail(EEA_ERR_UNSUPPORTED, "phase timing is built for fp64 only");
   eea_status st = use_device(e);
   if (st != EEA_OK) return st;
-  return control_batch_impl<double>(e, B, io, false, static_cast<hipStream_t>(stream), d_stamps);
+  // fp32: the wavefront-per-agent kernel only (control_batch_impl refuses the workgroup kernel's stamps)
+  return e->f32 ? control_batch_impl<float>(e, B, io, false, static_cast<hipStream_t>(stream), d_stamps)
+                : control_batch_impl<double>(e, B, io, false, static_cast<hipStream_t>(stream), d_stamps);
 }
 #endif
 

@@ -28,15 +28,18 @@ def main():
     lim = np.array([1.0, 0.0, 2.0])
     K = int(os.environ.get("EEA_PHASE_K", "10"))
     horizon = float(os.environ.get("EEA_PHASE_HORIZON", "20.0"))  # dt = 0.1
-    eng = capi.Engine(capi.make_config(model, 0.1, horizon, 0.1, 1.0, K, np.diag([1.0, 0.0, 2.0]), -lim, lim))
+    f32 = os.environ.get("EEA_PHASE_PRECISION", "f64") == "f32"
+    eng = capi.Engine(capi.make_config(model, 0.1, horizon, 0.1, 1.0, K, np.diag([1.0, 0.0, 2.0]), -lim, lim,
+                                       precision=capi.PREC_F32 if f32 else capi.PREC_F64))
     eng.set_target_gaussians([[2.5, 2.5], [8.5, 2.5]], [[1.5, 1.5], [1.5, 1.5]])
     eng.config_domain((-1.0, 11.0, -1.0, 5.0))
     T, K2 = eng.T, eng.K2
     rng = np.random.default_rng(1)
     poses = np.stack([rng.uniform(-0.5, 10.5, B), rng.uniform(-0.5, 4.5, B), rng.uniform(-3, 3, B)], 1)
-    d_pose = torch.as_tensor(poses).cuda()
-    d_ut = torch.zeros((B, T, 3), dtype=torch.float64, device="cuda")
-    d_u0 = torch.empty((B, 3), dtype=torch.float64, device="cuda")
+    tdt = torch.float32 if f32 else torch.float64
+    d_pose = torch.as_tensor(poses).to(tdt).cuda()
+    d_ut = torch.zeros((B, T, 3), dtype=tdt, device="cuda")
+    d_u0 = torch.empty((B, 3), dtype=tdt, device="cuda")
     for _ in range(int(os.environ.get("EEA_PHASE_WARMUP", "5"))):  # a long warm-up = the clock under sustained load
         eng.control_batch(B, d_pose, d_ut, d_u0)
     stamps = torch.zeros((B, 4, 16), dtype=torch.int64, device="cuda")
