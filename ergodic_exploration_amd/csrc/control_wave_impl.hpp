@@ -683,6 +683,52 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
           ta = tb;
           tb = tn;
         }
+        if constexpr (sizeof(R) == 4 && KC == 20) {
+          // fp32, K = 20 (the BASELINE config 3 shape; at K = 10 the packed form spills and is 4 % slower): the two
+          // multiply-adds per element of D as PACKED operations on pairs of x modes
+          // (v_pk_fma_f32) -- (G(k1), G(k1+1)) += (d, d') cos(b_k2 y) and (ha, hb) += (d, d') (cos a_k1 x, cos a_k1+1 x):
+          // the even / odd chains of the scalar form are the two halves of the pair, the pairs of D come out of LDS
+          // as they lie (rows start at even offsets).  k1 = 0 is not special-cased: cos(0 x) = 1 is in the table and
+          // G(0) is never used.
+          typedef float f2 __attribute__((ext_vector_type(2)));
+          constexpr int KP = KB / 2;
+          f2 cx2[KP], G2[KP];
+#pragma unroll
+          for (int q = 0; q < KP; ++q) {
+            cx2[q] = f2{ static_cast<float>(cxa[2 * q]), static_cast<float>(cxa[2 * q + 1]) };
+            G2[q] = *reinterpret_cast<const f2*>(s_D + kb0 + 2 * q);  // row k2 = 0: cos(0 y) = 1
+          }
+          float um = 0.0f, u0 = 1.0f;                          // U_{k2-2}, U_{k2-1} of the y angle
+          // T_{k2-1}, T_{k2} kept as pairs of equal halves: the recurrence is one packed instruction and the G
+          // updates need no broadcast to build
+          const f2 two2 = f2{ static_cast<float>(twoy), static_cast<float>(twoy) };
+          f2 tm2 = f2{ 1.0f, 1.0f }, t02 = f2{ static_cast<float>(c1y[j]), static_cast<float>(c1y[j]) };
+#pragma unroll
+          for (int k2 = 1; k2 < KA; ++k2) {
+            if (!kRowGuard || k2 < K) {  // wavefront-uniform
+              const R* const row = s_D + k2 * K + kb0;
+              f2 h2;
+#pragma unroll
+              for (int q = 0; q < KP; ++q) {
+                const f2 d = *reinterpret_cast<const f2*>(row + 2 * q);
+                G2[q] = __builtin_elementwise_fma(d, t02, G2[q]);
+                h2 = (q == 0) ? d * cx2[q] : __builtin_elementwise_fma(d, cx2[q], h2);
+              }
+              accy = fma_k(static_cast<R>(u0 * (h2.x + h2.y)), k2, accy);
+              const float un = static_cast<float>(twoy) * u0 - um;
+              um = u0;
+              u0 = un;
+              const f2 tn2 = __builtin_elementwise_fma(two2, t02, -tm2);
+              tm2 = t02;
+              t02 = tn2;
+            }
+          }
+#pragma unroll
+          for (int q = 0; q < KP; ++q) {
+            G[2 * q] = static_cast<R>(G2[q].x);
+            G[2 * q + 1] = static_cast<R>(G2[q].y);
+          }
+        } else {
         // row k2 = 0: cos(0 y) = 1 and k2 sin(0) = 0: only G takes part (G(0) is never used: k1 sin(0) = 0)
         {
           const R* const row = s_D + kb0;
@@ -719,6 +765,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
             tm = t0;
             t0 = tn;
           }
+        }
         }
         // edx_x: sum_k1 k1 U_{k1-1}(cos a x) G(k1) over this block
 #pragma unroll
