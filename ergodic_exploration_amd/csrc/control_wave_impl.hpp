@@ -71,16 +71,16 @@ constexpr int kMaxS = 4;        // steps per lane
 constexpr int kStageRows = 32;  // points staged per matrix-core pass (8 MFMAs)
 
 __host__ __device__ constexpr int tab_stride(int K) { return (K + 1) & ~1; }  // even: 16-byte rows
-// LDS carve per wavefront, in elements: heading park [2][kMaxS][64], then the region of the contraction's tiles
-// (x / y, 32 rows each, + the pad the last rows' operand reads run into), which D and the parked barrier
-// gradient take over once the last operand has been read
+// LDS carve per wavefront, in elements: the region of the contraction's tiles (x / y, 32 rows each), which D and the
+// parked barrier gradient take over once the last operand has been read, then the heading park [2][kMaxS][64].  The
+// operand reads of the last rows run past their row (modes beyond K, whose products land in accumulator entries
+// nobody reads): past the x tile into the y tile, past the y tile into the park -- no pad
 __host__ __device__ constexpr int park_elems() { return 2 * kMaxS * kWave; }
 __host__ __device__ constexpr int d_elems(int K) { return (K * K + 3) & ~3; }
 __host__ __device__ constexpr int tile_elems(int K)
 {
-  // the tiles of the contraction (+ the pad the last row's operand reads run into: one or two 16-mode tiles);
-  // afterwards D [K^2] and the parked barrier gradient [2][kMaxS][64]
-  const int t = 2 * kStageRows * tab_stride(K) + (K > 16 ? 32 : 16);
+  // the tiles of the contraction; afterwards D [K^2] and the parked barrier gradient [2][kMaxS][64]
+  const int t = 2 * kStageRows * tab_stride(K);
   const int d = d_elems(K) + 2 * kMaxS * kWave;
   return ((t > d ? t : d) + 3) & ~3;
 }
@@ -197,10 +197,10 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   constexpr int KS = (KC == 16) ? 16 : tab_stride(KC);
 
   R* const sm = reinterpret_cast<R*>(smem_raw) + static_cast<size_t>(wv) * wave_lds_elems(KC == 16 ? 16 : KC);
-  R* const s_cp = sm;                       // cos of the post-step heading, [j][lane]
-  R* const s_sp = sm + kMaxS * kWave;       // sin
-  R* const tabx = sm + park_elems();        // [32 rows][KS]
+  R* const tabx = sm;                       // [32 rows][KS]
   R* const taby = tabx + kStageRows * KS;
+  R* const s_cp = sm + tile_elems(KC == 16 ? 16 : KC);  // cos of the post-step heading, [j][lane]
+  R* const s_sp = s_cp + kMaxS * kWave;                 // sin
   R* const s_D = tabx;                      // D[k2 * K + k1]   (after the contraction)
   R* const s_g = tabx + d_elems(KC == 16 ? 16 : KC);  // barrier gradient parked during the gradient, [2 j + r][lane]
 

@@ -13,9 +13,9 @@ namespace
 template <typename R, int MODEL, int KC, bool STAGES>
 hipError_t launch_wave_one(const ControlParams<R>& p, unsigned B, bool rollout_only, hipStream_t stream)
 {
-  // K = 20 in fp64: 14.6 KB of LDS per agent; workgroups of 4 agents (58 KB) fit twice into the CU's 160 KB (8
-  // wavefronts), workgroups of 2 five times (10 wavefronts; the registers allow 12)
-  constexpr int WPB = (KC == 20 && sizeof(R) == 8) ? 2 : EEA_WAVE_WPB;
+  // K = 20 in fp64: 14.3 KB of LDS per agent; workgroups of 4 agents (57 KB) fit twice into the CU's 160 KB (8
+  // wavefronts), single agents 11 times (the registers allow 12)
+  constexpr int WPB = (KC == 20 && sizeof(R) == 8) ? 1 : EEA_WAVE_WPB;
   const int S = (p.T + kWave - 1) / kWave;
   const size_t lds = static_cast<size_t>(WPB) * wave::wave_lds_elems(KC) * sizeof(R);
   auto kern = wave::control_wave_kernel<R, MODEL, KC, STAGES, WPB>;
