@@ -23,7 +23,7 @@
 //   * the gradient makes ONE pass over D per step (rows from LDS, wavefront-uniform broadcast reads: the LDS
 //     return path, 4 cycles per 16-byte row read and wavefront, is what bounded a two-pass form) with the
 //     cosine array and the G accumulators of ONE step in registers at a time: <= 128 registers, 4 wavefronts
-//     per SIMD, 9.3 KB of LDS per agent -- the 4096-agent batch is resident on the 1024 SIMDs in one round.
+//     per SIMD, 9.2 KB of LDS per agent -- the 4096-agent batch is resident on the 1024 SIMDs in one round.
 //
 // What bounds it (profiles/r02_ubench_coissue.txt): fp64 matrix instructions run on the
 // vector pipe's own multipliers and hold it for their 64 cycles, so the pipe time of an agent is the SUM of its
