@@ -188,6 +188,15 @@ def test_k30_t500_shape():
     run_batch_vs_oracle("omni", 30, 50.0, 0.1, B=1, n_mem=0, calls=1, seed=8)
 
 
+@pytest.mark.parametrize("steps,n_mem", [(2, 0), (7, 3), (64, 0), (70, 61), (129, 100), (300, 37)])
+def test_k30_cooperative_staging(steps, n_mem):
+    """K = 30 stages the contraction tiles with all 64 lanes (point x axis x group of 8 modes, cos / sin of 8, 16, 24 times
+    the angle by doubling): horizons below / at / above one pass of 8 points and one wavefront, one and two chunks,
+    replay memory before the rollout points (ragged last passes), both models, warm-started second call."""
+    run_batch_vs_oracle("omni", 30, steps * 0.125, 0.125, B=3, n_mem=n_mem, calls=2, seed=71)
+    run_batch_vs_oracle("simple_cart", 30, steps * 0.125, 0.125, B=2, n_mem=n_mem, calls=1, seed=72)
+
+
 def test_survey_anchors_through_c_abi(anchors):
     """End-to-end control() outputs of the reference's own sources through
     the single-agent host entry point eea_control, closed loop."""
