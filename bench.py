@@ -44,8 +44,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--passes-per-step", type=int, default=100,
-                    help="consecutive control passes per timed step (receding horizon)")
+    ap.add_argument("--passes-per-step", type=int, default=4000,
+                    help="consecutive control passes per timed step (receding horizon); the default keeps the GPU "
+                         "busy for >= 2 s over the driver's --steps 20")
+    ap.add_argument("--exchange-passes-per-step", type=int, default=400,
+                    help="passes per step of the secondary legs (exchange, grid tile)")
+    ap.add_argument("--control-kernel", default="auto", choices=["auto", "workgroup"],
+                    help="eea_set_option(EEA_OPT_CONTROL_KERNEL): workgroup = the workgroup-per-agent kernel for every call")
+    ap.add_argument("--workgroup-threads", type=int, default=0, choices=[0, 64, 128, 256],
+                    help="eea_set_option(EEA_OPT_WORKGROUP_THREADS)")
+    ap.add_argument("--no-grid-tile", action="store_true", help="skip the grid-tile leg (BASELINE config 5 shard)")
     ap.add_argument("--agents", type=int, default=4096, help="agents per GPU")
     ap.add_argument("--model", default="simple_cart", choices=["simple_cart", "omni"])
     ap.add_argument("--num-basis", type=int, default=10)
@@ -211,11 +219,15 @@ def phik_legs(args, torch, capi, np):
 
 def dry_run(args):
     """EEA_BENCH_DRYRUN=1: the launch plumbing without a GPU (CPU test of `--gpus N`): the ranks rendezvous over
-    gloo, take the max over ranks of a dummy time like the real legs do, and rank 0 prints one JSON line."""
+    gloo, take the max over ranks of a dummy time like the real legs do, run the grid-tile leg's partition + collective
+    on a small grid (numpy in place of the device kernel), and rank 0 prints one JSON line."""
+    import numpy as np
     import torch
     import torch.distributed as dist
+    from ergodic_exploration_amd import agent_batch as ab
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
+    grid_tile = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
@@ -223,11 +235,34 @@ def dry_run(args):
         t = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         assert int(t.item()) == world
+    if not args.no_grid_tile:
+        # the grid-tile leg's structure: rows [row0, row0 + nrows) per rank -> K^2 un-normalised sums -> one all-reduce
+        # -> divide by element 0; checked against the un-tiled sums of the same grid
+        n, K, res = 48, 4, 0.1
+        L = (n - 1) * res
+        rng = np.random.default_rng(2024)
+        cells = rng.choice(np.array([0.001, 0.7, 0.5]), size=(n, n), p=[0.7, 0.2, 0.1])   # entropy-like cell values
+        coord = np.arange(n) * res
+        tab = np.cos(np.outer(np.arange(K) * np.pi / L, coord))                            # [k][i]
+
+        def sums(rows, r0):  # un-normalised [k2][k1] sums of the rows r0 .. r0 + len(rows) - 1
+            return (tab[:, r0:r0 + rows.shape[0]] @ rows @ tab.T).reshape(-1)
+
+        row0, nrows = ab.grid_row_tile(n, rank, world)
+        part = torch.as_tensor(sums(cells[row0:row0 + nrows], row0))
+        if world > 1:
+            phik = ab.reduce_occupancy_sums(part)
+        else:
+            phik = part / part[0]
+        full = sums(cells, 0)
+        err = float(np.abs(phik.numpy() - full / full[0]).max())
+        grid_tile = {"rows_per_rank": int(nrows), "max_abs_err_vs_untiled": err, "ok": bool(err < 1e-12)}
+    if world > 1:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
         os.write(1, (json.dumps({"dryrun": True, "n_gpus": world, "gpus_arg": args.gpus, "steps": args.steps,
-                                 "warmup": args.warmup}) + "\n").encode())
+                                 "warmup": args.warmup, "grid_tile": grid_tile}) + "\n").encode())
 
 
 def main():
@@ -278,10 +313,15 @@ def main():
                                        np.diag(rdiag), -lim, lim,
                                        precision=capi.PREC_F32 if f32 else capi.PREC_F64,
                                        device=device))
+    if args.control_kernel == "workgroup":
+        capi.set_option(capi.OPT_CONTROL_KERNEL, 1)
+    if args.workgroup_threads:
+        capi.set_option(capi.OPT_WORKGROUP_THREADS, args.workgroup_threads)
     eng.set_target_gaussians(MEANS, SIGMAS)
     eng.config_domain(MAP_BOUNDS)
     T, K2, B = eng.T, eng.K2, args.agents
     R = max(1, args.passes_per_step)
+    RX = max(1, args.exchange_passes_per_step)
 
     # synthetic inputs: random poses, zero warm start; resident in HBM before any timing
     rng = np.random.default_rng(12345 + rank)
@@ -345,21 +385,22 @@ def main():
                 d_cbar[xslot].copy_((sums[:-1] / sums[-1]).cuda(), non_blocking=False)
         ev_x[xslot].record(xstream)
 
-    def exchange_allgather(slot):
+    def exchange_allgather(slot, i):
+        dst = d_all[i % 2]  # consecutive gathers alternate between the two receive buffers
         if comm is not None:
-            comm.allgather_ck_async(eng, B, d_ck[slot], d_all[slot % 2], compute.cuda_stream, slot)
+            comm.allgather_ck_async(eng, B, d_ck[slot], dst, compute.cuda_stream, slot)
             return
         xstream.wait_event(ev_ck[slot])
         if backend == "nccl":
             with torch.cuda.stream(xstream):
-                dist.all_gather_into_tensor(d_all[slot % 2], d_ck[slot])
+                dist.all_gather_into_tensor(dst, d_ck[slot])
         else:
             with torch.cuda.stream(xstream):
                 h = d_ck[slot].cpu()
             hall = torch.empty((world * B, K2), dtype=tdt)
             dist.all_gather_into_tensor(hall, h)
             with torch.cuda.stream(xstream):
-                d_all[slot % 2].copy_(hall)
+                dst.copy_(hall)
         ev_x[slot].record(xstream)
 
     def setup_exchange():
@@ -455,23 +496,39 @@ def main():
             if feeds:   # exchange every n-th pass; the passes in between reuse an earlier consensus
                 exchange_consensus(slot, (i // state["every"]) % NB)
         else:
-            exchange_allgather(slot)
+            exchange_allgather(slot, i)
 
     def host_barrier():
         """a barrier every rank leaves together, as a host collective (gloo): independent of the device library"""
         dist.all_reduce(torch.zeros(1, dtype=torch.float64))
 
-    def timed(leg, steps, warmup, every=1):
-        """EXACTLY `steps` steps between barrier + synchronize on both sides; max over ranks"""
+    ev_join = [torch.cuda.Event() for _ in range(G)]
+
+    def fork_groups():
+        """every group stream waits for what the compute stream has enqueued so far"""
+        ev_join[0].record(compute)
+        for g in range(1, G):
+            gstreams[g].wait_event(ev_join[0])
+
+    def join_groups():
+        """the compute stream waits for everything the other group streams have enqueued so far"""
+        for g in range(1, G):
+            ev_join[g].record(gstreams[g])
+            compute.wait_event(ev_join[g])
+
+    def timed(leg, steps, warmup, every=1, passes=None):
+        """EXACTLY `steps` steps (of `passes` passes each) between barrier + synchronize on both sides; max over ranks"""
+        Rl = R if passes is None else passes
         state["i"] = 0
         state["every"] = every
-        d_ut.zero_()
+        d_ut.zero_()      # on the compute stream ...
+        fork_groups()     # ... and ordered before the first pass of every agent group
         # device spin-up, not part of any count: the shader clock needs a few tens of milliseconds of load to reach
         # its sustained state (with 100 passes of warm-up the timed region still starts on the ramp: 27.2 us per
         # pass against 25.8 us after 1000)
         for _ in range(SPINUP_PASSES if leg == "shard" else 0):
             one_pass(leg)
-        for _ in range(warmup * R):
+        for _ in range(warmup * Rl):
             one_pass(leg)
         torch.cuda.synchronize()
         if use_dist:
@@ -479,9 +536,10 @@ def main():
         torch.cuda.synchronize()
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev0.record(compute)
-        for _ in range(steps * R):
+        ev0.record(compute)   # the device is idle here (synchronised above): the start of every group's first pass
+        for _ in range(steps * Rl):
             one_pass(leg)
+        join_groups()         # the end event follows the last pass of EVERY agent group
         ev1.record(compute)
         enqueue_s = time.perf_counter() - t0
         torch.cuda.synchronize()  # all streams of the device
@@ -489,7 +547,7 @@ def main():
             host_barrier()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        pass_ms = ev0.elapsed_time(ev1) / (steps * R)  # HIP events on the kernel's own stream
+        pass_ms = ev0.elapsed_time(ev1) / (steps * Rl)  # HIP events bracketing the launches of all group streams
         if use_dist:
             t = torch.tensor([elapsed, pass_ms], dtype=torch.float64)  # host tensor: gloo
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -548,7 +606,9 @@ def main():
             "spinup_passes": SPINUP_PASSES,
             "host_enqueue_us_per_pass": 1e6 * enqueue_s / (args.steps * R),
             "parity_tol": PARITY_TOL[args.precision],
-            "roofline": {"bound": "valu-%s" % args.precision, "kernel": "control kernel (one launch per pass)",
+            "roofline": {"bound": "valu-%s" % args.precision,
+                         "kernel": "control_wave_kernel (%d concurrent launch%s per pass, one per agent group)"
+                                   % (G, "" if G == 1 else "es"),
                          "achieved": tflops, "peak": vpeak, "unit": "TFLOP/s", "frac": tflops / vpeak,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "flops_per_launch": flops_per_opt * Bl, "launch_ms": pass_ms, "agents_per_launch": Bl,
@@ -582,6 +642,68 @@ def main():
             except Exception as exc:  # the headline line must not die with a secondary leg
                 out["roofline_phik"] = {"error": repr(exc)}
 
+    def grid_tile_leg():
+        """BASELINE configs[4] shard: the 1024 x 1024 occupancy grid row-tiled over the ranks -- every rank streams its
+        rows (int8 cells -> entropy -> K^2 un-normalised sums, eea_spatial_coeff_occupancy_rows), ONE all-reduce of
+        K^2 = 900 reals (7.2 KB) over RCCL, phi_k = sums / sums[0] installed on the device (eea_set_phik_from_sums):
+        three stream-ordered steps, no host round trip.  With one rank it is the single-tile form of the same calls."""
+        from ergodic_exploration_amd import agent_batch as ab
+        n, K5, res = 1024, 30, 0.1
+        lx5 = ly5 = (n - 1) * res
+        rng5 = np.random.default_rng(2024)   # SURVEY.md 8(d) config 5: 70 % free, 10 % occupied, 20 % unknown, 32 x 32 blocks
+        blocks = rng5.choice(np.array([0, 100, -1], dtype=np.int8), size=(n // 32 + 1, n // 32 + 1), p=[0.7, 0.1, 0.2])
+        occ = np.ascontiguousarray(np.kron(blocks, np.ones((32, 32), dtype=np.int8))[:n, :n])
+        row0, nrows = ab.grid_row_tile(n, rank, world)
+        d_rows = torch.as_tensor(occ[row0:row0 + nrows]).cuda()
+        e5 = capi.Engine(capi.make_config(capi.MODEL_OMNI, 0.1, 50.0, res, 1.0, K5, np.diag([1.0, 1.0, 2.0]),
+                                          [-1.0, -1.0, -2.0], [1.0, 1.0, 2.0], device=device))
+        d_sums = torch.empty((K5 * K5,), dtype=torch.float64, device="cuda")
+        st = compute.cuda_stream
+
+        def rebuild():
+            e5.spatial_coeff_occupancy_rows(n, n, row0, nrows, d_rows, lx5, ly5, d_sums, stream=st)
+            if comm is not None:
+                comm.allreduce_sum(e5, d_sums, K5 * K5, stream=st)
+            elif use_dist and backend == "nccl":
+                dist.all_reduce(d_sums)            # torch's current stream is the compute stream
+            elif use_dist:                          # plumbing run (ranks share a GPU): staged through the host
+                h = d_sums.cpu()
+                dist.all_reduce(h)
+                d_sums.copy_(h)
+            e5.set_phik_from_sums(d_sums, lx5, ly5, stream=st)
+
+        for _ in range(5):
+            rebuild()
+        torch.cuda.synchronize()
+        if use_dist:
+            host_barrier()
+        reps = 200
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            rebuild()
+        torch.cuda.synchronize()
+        back_to_back = (time.perf_counter() - t0) / reps
+        lat = []
+        for _ in range(50):
+            t0 = time.perf_counter()
+            rebuild()
+            torch.cuda.synchronize()
+            lat.append(time.perf_counter() - t0)
+        t = torch.tensor([back_to_back, float(np.median(lat))], dtype=torch.float64)
+        if use_dist:
+            host_barrier()
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        phik0 = float(e5.phik()[0])
+        e5.close()
+        return {"workload": "BASELINE configs[4]: %dx%d int8 occupancy grid (entropy target), K=%d, rows tiled over %d rank%s"
+                            % (n, n, K5, world, "" if world == 1 else "s"),
+                "rows_per_rank": nrows, "bytes_streamed_per_rank": int(nrows) * n,
+                "allreduce_bytes": 8 * K5 * K5, "collective": (exchange_backend if world > 1 else "none (1 rank)"),
+                "us_per_rebuild_back_to_back": 1e6 * float(t[0]), "us_per_rebuild_with_host_wait": 1e6 * float(t[1]),
+                "phik_00_check": phik0,
+                "note": "rebuild = eea_spatial_coeff_occupancy_rows + all-reduce(K^2 reals) + eea_set_phik_from_sums, "
+                        "stream-ordered; max over ranks"}
+
     emitted = threading.Lock()
 
     def emit():
@@ -611,40 +733,54 @@ def main():
             if rank == 0:
                 out["exchange"] = {"error": "exchange legs did not finish within %g s; headline leg unaffected" % limit}
             emit()
-            os._exit(0)
+            # a process that has used the GPU and gives up on a hung collective must not look like a clean run: the
+            # headline line is out (rank 0), the exit code tells the launcher / driver that a leg deadlocked
+            os._exit(3)
 
         threading.Thread(target=watchdog, daemon=True).start()
         try:
             setup_exchange()
             exchange = {"backend": exchange_backend, "consumer": "eea_batch_io::d_ck_shared (gradient uses c_bar)"}
-            e_s, p_ms, q_s = timed("consensus", args.steps, args.warmup)
+            e_s, p_ms, q_s = timed("consensus", args.steps, args.warmup, passes=RX)
             exchange["consensus_allreduce"] = {
-                "host_enqueue_us_per_pass": 1e6 * q_s / (args.steps * R),
-                "value": world * B * R * args.steps / e_s, "unit": "optimisations/s", "ms_per_step": 1e3 * e_s / args.steps,
+                "host_enqueue_us_per_pass": 1e6 * q_s / (args.steps * RX),
+                "value": world * B * RX * args.steps / e_s, "unit": "optimisations/s", "ms_per_step": 1e3 * e_s / args.steps,
                 "pass_ms": p_ms, "lag_passes": args.consensus_lag,
                 "bytes_per_rank_per_pass": rs * (K2 + 1),
                 "note": "every pass: eea_ck_sum + ncclAllReduce(K^2+1 reals) + divide on a second stream; pass i uses the "
                         "consensus of pass i - lag"}
-            e_s, p_ms, q_s = timed("consensus", args.steps, args.warmup, every=8)
+            e_s, p_ms, q_s = timed("consensus", args.steps, args.warmup, every=8, passes=RX)
             exchange["consensus_allreduce_every_8_passes"] = {
-                "host_enqueue_us_per_pass": 1e6 * q_s / (args.steps * R),
-                "value": world * B * R * args.steps / e_s, "unit": "optimisations/s", "ms_per_step": 1e3 * e_s / args.steps,
+                "host_enqueue_us_per_pass": 1e6 * q_s / (args.steps * RX),
+                "value": world * B * RX * args.steps / e_s, "unit": "optimisations/s", "ms_per_step": 1e3 * e_s / args.steps,
                 "pass_ms": p_ms, "note": "the same exchange on every 8th pass; the passes in between use the last consensus"}
             if use_dist or args.force_exchange:
                 d_all = [torch.empty((world * B, K2), dtype=tdt, device="cuda") for _ in range(2)]
-                e_s, p_ms, _ = timed("allgather", args.steps, args.warmup)
+                e_s, p_ms, _ = timed("allgather", args.steps, args.warmup, passes=RX)
                 exchange["allgather_ck"] = {
-                    "value": world * B * R * args.steps / e_s, "unit": "optimisations/s",
+                    "value": world * B * RX * args.steps / e_s, "unit": "optimisations/s",
                     "ms_per_step": 1e3 * e_s / args.steps, "pass_ms": p_ms,
                     "bytes_received_per_rank_per_pass": rs * K2 * B * world,
                     "note": "every pass: one ncclAllGather of all agents' c_k (north_star's exchange); nothing on the "
                             "control path consumes the gathered matrix -- the consensus leg is the consuming form"}
 
+            if not args.no_grid_tile and not f32:
+                try:
+                    gt = grid_tile_leg()
+                except Exception as exc:  # noqa: BLE001
+                    gt = {"error": repr(exc)}
+                if rank == 0:
+                    out["grid_tile"] = gt
         except Exception as exc:  # noqa: BLE001 -- the headline line must not die with a secondary leg
             exchange = {"error": repr(exc)}
         finished.set()
         if rank == 0:
             out["exchange"] = exchange
+    elif world == 1 and not args.no_grid_tile and not f32:
+        try:
+            out["grid_tile"] = grid_tile_leg()
+        except Exception as exc:  # noqa: BLE001
+            out["grid_tile"] = {"error": repr(exc)}
     if comm is not None:
         comm.close()
     if comm_local is not None:

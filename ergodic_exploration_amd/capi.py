@@ -18,6 +18,8 @@ HEADER_PATH = os.path.join(ROOT, "include", "ergodic_amd.h")
 MODEL_OMNI, MODEL_SIMPLE_CART = 0, 1
 PREC_F64, PREC_F32 = 0, 1
 OK, ERR_INVALID_ARGUMENT, ERR_INVALID_TWIST, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_TARGET = range(6)
+# eea_set_option (process-wide dispatch options; the library reads no environment variable)
+OPT_CONTROL_KERNEL, OPT_WORKGROUP_THREADS, OPT_COLLISION_IMPL, OPT_MAILBOX_POLL = range(4)
 
 
 class EngineError(RuntimeError):
@@ -111,12 +113,15 @@ def lib():
                                                        C.c_void_p, C.c_double, C.c_double, C.c_void_p,
                                                        C.c_void_p]
         L.eea_set_phik.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double]
+        L.eea_set_phik_from_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
         L.eea_config_domain.argtypes = [C.c_void_p] + [C.c_double] * 4 + [C.POINTER(C.c_int), C.c_void_p]
         L.eea_get_phik.argtypes = [C.c_void_p, C.c_void_p]
         L.eea_get_lamdak.argtypes = [C.c_void_p, C.c_void_p]
         L.eea_target_grid_size.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
         L.eea_get_target_grid.argtypes = [C.c_void_p, C.c_void_p]
         L.eea_control_batch.argtypes = [C.c_void_p, C.c_uint, C.POINTER(BatchIO), C.c_void_p]
+        L.eea_set_option.argtypes = [C.c_int, C.c_int]
+        L.eea_get_option.argtypes = [C.c_int]
         if hasattr(L, "eea_debug_phase_timing"):  # A/B library only (EEA_LIB_VARIANT=_ab, tools/ab/)
             L.eea_debug_phase_timing.argtypes = [C.c_void_p, C.c_uint, C.POINTER(BatchIO), C.c_void_p, C.c_void_p]
         L.eea_comm_get_unique_id.argtypes = [C.c_void_p]
@@ -238,6 +243,10 @@ class Engine:
     def set_phik(self, phik, lx, ly):
         on_device = 1 if (hasattr(phik, "is_cuda") and phik.is_cuda) else 0
         check(lib().eea_set_phik(self.h, _ptr(phik), on_device, lx, ly))
+
+    def set_phik_from_sums(self, sums, lx, ly, stream=None):
+        """phi_k = sums / sums[0] on the device, stream-ordered (grid-tiled occupancy target after the all-reduce)"""
+        check(lib().eea_set_phik_from_sums(self.h, _ptr(sums), lx, ly, C.c_void_p(stream or 0)))
 
     def config_domain(self, bounds, stream=None):
         rebuilt = C.c_int(0)
@@ -412,6 +421,15 @@ def release_collision_caches():
     L = lib()
     L.eea_release_collision_caches.restype = None
     L.eea_release_collision_caches()
+
+
+def set_option(option, value):
+    """eea_set_option: process-wide dispatch option (OPT_*)"""
+    check(lib().eea_set_option(option, value))
+
+
+def get_option(option):
+    return lib().eea_get_option(option)
 
 
 COMM_ID_BYTES = 128

@@ -17,6 +17,7 @@
 #include <utility>
 #include <vector>
 
+#include "../../include/ergodic_amd.h"
 #include "common.hpp"
 
 namespace eea
@@ -511,14 +512,11 @@ void release_hit_map(MapScratch& sc, hipStream_t s)
 // Inflated map or ring search?  A ring search is a chain of ~200 dependent byte loads per pose
 // (~40 us on MI355X, and the steps of one rollout follow each other in one lane), the map costs a
 // fixed ~25 us of stream operations plus a pass over the grid (measured: profiles/r01_tick_kernels.txt).
-// EEA_COLLISION_MAP=0/1 forces one of them.
+// EEA_OPT_COLLISION_IMPL = 1 / 2 forces one of them.
 bool use_hit_map(size_t poses, unsigned sequential_steps, const CollisionParams& c)
 {
-  static const int forced = [] {
-    const char* v = std::getenv("EEA_COLLISION_MAP");
-    return v ? (std::atoi(v) != 0 ? 1 : 0) : -1;
-  }();
-  if (forced >= 0) return forced == 1;
+  const int forced = option(EEA_OPT_COLLISION_IMPL);
+  if (forced != 0) return forced == 2;
   if (poses >= 4096) return true;
   const double cells = static_cast<double>(c.xsize) * c.ysize;
   const double t_map_us = 25.0 + 2.0e-6 * cells, t_ring_us = 40.0 * (sequential_steps ? sequential_steps : 1u);

@@ -18,6 +18,9 @@ constexpr double kPi = 3.14159265358979323846;
 
 enum : int { kModelOmni = 0, kModelSimpleCart = 1 };
 
+// process-wide dispatch option (eea_set_option, EEA_OPT_* of include/ergodic_amd.h); defined in engine.cpp
+int option(int id);
+
 // Everything one control launch needs; passed by value (kernarg).
 template <typename R>
 struct ControlParams
@@ -47,7 +50,7 @@ struct ControlParams
   R* bdx;
   R* rhot;
   int* status;
-  long long* dbg;     // phase-timing stamps [B][4 waves][16] (diagnostic build only), else null
+  long long* dbg;     // phase stamps of the A/B library's kernels (tools/ab/); null in the product
   // single-agent path: host-visible completion word, set to done_seq (system-scope release) after
   // u0 / status of agent 0 are written; null for batches
   int* done;
@@ -71,21 +74,6 @@ template <typename R>
 hipError_t launch_control_wave(const ControlParams<R>& p, unsigned B, int model, bool rollout_only,
                                hipStream_t stream);
 
-#ifdef EEA_AB_BUILD
-// A/B library only (tools/ab/): diagnostic instantiation (K = 10, fp64) that records per-phase shader-clock
-// stamps into p.dbg, and the first version of the control kernel
-hipError_t launch_control_timing(const ControlParams<double>& p, unsigned B, int model, int n_mem_max,
-                                 hipStream_t stream);
-
-namespace v1
-{
-template <typename R>
-size_t control_lds_bytes(int T, int K, int n_mem_max, int chunk);
-template <typename R>
-hipError_t launch_control(const ControlParams<R>& p, unsigned B, int model, int n_mem_max,
-                          bool rollout_only, hipStream_t stream);
-}  // namespace v1
-#endif  // EEA_AB_BUILD
 
 // ---- phi_k path ----------------------------------------------------------------------
 // Gaussians of a target passed to the fill kernel by value: [mean x, mean y (Fourier frame), cov_inv xx, yy]

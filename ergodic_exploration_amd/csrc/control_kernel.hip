@@ -1,6 +1,5 @@
 // Instantiations and dispatch of the fused control kernel (control_kernel_impl.hpp).
-#include <cstdlib>
-
+#include "../../include/ergodic_amd.h"
 #include "control_kernel_impl.hpp"
 
 namespace eea
@@ -8,15 +7,11 @@ namespace eea
 namespace
 {
 // Threads per agent: one lane per horizon step up to 256; horizons of at most 64 / 128 steps take one /
-// two wavefronts per agent (no cross-wavefront exchange at all for one).  EEA_BLOCK overrides
-// (A/B experiments: longer horizons then run several steps per lane through the chunk loop).
+// two wavefronts per agent (no cross-wavefront exchange at all for one).  EEA_OPT_WORKGROUP_THREADS overrides
+// (longer horizons then run several steps per lane through the chunk loop).
 int control_threads(int T)
 {
-  static const int forced = [] {
-    const char* v = std::getenv("EEA_BLOCK");
-    const int b = v ? std::atoi(v) : 0;
-    return (b == 64 || b == 128 || b == 256) ? b : 0;
-  }();
+  const int forced = option(EEA_OPT_WORKGROUP_THREADS);
   if (forced) return forced;
   return T <= 64 ? 64 : (T <= 128 ? 128 : 256);
 }
@@ -66,13 +61,7 @@ hipError_t launch_control(const ControlParams<R>& p, unsigned B, int model, int 
 {
   if (B == 0) return hipSuccess;
   const int Nmax = p.T + n_mem_max;
-  size_t lds = control_lds_bytes<R>(p.T, p.K, n_mem_max, p.chunk);
-  // occupancy experiment knob (tools/ab_bench.sh): extra dynamic LDS per workgroup in KiB
-  static const int pad_kib = [] {
-    const char* v = std::getenv("EEA_LDS_PAD_KIB");
-    return v ? std::atoi(v) : 0;
-  }();
-  if (pad_kib > 0 && lds + static_cast<size_t>(pad_kib) * 1024 <= 160 * 1024) lds += static_cast<size_t>(pad_kib) * 1024;
+  const size_t lds = control_lds_bytes<R>(p.T, p.K, n_mem_max, p.chunk);
   if (model == kModelOmni) return launch_block<R, kModelOmni>(p, B, Nmax, rollout_only, lds, stream);
   return launch_block<R, kModelSimpleCart>(p, B, Nmax, rollout_only, lds, stream);
 }

@@ -30,23 +30,16 @@
 //     4 workgroups per CU.
 #include "common.hpp"
 
-// Phase stamps: compiled in only by tools/ab/control_kernel_timing.hip (EEA_TIMING, A/B library);
-// each wavefront's lane 0 records the shader clock at the phase boundaries into p.dbg.
+// Phase markers EEA_STAMP(n): nothing in the product; tools/ab/control_kernel_timing.hip (A/B library) defines them
+// as shader-clock stamps into p.dbg before including this file.
 
 // waves per SIMD the K <= 12 instances are compiled for (register budget 512 / waves)
 #ifndef EEA_WAVES_SMALL_K
 #define EEA_WAVES_SMALL_K 5
 #endif
 
-#ifdef EEA_TIMING
-#define EEA_STAMP(n)                                                                            \
-  do {                                                                                          \
-    if (p.dbg != nullptr && (threadIdx.x & 63) == 0)                                            \
-      p.dbg[(static_cast<size_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16 + (n)] =            \
-          static_cast<long long>(__builtin_readcyclecounter());                                 \
-  } while (0)
-#else
-#define EEA_STAMP(n) do { } while (0)
+#ifndef EEA_STAMP
+#define EEA_STAMP(n) ((void)0)
 #endif
 
 namespace eea

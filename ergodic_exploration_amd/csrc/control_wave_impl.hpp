@@ -36,31 +36,12 @@
 
 #include "common.hpp"
 
-// phase stamps: A/B library only (tools/phase_timing.py through eea_debug_phase_timing); lane 0 of every
-// wavefront records the shader clock at the phase boundaries into p.dbg [agent][16]
-#ifdef EEA_AB_BUILD
-#define EEA_WSTAMP(n)                                                                                   \
-  do {                                                                                                  \
-    if (p.dbg != nullptr && lane == 0) p.dbg[static_cast<size_t>(b) * 16 + (n)] = static_cast<long long>(__builtin_readcyclecounter()); \
-  } while (0)
-// slots 10 / 11: the constant 100 MHz counter at the wavefront's start / end; 12: HW_ID (which SIMD it ran on)
-#define EEA_WSTAMP_RT(n)                                                                                \
-  do {                                                                                                  \
-    if (p.dbg != nullptr && lane == 0) p.dbg[static_cast<size_t>(b) * 16 + (n)] = static_cast<long long>(__builtin_amdgcn_s_memrealtime()); \
-  } while (0)
-#define EEA_WSTAMP_HWID(n)                                                                              \
-  do {                                                                                                  \
-    if (p.dbg != nullptr && lane == 0) {                                                                \
-      unsigned hw_, xcc_;                                                                               \
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw_));                                 \
-      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                               \
-      p.dbg[static_cast<size_t>(b) * 16 + (n)] = static_cast<long long>(hw_) | (static_cast<long long>(xcc_) << 32); \
-    }                                                                                                   \
-  } while (0)
-#else
-#define EEA_WSTAMP(n) do { } while (0)
-#define EEA_WSTAMP_RT(n) do { } while (0)
-#define EEA_WSTAMP_HWID(n) do { } while (0)
+// phase markers: nothing in the product; the A/B library (make AB=1) pre-includes tools/ab/wave_stamps.hpp, which
+// makes them shader-clock stamps into p.dbg (tools/phase_timing.py)
+#ifndef EEA_WSTAMP
+#define EEA_WSTAMP(n) ((void)0)
+#define EEA_WSTAMP_RT(n) ((void)0)
+#define EEA_WSTAMP_HWID(n) ((void)0)
 #endif
 
 namespace eea

@@ -4,10 +4,8 @@
 // host code here only prepares their inputs the way the reference's host code does
 // (steps_ truncation, grid coordinates by accumulation, covariance inverse).
 #include "../../include/ergodic_amd.h"
-#ifdef EEA_AB_BUILD
-#include "../../tools/ab/ergodic_amd_ab.h"
-#endif
 
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -17,6 +15,19 @@
 
 #include "abi_util.hpp"
 #include "common.hpp"
+
+namespace
+{
+using eea::fail;
+
+// process-wide dispatch options (eea_set_option); index = EEA_OPT_*
+std::atomic<int> g_options[EEA_OPT_COUNT] = { { 0 }, { 0 }, { 0 }, { 1 } };
+}  // namespace
+
+namespace eea
+{
+int option(int id) { return (id >= 0 && id < EEA_OPT_COUNT) ? g_options[id].load(std::memory_order_relaxed) : 0; }
+}  // namespace eea
 
 namespace
 {
@@ -67,9 +78,6 @@ struct eea_engine
   bool f32 = false;
   size_t rs = 8;  // sizeof(real)
   int chunk = 128;
-#ifdef EEA_AB_BUILD
-  bool impl_v1 = false;  // A/B library: EEA_CONTROL_IMPL=v1 selects the first kernel version
-#endif
 
   // Basis state (basis_.lx_, ly_ start at 0: ergodic_control.hpp:208)
   double lx = 0.0, ly = 0.0, map_x = 0.0, map_y = 0.0;
@@ -208,8 +216,13 @@ eea_status upload_axes_and_tables(eea_engine* e, unsigned nx, unsigned ny, hipSt
   }
   if (e->tab_nx == nx && e->tab_ny == ny && e->tab_lx == e->lx && e->tab_ly == e->ly) return EEA_OK;
   const R pi_lx = static_cast<R>(eea::kPi / e->lx), pi_ly = static_cast<R>(eea::kPi / e->ly);
-  if (stale) *stale = true;
-  else EEA_HIP(eea::launch_axis_tables<R>(static_cast<const R*>(e->d_axis.p), nx, ny, e->K, pi_lx, pi_ly,
+  if (stale) {
+    // the caller computes the tables inside its own launch and records the key once that launch is enqueued: a
+    // failure in between must not leave the key on tables that were never written
+    *stale = true;
+    return EEA_OK;
+  }
+  EEA_HIP(eea::launch_axis_tables<R>(static_cast<const R*>(e->d_axis.p), nx, ny, e->K, pi_lx, pi_ly,
                                      static_cast<R*>(e->d_cx.p), static_cast<R*>(e->d_cy.p), s));
   e->tab_nx = nx;
   e->tab_ny = ny;
@@ -389,48 +402,20 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
   p.done = e->mail_done;
   p.done_seq = e->mail_seq;
   const int n_mem_max = rollout_only ? 0 : static_cast<int>(p.mem_stride);
+  p.dbg = d_stamps;  // phase stamps: null in the product (only the A/B library's kernels read it, tools/ab/)
   // two kernels ship: one wavefront per agent (horizons <= 256 steps, K <= 16 or K = 20) and one workgroup per agent
-  // (everything else, and the rollout-only entry).  EEA_CONTROL_PATH=workgroup forces the second.
-  static const bool force_workgroup = [] {
-    const char* v = std::getenv("EEA_CONTROL_PATH");
-    return v != nullptr && std::strcmp(v, "workgroup") == 0;
-  }();
-  // the single-agent entry (eea_control / eea_opt_traj: one agent, latency) keeps four wavefronts per agent;
-  // batches take the throughput kernel
-  bool use_wave = !force_workgroup && e->mail_done == nullptr && eea::control_wave_eligible<R>(p, rollout_only);
-#ifdef EEA_AB_BUILD
-  if (e->impl_v1) use_wave = false;
-  if (d_stamps != nullptr && !use_wave && sizeof(R) != 8) return fail(EEA_ERR_UNSUPPORTED, "phase timing is built for fp64 only");
-  if (d_stamps != nullptr && use_wave) p.dbg = d_stamps;  // [agent][16] stamps of the wavefront-per-agent kernel
-#endif
+  // (everything else).  The single-agent entry (eea_control / eea_opt_traj: one agent, latency) keeps four
+  // wavefronts per agent; batches take the throughput kernel unless EEA_OPT_CONTROL_KERNEL says otherwise
+  const bool use_wave = eea::option(EEA_OPT_CONTROL_KERNEL) == 0 && e->mail_done == nullptr &&
+                        eea::control_wave_eligible<R>(p, rollout_only);
   if (use_wave) {
     EEA_HIP(eea::launch_control_wave<R>(p, B, e->cfg.model, rollout_only, s));
     return EEA_OK;
   }
-  size_t lds = eea::control_lds_bytes<R>(p.T, p.K, n_mem_max, p.chunk);
-#ifdef EEA_AB_BUILD
-  if (e->impl_v1) lds = eea::v1::control_lds_bytes<R>(p.T, p.K, n_mem_max, p.chunk);
-#endif
+  const size_t lds = eea::control_lds_bytes<R>(p.T, p.K, n_mem_max, p.chunk);
   if (lds > 160 * 1024) {
     return fail(EEA_ERR_UNSUPPORTED, "horizon/memory/basis too large for one workgroup's 160 KiB LDS");
   }
-#ifdef EEA_AB_BUILD
-  if (d_stamps != nullptr) {
-    if constexpr (sizeof(R) == 8) {
-      p.dbg = d_stamps;
-      EEA_HIP(eea::launch_control_timing(p, B, e->cfg.model, n_mem_max, s));
-      return EEA_OK;
-    } else {
-      return fail(EEA_ERR_UNSUPPORTED, "phase timing is built for fp64 only");
-    }
-  }
-  if (e->impl_v1) {
-    EEA_HIP(eea::v1::launch_control<R>(p, B, e->cfg.model, n_mem_max, rollout_only, s));
-    return EEA_OK;
-  }
-#else
-  (void)d_stamps;
-#endif
   EEA_HIP(eea::launch_control<R>(p, B, e->cfg.model, n_mem_max, rollout_only, s));
   return EEA_OK;
 }
@@ -490,6 +475,22 @@ eea_status check_engine(const eea_engine* e)
 extern "C" {
 
 const char* eea_last_error(void) { return eea::g_last_error.c_str(); }
+
+eea_status eea_set_option(int option, int value)
+{
+  bool ok = false;
+  switch (option) {
+    case EEA_OPT_CONTROL_KERNEL: ok = value == 0 || value == 1; break;
+    case EEA_OPT_WORKGROUP_THREADS: ok = value == 0 || value == 64 || value == 128 || value == 256; break;
+    case EEA_OPT_COLLISION_IMPL: ok = value >= 0 && value <= 2; break;
+    case EEA_OPT_MAILBOX_POLL: ok = value == 0 || value == 1; break;
+    default: return fail(EEA_ERR_INVALID_ARGUMENT, "unknown option");
+  }
+  if (!ok) return fail(EEA_ERR_INVALID_ARGUMENT, "option value out of range");
+  g_options[option].store(value, std::memory_order_relaxed);
+  return EEA_OK;
+}
+int eea_get_option(int option) { return eea::option(option); }
 unsigned eea_abi_version(void) { return EEA_ABI_VERSION; }
 
 eea_status eea_create(const eea_config* cfg, eea_engine** out)
@@ -528,13 +529,6 @@ eea_status eea_create(const eea_config* cfg, eea_engine** out)
   e->K2 = e->K * e->K;
   e->f32 = cfg->precision == EEA_PREC_F32;
   e->rs = e->f32 ? 4 : 8;
-  if (const char* c = std::getenv("EEA_CHUNK")) {
-    const int v = std::atoi(c);
-    if (v >= 64 && v <= 1024 && (v % 64) == 0) e->chunk = v;
-  }
-#ifdef EEA_AB_BUILD
-  if (const char* c = std::getenv("EEA_CONTROL_IMPL")) e->impl_v1 = std::strcmp(c, "v1") == 0;
-#endif
   eea_status st = e->f32 ? upload_lamdak<float>(e) : upload_lamdak<double>(e);
   if (st != EEA_OK) {
     eea_destroy(e);
@@ -719,6 +713,26 @@ eea_status eea_set_phik(eea_engine* e, const void* phik, int on_device, double l
   return EEA_OK;
 }
 
+eea_status eea_set_phik_from_sums(eea_engine* e, const void* d_sums, double lx, double ly, void* stream)
+{
+  if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (d_sums == nullptr || !(lx > 0.0) || !(ly > 0.0)) return fail(EEA_ERR_INVALID_ARGUMENT, "bad sums");
+  eea_status st = use_device(e);
+  if (st != EEA_OK) return st;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (e->f32) {
+    EEA_HIP(eea::launch_normalise_by_first<float>(static_cast<const float*>(d_sums), e->K2,
+                                                  static_cast<float*>(e->d_phik.p), s));
+  } else {
+    EEA_HIP(eea::launch_normalise_by_first<double>(static_cast<const double*>(d_sums), e->K2,
+                                                   static_cast<double*>(e->d_phik.p), s));
+  }
+  e->lx = lx;
+  e->ly = ly;
+  e->have_phik = true;
+  return EEA_OK;
+}
+
 eea_status eea_config_domain(eea_engine* e, double xmin, double xmax, double ymin, double ymax,
                              int* rebuilt, void* stream)
 {
@@ -819,23 +833,6 @@ eea_status eea_control_batch(eea_engine* e, unsigned B, const eea_batch_io* io, 
                 : control_batch_impl<double>(e, B, io, false, s);
 }
 
-#ifdef EEA_AB_BUILD
-eea_status eea_debug_phase_timing(eea_engine* e, unsigned B, const eea_batch_io* io, void* stream,
-                                  long long* d_stamps)
-{
-  if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
-  if (io == nullptr || io->d_pose == nullptr || io->d_ut == nullptr || io->d_u0 == nullptr || d_stamps == nullptr) {
-    return fail(EEA_ERR_INVALID_ARGUMENT, "d_pose, d_ut, d_u0 and d_stamps are required");
-  }
-  if (!e->have_phik) return fail(EEA_ERR_NO_TARGET, "no phi_k");
-  eea_status st = use_device(e);
-  if (st != EEA_OK) return st;
-  // fp32: the wavefront-per-agent kernel only (control_batch_impl refuses the workgroup kernel's stamps)
-  return e->f32 ? control_batch_impl<float>(e, B, io, false, static_cast<hipStream_t>(stream), d_stamps)
-                : control_batch_impl<double>(e, B, io, false, static_cast<hipStream_t>(stream), d_stamps);
-}
-#endif
-
 eea_status eea_rollout_batch(eea_engine* e, unsigned B, const void* d_pose, const void* d_ut,
                              void* d_traj, int* d_status, void* stream)
 {
@@ -903,10 +900,7 @@ eea_status eea_control(eea_engine* e, double xmin, double xmax, double ymin, dou
   if (st != EEA_OK) return st;
   // the kernel publishes u0 / status and then the sequence number with a system-scope release: poll it
   // (a few microseconds earlier than the stream's completion signal); bounded, then the ordinary wait
-  static const bool poll = [] {
-    const char* v = std::getenv("EEA_MAILBOX_POLL");
-    return v == nullptr || std::atoi(v) != 0;
-  }();
+  const bool poll = eea::option(EEA_OPT_MAILBOX_POLL) != 0;
   bool seen = false;
   if (poll) {
     const volatile int* const flag = &e->h_mail->done;
@@ -1232,3 +1226,8 @@ eea_status eea_dwa_control_batch(int device, const eea_collision_cfg* ccfg, cons
 }
 
 }  // extern "C"
+
+// the A/B library (make AB=1; tools/ab/) adds its diagnostic entry point here; the product does not
+#ifdef EEA_AB_BUILD
+#include "../../tools/ab/engine_ab.inc"
+#endif

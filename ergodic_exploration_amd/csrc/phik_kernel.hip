@@ -224,10 +224,6 @@ __global__ __launch_bounds__(kBlock) void scale_by_inv_kernel(R* __restrict__ ph
 // input kinds of the phi_k pass: fp64 values, fp32 values, occupancy cells (bytes)
 constexpr int kKindF64 = 0, kKindF32 = 1, kKindCells = 2;
 
-#ifdef EEA_AB_BUILD
-#include "../../tools/ab/phik_pass1_kernel.inc"
-#endif
-
 // pass 1 on the matrix cores: S[k2][col] = sum_rows cy[row][k2] * phi[row][col] is a GEMM whose
 // B operand (4 rows x 16 columns per v_mfma_*_16x16x4) is exactly what a wavefront loads from the
 // row-major grid: lane (k, j) = 16 k + j holds phi[row + k][col + j].  The grid therefore goes from
@@ -700,16 +696,6 @@ hipError_t launch_scale_by_inv(R* d_phi, size_t n, const R* d_sum, hipStream_t s
 }
 
 // ---- geometry of the matrix-core streaming kernel -------------------------------------------
-#ifdef EEA_AB_BUILD
-inline bool spatial_use_mfma()
-{
-  static const bool valu = [] {
-    const char* v = std::getenv("EEA_PHIK_IMPL");
-    return v != nullptr && std::string(v) == "valu";
-  }();
-  return !valu;  // EEA_PHIK_IMPL=valu selects the per-column accumulator kernel (A/B baseline)
-}
-#endif
 // columns per workgroup: 4 wavefronts x 16 x (columns per lane)
 inline int stream_cols(int kind, int NT)
 {
@@ -719,23 +705,14 @@ inline int stream_cols(int kind, int NT)
 }
 inline int stream_rows_per_tile(int nx, int ny, int kind, int NT)
 {
-  static const int forced = [] {
-    const char* v = std::getenv("EEA_PHIK_ROWS");
-    return v ? std::atoi(v) : 0;
-  }();
   const int cols = stream_cols(kind, NT);
   const int col_tiles = (nx + cols - 1) / cols;
-  int rpt;
-  if (forced > 0) {
-    rpt = forced;
-  } else {
-    // ~6 workgroups per CU in total; at least 64 rows so that the epilogue (16 NT^2 matrix
-    // instructions per accumulator set) stays a small part of the tile
-    int row_tiles = 1536 / col_tiles;
-    if (row_tiles < 1) row_tiles = 1;
-    rpt = (ny + row_tiles - 1) / row_tiles;
-    if (rpt < 64) rpt = 64;
-  }
+  // ~6 workgroups per CU in total; at least 64 rows so that the epilogue (16 NT^2 matrix
+  // instructions per accumulator set) stays a small part of the tile
+  int row_tiles = 1536 / col_tiles;
+  if (row_tiles < 1) row_tiles = 1;
+  int rpt = (ny + row_tiles - 1) / row_tiles;
+  if (rpt < 64) rpt = 64;
   rpt = (rpt + 31) & ~31;  // whole pipeline stages (4 G rows, G <= 8)
   if (rpt > ny) rpt = ny;
   return rpt;
@@ -745,16 +722,6 @@ size_t spatial_work_elems(int nx, int ny, int K)
 {
   // the largest tile count over the input kinds
   size_t tiles = 0;
-#ifdef EEA_AB_BUILD
-  for (int cpt = 1; cpt <= 4; cpt *= 2) {
-    const int cols = kBlock * cpt;
-    const int col_tiles = (nx + cols - 1) / cols;
-    const int rpt = spatial_rows_per_tile(nx, ny, K, cpt);
-    const int row_tiles = (ny + rpt - 1) / rpt;
-    const size_t t = static_cast<size_t>(col_tiles) * row_tiles;
-    tiles = t > tiles ? t : tiles;
-  }
-#endif
   const int NT = K <= 16 ? 1 : 2;
   for (int kind = 0; kind < 3; ++kind) {
     const int cols = stream_cols(kind, NT);
@@ -775,11 +742,6 @@ hipError_t launch_spatial_generic(const IN* d_in, int nx, int ny, int K, const R
   constexpr bool kCells = !std::is_same<IN, R>::value;
   constexpr int kind = kCells ? kKindCells : (sizeof(R) == 8 ? kKindF64 : kKindF32);
   const int K2 = K * K;
-#ifdef EEA_AB_BUILD
-  if (!spatial_use_mfma()) {
-#include "../../tools/ab/phik_pass1_dispatch.inc"
-  }
-#endif
   {
     const int NT = K <= 16 ? 1 : 2;
     const int cols = stream_cols(kind, NT);

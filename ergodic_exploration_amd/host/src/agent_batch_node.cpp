@@ -5,7 +5,7 @@
 //   agent_batch --ranks N [--agents B] [--steps S] [--model omni|cart] [--consensus] [--horizon H] [--basis K]
 //
 // The parent makes NO GPU call: it forks the N ranks first (rank r takes HIP device r), rank 0 creates the RCCL id
-// and hands it to the others through a file in $TMPDIR, every rank creates its communicator.  No counterpart in
+// and hands it to the others through pipes the parent opened before forking, every rank creates its communicator.  No counterpart in
 // the single-agent reference; the per-agent computation is its ErgodicControl::control
 // (include/ergodic_exploration/ergodic_control.hpp:224-311), the exchange follows README.md:225-227 (ref. [2]).
 #include <sys/wait.h>
@@ -15,9 +15,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <fstream>
 #include <string>
-#include <thread>
+#include <vector>
 
 #include <ergodic_exploration/agent_batch.hpp>
 
@@ -33,26 +32,55 @@ struct Options
   bool cart = true, consensus = false;
 };
 
+// RCCL id hand-off: one pipe per rank > 0, created by the parent before fork(); rank 0 writes, rank r reads.  (A file
+// named after the parent's pid could be stale, pre-created or left behind by a crashed run.)
+struct IdPipes
+{
+  std::vector<int> rd, wr;  // index = rank (entry 0 unused)
+};
+
+bool write_all(int fd, const char* p, size_t n)
+{
+  while (n > 0) {
+    const ssize_t k = write(fd, p, n);
+    if (k <= 0) return false;
+    p += k;
+    n -= static_cast<size_t>(k);
+  }
+  return true;
+}
+bool read_all(int fd, char* p, size_t n)
+{
+  while (n > 0) {
+    const ssize_t k = read(fd, p, n);
+    if (k <= 0) return false;  // 0 = rank 0 died before writing: every write end is closed
+    p += k;
+    n -= static_cast<size_t>(k);
+  }
+  return true;
+}
+
 template <class ModelT>
-int run_rank(const Options& o, int rank, const std::string& id_path)
+int run_rank(const Options& o, int rank, const IdPipes& pipes)
 {
   ee::device_ordinal() = rank;
   eea_comm* comm = nullptr;
   if (o.ranks > 1) {
     char id[EEA_COMM_ID_BYTES];
+    // every rank keeps only its own end: a reader then sees end-of-file if rank 0 dies before writing
+    for (int r = 1; r < o.ranks; ++r) {
+      if (rank != 0) close(pipes.wr[r]);
+      if (rank != r) close(pipes.rd[r]);
+    }
     if (rank == 0) {
       ee::throw_on_error(eea_comm_get_unique_id(id));
-      std::ofstream f(id_path + ".tmp", std::ios::binary);
-      f.write(id, sizeof(id));
-      f.close();
-      std::rename((id_path + ".tmp").c_str(), id_path.c_str());
-    } else {
-      for (int tries = 0;; ++tries) {
-        std::ifstream f(id_path, std::ios::binary);
-        if (f && f.read(id, sizeof(id))) break;
-        if (tries > 3000) throw std::runtime_error("no RCCL id from rank 0");
-        std::this_thread::sleep_for(std::chrono::milliseconds(10));
+      for (int r = 1; r < o.ranks; ++r) {
+        if (!write_all(pipes.wr[r], id, sizeof(id))) throw std::runtime_error("cannot hand the RCCL id to a rank");
+        close(pipes.wr[r]);
       }
+    } else {
+      if (!read_all(pipes.rd[rank], id, sizeof(id))) throw std::runtime_error("no RCCL id from rank 0");
+      close(pipes.rd[rank]);
     }
     ee::throw_on_error(eea_comm_create(rank, o.ranks, rank, id, &comm));
   }
@@ -120,11 +148,18 @@ int main(int argc, char** argv)
     }
   }
   if (o.ranks < 1 || o.agents == 0) return 2;
-  const char* tmp = std::getenv("TMPDIR");
-  const std::string id_path = std::string(tmp ? tmp : "/tmp") + "/eea_rccl_id_" + std::to_string(getpid());
+  IdPipes pipes;
+  pipes.rd.assign(static_cast<size_t>(o.ranks), -1);
+  pipes.wr.assign(static_cast<size_t>(o.ranks), -1);
+  for (int r = 1; r < o.ranks; ++r) {
+    int fd[2];
+    if (pipe(fd) != 0) return 1;
+    pipes.rd[r] = fd[0];
+    pipes.wr[r] = fd[1];
+  }
   auto rank_main = [&](int rank) -> int {
     try {
-      return o.cart ? run_rank<ee::models::SimpleCart>(o, rank, id_path) : run_rank<ee::models::Omni>(o, rank, id_path);
+      return o.cart ? run_rank<ee::models::SimpleCart>(o, rank, pipes) : run_rank<ee::models::Omni>(o, rank, pipes);
     } catch (const std::exception& e) {
       std::fprintf(stderr, "rank %d: %s\n", rank, e.what());
       return 1;
@@ -138,10 +173,13 @@ int main(int argc, char** argv)
     if (pid == 0) _exit(rank_main(r));
     if (pid < 0) return 1;
   }
+  for (int r = 1; r < o.ranks; ++r) {  // the parent holds no end of the pipes
+    close(pipes.rd[r]);
+    close(pipes.wr[r]);
+  }
   for (int r = 0; r < o.ranks; ++r) {
     int status = 0;
     if (wait(&status) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) failed = 1;
   }
-  std::remove(id_path.c_str());
   return failed;
 }

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EEA_ABI_VERSION 2
+#define EEA_ABI_VERSION 3
 
 /* models usable with ErgodicControl (Cart/Mecanum cannot run under it) */
 enum { EEA_MODEL_OMNI = 0,        /* models::Omni        models/omni.hpp:164-215 */
@@ -74,6 +74,19 @@ eea_status eea_create(const eea_config* cfg, eea_engine** out);
 void eea_destroy(eea_engine* e);
 const char* eea_last_error(void);
 unsigned eea_abi_version(void);
+
+/* Process-wide dispatch options (no reference counterpart; every default reproduces the engine's own choice).
+ * They replace the environment knobs of ABI 2: the library reads no environment variable. */
+enum { EEA_OPT_CONTROL_KERNEL = 0,    /* 0 = automatic (wavefront-per-agent kernel where eligible), 1 = the
+                                         workgroup-per-agent kernel for every control call */
+       EEA_OPT_WORKGROUP_THREADS = 1, /* threads per agent of the workgroup-per-agent kernel: 0 = by horizon,
+                                         or 64 / 128 / 256 */
+       EEA_OPT_COLLISION_IMPL = 2,    /* Collision::collisionCheck implementation: 0 = cost model, 1 = ring
+                                         search, 2 = inflated map (both bit-exact) */
+       EEA_OPT_MAILBOX_POLL = 3,      /* eea_control: 1 = poll the completion word (default), 0 = wait for the stream */
+       EEA_OPT_COUNT = 4 };
+eea_status eea_set_option(int option, int value);
+int eea_get_option(int option);
 
 unsigned eea_steps(const eea_engine* e);      /* T = steps_ (ergodic_control.hpp:199) */
 unsigned eea_num_modes(const eea_engine* e);  /* K^2 */
@@ -119,6 +132,11 @@ eea_status eea_spatial_coeff_occupancy_rows(eea_engine* e, unsigned nx, unsigned
                                             void* d_sums_partial, void* stream);
 /* installs phi_k (K^2 reals, device pointer if on_device != 0) for a domain lx x ly */
 eea_status eea_set_phik(eea_engine* e, const void* phik, int on_device, double lx, double ly);
+/* the last step of a grid-tiled occupancy target without a host round trip: phi_k = d_sums / d_sums[0], where d_sums
+ * (device, K^2 reals) holds the un-normalised sums of eea_spatial_coeff_occupancy_rows after the all-reduce over the
+ * ranks (element 0, mode (0,0), is the sum of the cell entropies: the normaliser of target.cpp:87).  Asynchronous
+ * on `stream`; control calls enqueued on the same stream afterwards use the new phi_k. */
+eea_status eea_set_phik_from_sums(eea_engine* e, const void* d_sums, double lx, double ly, void* stream);
 
 /* ErgodicControl::configTarget (ergodic_control.hpp:362-416): refreshes map_pos; rebuilds
  * phi_k (Target::fill target.cpp:78-89 + Basis::spatialCoeff) only when the extent changed

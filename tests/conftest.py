@@ -28,3 +28,17 @@ def kats():
 @pytest.fixture(scope="session")
 def anchors():
     return load_golden("survey_anchors.json")
+
+
+@pytest.fixture(autouse=True, scope="session")
+def _forced_dispatch_options():
+    """EEA_TEST_OPTIONS="<option>=<value>,..." (test plumbing, read HERE and not by the library): applied through
+    eea_set_option before the first test, so that a whole test file can be re-run with one implementation pinned
+    (tests/test_gpu_collision_parity.py::test_both_implementations_forced)."""
+    spec = os.environ.get("EEA_TEST_OPTIONS", "")
+    if spec:
+        from ergodic_exploration_amd import capi
+        for item in spec.split(","):
+            opt, val = item.split("=")
+            capi.set_option(int(opt), int(val))
+    yield

@@ -193,7 +193,10 @@ def test_bench_starts_its_own_ranks_dry_run():
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     rec = json.loads(lines[0])
+    gt = rec.pop("grid_tile")
     assert rec == {"dryrun": True, "n_gpus": 2, "gpus_arg": 2, "steps": 3, "warmup": 1}
+    # the grid-tile leg's partition + all-reduce + normalisation (numpy in place of the device kernel): 48 rows over 2 ranks
+    assert gt["ok"] and gt["rows_per_rank"] == 24 and gt["max_abs_err_vs_untiled"] < 1e-12
     # a failing rank must surface as a non-zero exit code of the parent
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--bogus-flag"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=300)

@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 25
     missing = [s for s in syms if not hasattr(L, s)]
     assert missing == []
-    assert capi.lib().eea_abi_version() == 2
+    assert capi.lib().eea_abi_version() == 3
 
 
 def test_library_exports_only_the_documented_abi():
@@ -62,3 +62,23 @@ def test_argument_errors_do_not_need_a_device():
     assert L.eea_comm_create(0, 2, 0, None, C.byref(h)) == capi.ERR_INVALID_ARGUMENT  # nranks > 1 needs an id
     assert L.eea_comm_get_unique_id(None) == capi.ERR_INVALID_ARGUMENT
     assert L.eea_comm_nranks(None) == 1 and L.eea_comm_rank(None) == 0
+
+
+def test_options_need_no_device_and_reject_bad_values():
+    """eea_set_option / eea_get_option (the library reads no environment variable): defaults, round trip, range checks"""
+    assert [capi.get_option(o) for o in range(4)] == [0, 0, 0, 1]
+    capi.set_option(capi.OPT_COLLISION_IMPL, 2)
+    assert capi.get_option(capi.OPT_COLLISION_IMPL) == 2
+    capi.set_option(capi.OPT_COLLISION_IMPL, 0)
+    for opt, bad in ((capi.OPT_CONTROL_KERNEL, 2), (capi.OPT_WORKGROUP_THREADS, 96), (capi.OPT_COLLISION_IMPL, 3),
+                     (capi.OPT_MAILBOX_POLL, -1), (17, 0)):
+        with pytest.raises(capi.EngineError):
+            capi.set_option(opt, bad)
+    assert capi.get_option(99) == 0
+
+
+def test_library_reads_no_environment_variable():
+    """the knobs of ABI 2 (EEA_CONTROL_PATH, EEA_BLOCK, ...) are gone: no getenv in the product library"""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--undefined-only", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "getenv" not in out

@@ -137,17 +137,17 @@ def test_inflated_map_and_ring_search_agree_with_oracle(res, coll):
     assert 0 < ref.sum() < P
 
 
-@pytest.mark.parametrize("forced", ["0", "1"])
+@pytest.mark.parametrize("forced", [1, 2])
 def test_both_implementations_forced(forced):
-    """EEA_COLLISION_MAP=0 / 1 pins the ring search / the inflated map for every call (read once per
-    process, hence the subprocess): the collision and DWA parity tests must pass with either."""
+    """EEA_OPT_COLLISION_IMPL = 1 / 2 pins the ring search / the inflated map for every call: the collision and DWA
+    parity tests must pass with either (re-run in a subprocess whose conftest applies the option)."""
     import os
     import subprocess
     import sys
-    if os.environ.get("EEA_COLLISION_MAP") is not None:
+    if os.environ.get("EEA_TEST_OPTIONS"):
         pytest.skip("already inside a forced run")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, EEA_COLLISION_MAP=forced)
+    env = dict(os.environ, EEA_TEST_OPTIONS="%d=%d" % (capi.OPT_COLLISION_IMPL, forced))
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", "tests/test_gpu_collision_parity.py",
                         "tests/test_gpu_dwa_parity.py", "-k", "not forced"], cwd=root, env=env, capture_output=True,
                        text=True, timeout=900)

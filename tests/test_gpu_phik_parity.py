@@ -262,6 +262,15 @@ def test_occupancy_row_tiles():
             total += part
         torch.cuda.synchronize()
         assert np.abs((total / total[0]).cpu().numpy() - full).max() < 1e-13
+        # the device-side finish of the tiled form: phi_k = sums / sums[0], stream-ordered, no host round trip
+        e2 = _engine(K, res)
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            sums = total.clone()
+        e2.set_phik_from_sums(sums, lx, ly, stream=st.cuda_stream)
+        torch.cuda.synchronize()
+        assert np.abs(e2.phik() - full).max() < 1e-13
+        e2.close()
     eng.close()
 
 

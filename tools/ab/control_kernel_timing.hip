@@ -1,6 +1,12 @@
-// Diagnostic build of the fused control kernel with phase stamps (EEA_TIMING): K = 10 and 30, fp64 only.
-// Not used by the product path; reached through eea_debug_phase_timing.
-#define EEA_TIMING 1
+// Diagnostic build of the workgroup-per-agent control kernel with phase stamps: K = 10 and 30, fp64 only.
+// Not used by the product path; reached through eea_debug_phase_timing (engine_ab.inc).
+// Each wavefront's lane 0 records the shader clock at the phase boundaries into p.dbg [agent][4 waves][16].
+#define EEA_STAMP(n)                                                                            \
+  do {                                                                                          \
+    if (p.dbg != nullptr && (threadIdx.x & 63) == 0)                                            \
+      p.dbg[(static_cast<size_t>(blockIdx.x) * 4 + (threadIdx.x >> 6)) * 16 + (n)] =            \
+          static_cast<long long>(__builtin_readcyclecounter());                                 \
+  } while (0)
 #include "control_kernel_impl.hpp"
 
 namespace eea

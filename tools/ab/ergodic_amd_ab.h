@@ -10,10 +10,8 @@ extern "C" {
 /* same as eea_control_batch for an fp64 engine, through the instrumented builds of the control kernels, which
  * record the shader clock at the phase boundaries (tools/phase_timing.py):
  *   wavefront-per-agent kernel (default path): lane 0 of the agent's wavefront, 10 stamps, d_stamps [B][16] int64;
- *   workgroup-per-agent kernel (EEA_CONTROL_PATH=workgroup, K = 10 only): every wavefront, 12 stamps,
- *   d_stamps [B][4][16] int64.
- * Environment knobs of the A/B library: EEA_CONTROL_IMPL=v1 (first control kernel),
- * EEA_PHIK_IMPL=valu (per-column phi_k pass). */
+ *   workgroup-per-agent kernel (eea_set_option(EEA_OPT_CONTROL_KERNEL, 1) or a shape the wavefront kernel does
+ *   not take; K = 10 and 30): every wavefront, 12 stamps, d_stamps [B][4][16] int64. */
 eea_status eea_debug_phase_timing(eea_engine* e, unsigned B, const eea_batch_io* io, void* stream,
                                   long long* d_stamps);
 #ifdef __cplusplus

@@ -7,13 +7,17 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+os.environ["EEA_PRINT_WORST"] = "1"   # the full-size tests print their measured worst differences
+
 from ergodic_exploration_amd import capi  # noqa: E402
 from tests import test_gpu_control_parity as t  # noqa: E402
+from tests import test_gpu_round2_parity as t2  # noqa: E402
 
 CASES = [("omni", 5, 0.5, 0.1, 0), ("simple_cart", 10, 2.0, 0.1, 0), ("omni", 10, 5.0, 0.1, 7),
          ("simple_cart", 10, 5.0, 0.1, 100), ("omni", 10, 20.0, 0.1, 0), ("simple_cart", 10, 20.0, 0.1, 100),
          ("omni", 7, 30.0, 0.1, 5), ("omni", 30, 50.0, 0.1, 0)]
-print("fp64: worst abs difference kernel vs oracle over B agents x calls")
+print("fp64: worst abs difference kernel vs oracle over B agents x calls (per case: the run's own line with the stage\n"
+      "magnitudes, then the summary)")
 for model, K, hor, dt, n_mem in CASES:
     B = 1 if K >= 30 else 4
     w = t.run_batch_vs_oracle(model, K, hor, dt, B=B, n_mem=n_mem, calls=2, seed=21)
@@ -25,3 +29,12 @@ for prec, name, tol, tck in ((capi.PREC_F64, "f64", 1e-9, 1e-11), (capi.PREC_F32
     w = t.run_batch_vs_oracle("omni", 20, 5.0, 0.02, B=2, n_mem=0, calls=2, seed=3, bounds=bounds, means=means,
                               sigmas=sigmas, precision=prec, tol=tol, tol_ck=tck)
     print("config3 %s  K=20 T=250 " % name + " ".join("%s=%.1e" % (k, v) for k, v in sorted(w.items())))
+print("BASELINE config 4 at full size (4096 agents, K=10, T=200): (|u0 diff|, |ut diff|) after call 1 and call 2")
+for model in ("simple_cart", "omni"):
+    t2.test_config4_full_size_against_oracle(model)
+t2.test_config4_full_size_f32_against_f64_oracle()
+print("BASELINE config 5 end to end (1024^2 occupancy -> phi_k K=30 -> control T=500)")
+t2.test_config5_end_to_end_against_oracle()
+for dt in (1.0, 2.0):
+    print("large step increments dt=%g (bars relative to max(1, |stage|))" % dt)
+    t.test_small_and_large_step_increments(dt)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Per-phase latency of the control kernel (K = 10, T = 200, fp64) from the instrumented A/B build
 (make -C ergodic_exploration_amd/csrc AB=1): mean shader-clock cycles every wavefront spends between the
-phase stamps.  Default: the wavefront-per-agent kernel ([agent][16] stamps); EEA_CONTROL_PATH=workgroup: the
-workgroup-per-agent kernel ([agent][4 waves][16])."""
+phase stamps.  Default: the wavefront-per-agent kernel ([agent][16] stamps); EEA_PHASE_KERNEL=workgroup: the
+workgroup-per-agent kernel ([agent][4 waves][16]) through eea_set_option(EEA_OPT_CONTROL_KERNEL, 1)."""
 import os
 import sys
 
@@ -22,7 +22,10 @@ PHASES_WAVE = ["load+shift controls", "heading scan", "heading sincos + position
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-    wg = os.environ.get("EEA_CONTROL_PATH") == "workgroup" or int(os.environ.get("EEA_PHASE_K", "10")) > 20 or \
+    force_wg = os.environ.get("EEA_PHASE_KERNEL") == "workgroup"
+    if force_wg:
+        capi.set_option(capi.OPT_CONTROL_KERNEL, 1)
+    wg = force_wg or int(os.environ.get("EEA_PHASE_K", "10")) > 20 or \
         float(os.environ.get("EEA_PHASE_HORIZON", "20.0")) > 25.6
     model = capi.MODEL_SIMPLE_CART
     lim = np.array([1.0, 0.0, 2.0])

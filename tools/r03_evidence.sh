@@ -1,0 +1,23 @@
+#!/bin/bash
+# Round-3 evidence run (on the GPU box through gpurun): the default bench line, rocprofv3 kernel stats + PMC passes
+# of the SAME command shape (spin-up on, two agent groups) and of one launch per pass, the shader clock under
+# sustained load (phase stamps of the A/B library), phi_k counters at the bench's 16384^2 grid, parity report.
+# Output: gpurun_out/r03_evidence/  (copy what is to be judged into profiles/)
+set -u
+OUT=gpurun_out/r03_evidence
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp; cd "$GRAFT_REPO_ROOT"
+python3 bench.py --steps 20 --warmup 5 > "$OUT/bench.json" 2> "$OUT/bench.err"
+bash tools/profile_r.sh r03_g2 > /dev/null 2>&1
+bash tools/profile_r.sh r03_g1 --agent-groups 1 > /dev/null 2>&1
+for g in g2 g1; do
+  cp gpurun_out/prof_r03_$g/summary.txt "$OUT/${g}_summary.txt"; cp gpurun_out/prof_r03_$g/summary.json "$OUT/${g}_summary.json"
+  cp gpurun_out/prof_r03_$g/trace/trace_kernel_stats.csv "$OUT/${g}_kernel_stats.csv" 2>/dev/null
+done
+# shader clock while the kernel runs, after 1000 passes of load: cycles (s_memtime) / lifetime (s_memrealtime)
+EEA_PHASE_WARMUP=1000 python3 tools/phase_timing.py 4096 > "$OUT/phase_timing.txt" 2>&1
+EEA_PHASE_WARMUP=1000 python3 tools/phase_timing.py 2048 >> "$OUT/phase_timing.txt" 2>&1
+PHIK_CASES="16384:10:f64" bash tools/phik_pmc.sh > "$OUT/phik_pmc.txt" 2>&1
+python3 tools/parity_report.py > "$OUT/parity_report.txt" 2>&1
+python3 tools/rebuild_bench.py > "$OUT/rebuild.txt" 2>&1
+ls -la "$OUT"

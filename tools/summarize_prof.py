@@ -27,15 +27,53 @@ def main():
             if "control_kernel" in name or "control_wave_kernel" in name:
                 summary["control_kernel_avg_ns"] = float(r.get("AverageNs", 0))
                 summary["control_kernel_calls"] = int(r.get("Calls", 0))
-    # kernel trace: register / LDS use of the control kernel
+    # the bench line the traced run itself printed (last JSON line of trace.log)
+    bench = None
+    try:
+        with open(os.path.join(out, "trace.log")) as f:
+            for line in f:
+                if line.startswith("{") and '"metric"' in line:
+                    bench = json.loads(line)
+    except OSError:
+        pass
+    # kernel trace: register / LDS use of the control kernel, and the dispatches of the TIMED region
     for p in glob.glob(os.path.join(out, "trace", "**", "*kernel_trace.csv"), recursive=True):
+        disp = []
         for r in rows(p):
             if "control_" in r.get("Kernel_Name", ""):
-                keys = ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size",
-                        "Workgroup_Size", "Grid_Size")
-                summary["control_kernel_resources"] = {k: r.get(k) for k in keys if k in r}
-                print("== control kernel resources:", summary["control_kernel_resources"])
-                break
+                if "control_kernel_resources" not in summary:
+                    keys = ("VGPR_Count", "Accum_VGPR_Count", "SGPR_Count", "LDS_Block_Size", "Scratch_Size",
+                            "Workgroup_Size_X", "Grid_Size_X")
+                    summary["control_kernel_resources"] = {k: r.get(k) for k in keys if k in r}
+                    print("== control kernel resources:", summary["control_kernel_resources"])
+                disp.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+        if bench is not None and disp:
+            disp.sort()
+            G = int(bench["config"]["agent_groups"])
+            n_timed = int(bench["steps"]) * int(bench["config"]["passes_per_step"]) * G
+            timed = disp[-n_timed:]
+            dur = [e - s for s, e in timed]
+            avg_ns = sum(dur) / len(dur)
+            span_ns = max(e for _, e in timed) - min(s for s, _ in timed)
+            passes = n_timed // G
+            tr = {"dispatches_timed_region": len(timed), "dispatches_total": len(disp), "concurrent_launches": G,
+                  "agents_per_launch": bench["roofline"]["agents_per_launch"],
+                  "kernel_avg_us_timed_region": avg_ns * 1e-3,
+                  "kernel_avg_us_all_dispatches": sum(e - s for s, e in disp) / len(disp) * 1e-3,
+                  "pass_period_us_from_trace": span_ns * 1e-3 / passes,
+                  "bench_ms_per_pass_same_run": bench["ms_per_pass"],
+                  "bench_launch_ms_same_run": bench["roofline"]["launch_ms"],
+                  "flops_per_launch": bench["roofline"]["flops_per_launch"]}
+            # launches_per_pass x avg / concurrent launches = pass period the kernel durations alone would give
+            tr["pass_us_from_kernel_avg"] = tr["kernel_avg_us_timed_region"] * G / G
+            tr["tflops_from_kernel_avg"] = G * tr["flops_per_launch"] / (avg_ns * 1e-9) / 1e12
+            tr["frac_of_78.6_from_kernel_avg"] = tr["tflops_from_kernel_avg"] / 78.6
+            tr["frac_same_run_bench_line"] = bench["roofline"]["frac"]
+            summary["timed_region"] = tr
+            print("== timed region (last %d of %d control dispatches; %d concurrent launches per pass)" % (
+                len(timed), len(disp), G))
+            for k, v in tr.items():
+                print("   %-34s %s" % (k, ("%.6g" % v) if isinstance(v, float) else v))
     # counters
     counters = defaultdict(list)
     for p in glob.glob(os.path.join(out, "pmc_*", "**", "*counter_collection.csv"), recursive=True):
