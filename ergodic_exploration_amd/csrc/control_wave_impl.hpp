@@ -123,6 +123,26 @@ __device__ __forceinline__ void half_swap(float v, float& from_lower, float& fro
   from_upper = __int_as_float(static_cast<int>(r[1]));
 }
 
+// v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 products D_b = A_b B_b + C_b in 16 cycles (a quarter of the 16x16x4
+// instruction's 64).  Operand layout (probed on the MI355X, tools/ubench/mfma4x4.hip): lane l supplies A_b[i][k] and
+// B_b[k][j] with k = l / 16, b = (l / 4) % 4, i (j) = l % 4 and holds D_b[i][j] with i = l / 16, b = (l / 4) % 4, j = l % 4.
+__device__ __forceinline__ double mfma4(double a, double b, double c)
+{
+  return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float mfma4(float, float, float c) { return c; }  // fp32 keeps the 16x16x4 form
+
+// v + (v rotated right by N lanes inside its row of 16 lanes)
+template <int N>
+__device__ __forceinline__ double add_row_ror(double v)
+{
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(0, lo, 0x120 + N, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + N, 0xf, 0xf, false);
+  return v + __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float add_row_ror4(float v) { return v; }
+
 template <typename R, int MODEL>
 __device__ __forceinline__ void model_xy(R vx, R vy, R c, R s, R& fx, R& fy)
 {
@@ -185,7 +205,20 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   R* const s_D = tabx;                      // D[k2 * K + k1]   (after the contraction)
   R* const s_g = tabx + d_elems(KC == 16 ? 16 : KC);  // barrier gradient parked during the gradient, [2 j + r][lane]
 
-  const int i0 = S * lane;  // first horizon step of this lane
+  // Lane -> horizon steps.  Lanes [0, q16) own S consecutive steps each, q16 = the number of full lanes rounded DOWN to
+  // a multiple of 16; what is left of the horizon (rem < 16 S steps) is spread over the next <= 16 lanes, sc =
+  // ceil(rem / 16) <= S steps each.  Lane order is step order (the scans need nothing else), and the valid lanes of a
+  // slot j are whole groups of 16 plus at most one partial group -- the contraction multiplies groups of 16 points
+  // (T = 200: lanes 0..47 own 4 steps, lanes 48..55 one: 13 groups instead of 16).
+  const int q16 = (T / S) & ~15;
+  const int rem = T - S * q16;
+  const int sc = (rem + 15) >> 4;
+  const int i0 = lane < q16 ? S * lane : S * q16 + sc * (lane - q16);  // first horizon step of this lane
+  const int cnt = lane < q16 ? S : max(0, min(sc, T - i0));            // steps of this lane
+  // number of lanes that own a step in slot j (wave-uniform)
+  auto lanes_in_slot = [&](int j) { return q16 + (j < sc ? (rem - j + sc - 1) / sc : 0); };
+  // steps of another lane
+  auto cnt_of = [&](int l) { return l < q16 ? S : max(0, min(sc, rem - sc * (l - q16))); };
   const R* const pose = p.pose + 3 * static_cast<size_t>(b);
   R* const ut = p.ut + 3 * static_cast<size_t>(T) * b;
 
@@ -200,13 +233,13 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
     vx[j] = vy[j] = w[j] = R(0);
     if (j < S) {
       const int src = rollout_only ? i0 + j : i0 + j + 1;  // optTraj rolls the controls out as they are
-      if (src < T) {
+      if (j < cnt && src < T) {
         vx[j] = ut[3 * src + 0];
         vy[j] = ut[3 * src + 1];
         w[j] = ut[3 * src + 2];
       }
       // SimpleCart::operator() rejects a lateral velocity (cart.hpp:167-170)
-      if (MODEL == kModelSimpleCart && i0 + j < T && !(fabs(vy[j]) < R(1.0e-12))) bad = true;
+      if (MODEL == kModelSimpleCart && j < cnt && !(fabs(vy[j]) < R(1.0e-12))) bad = true;
     }
   }
   const R x0 = pose[0], y0 = pose[1], th0 = pose[2];
@@ -314,7 +347,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
     R* const traj = p.traj + 3 * static_cast<size_t>(T) * b;
 #pragma unroll
     for (int j = 0; j < kMaxS; ++j) {
-      if (j < S && i0 + j < T) {
+      if (j < cnt) {
         traj[3 * (i0 + j) + 0] = px[j];
         traj[3 * (i0 + j) + 1] = py[j];
         traj[3 * (i0 + j) + 2] = wrap_pi_fast(thp[j]);
@@ -483,7 +516,140 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
     lds_fence();
   };
 
-  if (KC != 16 && NT == 1) {
+  // ---- fp64, K = 5 / 10: the contraction in 4x4 blocks ----------------------------------------------------------
+  // fp64 matrix instructions run on the vector pipe's own multipliers (profiles/r02_ubench_coissue.txt): the 16x16 tile
+  // of the form above -- 100 useful entries of 256 at K = 10, 64 cycles per 4 points -- is a quarter of the agent's
+  // pipe time.  v_mfma_f64_4x4x4_4b multiplies four independent 4x4x4 blocks in 16 cycles.  The four blocks of an
+  // instruction are four GROUPS OF 4 POINTS (16 rows of the tile) for ONE pair (I, J) of 4-mode blocks: the A operand
+  // of block I serves the NB instructions (I, 0..NB-1) and the B operand of block J the NB instructions (0..NB-1, J),
+  // so a group of 16 points costs 2 NB operand reads and NB^2 instructions: K = 10: 6 reads + 9 x 16 = 144 cycles per 16
+  // points instead of 8 reads + 4 x 64 = 256.  Every accumulator holds four partial sums (one per point group), added
+  // at the end by two row rotations.  (Round 2's block form gave the four blocks four different (I, J) pairs of the
+  // same 4 points: every instruction then needs its own operands -- 288 LDS reads per agent -- and the phase became
+  // LDS-bound, tools/ab/block4_contraction.patch.)
+  constexpr bool kBlock4 = sizeof(R) == 8 && (KC == 10 || KC == 5);
+  constexpr int NB = (KC + 3) / 4;          // 4-mode blocks per axis
+  R cacc[kBlock4 ? NB : 1][kBlock4 ? NB : 1];
+#pragma unroll
+  for (int I = 0; I < (kBlock4 ? NB : 1); ++I) {
+#pragma unroll
+    for (int J = 0; J < (kBlock4 ? NB : 1); ++J) cacc[I][J] = R(0);
+  }
+  // operand coordinates of this lane: row of the 16-row group, mode inside the 4-mode block (modes past K read the
+  // next row's first entries -- finite values whose products land in accumulator entries nobody reads)
+  const int orow = 4 * ((lane >> 2) & 3) + (lane >> 4), oi = lane & 3;
+  R qa[2][kBlock4 ? NB : 1], qb[2][kBlock4 ? NB : 1];
+  auto read_operands4 = [&]() {  // both 16-row groups of the tile
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+#pragma unroll
+      for (int g = 0; g < NB; ++g) {
+        const int off = (16 * q + orow) * KS + 4 * g + oi;
+        qa[q][g] = tabx[off];
+        qb[q][g] = taby[off];
+      }
+    }
+  };
+  auto mma4_group = [&](int q) {
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+#pragma unroll
+      for (int J = 0; J < NB; ++J) cacc[I][J] = mfma4(qa[q][I], qb[q][J], cacc[I][J]);
+    }
+  };
+  // plain (not software-pipelined) pass of the block form: replay-memory columns
+  auto stage_and_mma4 = [&](R c_axis, int h, int nl_valid) {
+    {
+      Tab1 t = tab1_init(c_axis, 32 * h + row < nl_valid);
+      R* const dst = h ? st_upper : st_lower;
+#pragma unroll
+      for (int q = 0; q < kPairs; ++q) {
+        tab1_store(t, dst, 2 * q);
+        tab1_step(t);
+      }
+    }
+    const int rows_valid = nl_valid - 32 * h;  // > 0
+    lds_fence();
+    read_operands4();
+    lds_fence();
+    mma4_group(0);
+    if (rows_valid > 16) mma4_group(1);  // wavefront-uniform
+  };
+
+  if constexpr (kBlock4) {
+    // Rollout points, software-pipelined as below: the operands of a pass (12 reads) are read first, then the tile is
+    // free and the recurrence + stores of the NEXT pass are issued between the matrix instructions of the first
+    // 16-row group (pinned with scheduling barriers); the second group is skipped when it holds no valid point.
+    R cl, cu;
+    stage_cos(c1x[0], c1y[0], cl, cu);
+    {
+      Tab1 u = tab1_init(cl, 0 < cnt_of(row));
+#pragma unroll
+      for (int q = 0; q < kPairs; ++q) {
+        tab1_store(u, st_lower, 2 * q);
+        tab1_step(u);
+      }
+    }
+    // the matrix instructions of one 16-row group with the staging of `dst` (kPairs stores) spread between them
+    auto mma4_group_staging = [&](int q, Tab1& u, R* dst) {
+      constexpr int kEvery = (NB * NB + kPairs - 1) / kPairs;  // a store after every kEvery-th instruction
+      int done = 0;
+#pragma unroll
+      for (int I = 0; I < NB; ++I) {
+#pragma unroll
+        for (int J = 0; J < NB; ++J) {
+          cacc[I][J] = mfma4(qa[q][I], qb[q][J], cacc[I][J]);
+          const int n = I * NB + J + 1;
+          if (n % kEvery == 0 && done < kPairs) {
+            tab1_store(u, dst, 2 * done);
+            tab1_step(u);
+            ++done;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+#pragma unroll
+      for (int q2 = 0; q2 < kPairs; ++q2) {  // (none left when kPairs * kEvery <= NB * NB)
+        if (q2 >= done) {
+          tab1_store(u, dst, 2 * q2);
+          tab1_step(u);
+        }
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      if (j < S) {  // wavefront-uniform
+        const int nl = lanes_in_slot(j);  // > 0
+        lds_fence();
+        read_operands4();  // rows of lanes 0..31, step j
+        lds_fence();       // operands in registers: the tile is free
+        {
+          Tab1 u = tab1_init(cu, j < cnt_of(row + 32));
+          mma4_group_staging(0, u, st_upper);
+          if (nl > 16) mma4_group(1);
+        }
+        lds_fence();
+        read_operands4();  // rows of lanes 32..63, step j
+        lds_fence();
+        {
+          const int jn = (j + 1 < kMaxS) ? j + 1 : j;
+          stage_cos(c1x[jn], c1y[jn], cl, cu);
+          Tab1 u = tab1_init(cl, (j + 1 < S) && (j + 1 < cnt_of(row)));
+          if (nl > 32) {
+            mma4_group_staging(0, u, st_lower);
+            if (nl > 48) mma4_group(1);
+          } else {
+#pragma unroll
+            for (int q = 0; q < kPairs; ++q) {
+              tab1_store(u, st_lower, 2 * q);
+              tab1_step(u);
+            }
+          }
+        }
+      }
+    }
+    lds_fence();
+  } else if (KC != 16 && NT == 1) {
     // Rollout points, software-pipelined: the 8 matrix instructions of a pass take 65 cycles of the matrix pipe
     // each; the table recurrence and the LDS stores of the NEXT pass are issued in between them (in program
     // order, pinned with scheduling barriers), so that only the operand reads wait.  Branch-free: passes beyond
@@ -497,12 +663,10 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
         ob[m] = taby[off];
       }
     };
-    // lanes l with S l + j < T: floor((T - 1 - j) / S) + 1 = q + (j <= rem), one division for all steps
-    const int nl_q = (T - 1) / S, nl_rem = (T - 1) - S * nl_q;
     R cl, cu;
     stage_cos(c1x[0], c1y[0], cl, cu);
     {
-      Tab1 u = tab1_init(cl, S * row < T);
+      Tab1 u = tab1_init(cl, 0 < cnt_of(row));
 #pragma unroll
       for (int q = 0; q < kPairs; ++q) {
         tab1_store(u, st_lower, 2 * q);
@@ -520,10 +684,10 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
         // (m >= kPairs): fp64 matrix instructions hold the vector pipe of the whole SIMD for their 64 cycles
         // (profiles/r02_ubench_coissue.txt), so at T = 200 the 3 empty groups of every upper pass are 19 % of the
         // contraction's pipe time
-        const int nl = nl_q + (j <= nl_rem ? 1 : 0);              // lanes l with S l + j < T
+        const int nl = lanes_in_slot(j);
         const int n_lo = ((nl < 32 ? nl : 32) + 3) >> 2, n_up = (nl - 32 + 3) >> 2;  // row groups with a valid row
         {
-          Tab1 u = tab1_init(cu, S * (row + 32) + j < T);
+          Tab1 u = tab1_init(cu, j < cnt_of(row + 32));
 #pragma unroll
           for (int m = 0; m < kStageRows / 4; ++m) {
             if (m < kPairs || m < n_lo) {  // wavefront-uniform
@@ -544,7 +708,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
         {
           const int jn = (j + 1 < kMaxS) ? j + 1 : j;
           stage_cos(c1x[jn], c1y[jn], cl, cu);
-          Tab1 u = tab1_init(cl, (j + 1 < S) && (S * row + j + 1 < T));
+          Tab1 u = tab1_init(cl, (j + 1 < S) && (j + 1 < cnt_of(row)));
 #pragma unroll
           for (int m = 0; m < kStageRows / 4; ++m) {
             if (m < kPairs || m < n_up) {  // wavefront-uniform
@@ -565,8 +729,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
 #pragma unroll
     for (int j = 0; j < kMaxS; ++j) {
       if (j < S) {
-        // lanes l with S l + j < T  <=>  l < ceil((T - j) / S)
-        const int nl = (T - j + S - 1) / S;
+        const int nl = lanes_in_slot(j);
         R cl, cu;
         stage_cos(c1x[j], c1y[j], cl, cu);
         stage_and_mma(cl, 0, nl);
@@ -587,15 +750,58 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
       const int nl = nmem - c0;  // > 0
       R cl, cu;
       stage_cos(ca, cb, cl, cu);
-      stage_and_mma(cl, 0, nl);
-      if (nl > 32) stage_and_mma(cu, 1, nl);
+      if constexpr (kBlock4) {
+        stage_and_mma4(cl, 0, nl);
+        if (nl > 32) stage_and_mma4(cu, 1, nl);
+      } else {
+        stage_and_mma(cl, 0, nl);
+        if (nl > 32) stage_and_mma(cu, 1, nl);
+      }
     }
   }
 
-  load_lam_phi();
+  if constexpr (!kBlock4) load_lam_phi();
   EEA_WSTAMP(5);
   // D = lambda (c - phi), fourier_diff of ergodic_control.hpp:422, in both orientations
-  {
+  if constexpr (kBlock4) {
+    // every accumulator holds, in the four blocks of its row of 16 lanes, four partial sums over different point
+    // groups: two row rotations complete them in all four copies.  Copy d of the row then finishes the pairs
+    // (I, J) with (I NB + J) % 4 == d: lane l = 16 i + 4 d + j holds c(k1 = 4 I + i, k2 = 4 J + j).
+    const R invN = R(1) / static_cast<R>(N);
+    const int di = lane >> 4, db = (lane >> 2) & 3, dj = lane & 3;
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+#pragma unroll
+      for (int J = 0; J < NB; ++J) cacc[I][J] = add_row_ror<8>(add_row_ror<4>(cacc[I][J]));
+    }
+    constexpr int TS = (NB * NB + 3) / 4;  // pairs per block copy
+    R cv[TS], lamv[TS], phiv[TS];
+    int idx[TS];
+    bool okv[TS];
+#pragma unroll
+    for (int t = 0; t < TS; ++t) {
+      R v = cacc[(4 * t) / NB][(4 * t) % NB];
+#pragma unroll
+      for (int d = 1; d < 4; ++d) {
+        if (4 * t + d < NB * NB) v = (db == d) ? cacc[(4 * t + d) / NB][(4 * t + d) % NB] : v;
+      }
+      const int pi = 4 * t + db, I = pi / NB, J = pi - NB * I;
+      const int k1 = 4 * I + di, k2 = 4 * J + dj;
+      okv[t] = pi < NB * NB && k1 < K && k2 < K;
+      idx[t] = okv[t] ? k2 * K + k1 : 0;
+      cv[t] = invN * v;
+      lamv[t] = p.lamdak[idx[t]];
+      phiv[t] = p.phik[idx[t]];
+      if (p.ck != nullptr && okv[t]) p.ck[static_cast<size_t>(b) * K2 + idx[t]] = cv[t];
+      // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
+      if (p.ck_shared != nullptr) cv[t] = p.ck_shared[idx[t]];
+    }
+#pragma unroll
+    for (int t = 0; t < TS; ++t) {
+      if (okv[t]) s_D[idx[t]] = lamv[t] * (cv[t] - phiv[t]);
+    }
+    lds_fence();
+  } else {
     const R invN = R(1) / static_cast<R>(N);
     if (NT == 1) acc0 = acc0 + acc1;
     const acc_t* const accs[4] = { &acc0, &acc1, &acc2, &acc3 };
@@ -766,7 +972,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
       } else {
         // g = edx + bdx (inactive steps contribute nothing to the suffix sums); the basis registers of this
         // step are dead from here on
-        const bool act = i0 + j < T;
+        const bool act = j < cnt;
         g0[j] = act ? exj + s_g[(2 * j + 0) * kWave + lane] : R(0);
         g1[j] = act ? eyj + s_g[(2 * j + 1) * kWave + lane] : R(0);
       }
@@ -775,7 +981,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   if (STAGES) {
 #pragma unroll
     for (int j = 0; j < kMaxS; ++j) {
-      if (j < S && i0 + j < T) {
+      if (j < cnt) {
         if (p.edx != nullptr) {
           R* const o = p.edx + 3 * (static_cast<size_t>(T) * b + i0 + j);
           o[0] = ex[j];
@@ -808,7 +1014,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
 #pragma unroll
     for (int j = 0; j < kMaxS; ++j) {
       const int src = i0 + j + 1;
-      const bool ok = j < S && src < T;
+      const bool ok = j < cnt && src < T;  // (a slot this lane does not own belongs to another lane's step)
       const int idx = ok ? 3 * src : 0;
       const R a = ut_again[idx];
       vxr[j] = ok ? a : R(0);
@@ -825,7 +1031,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
 #pragma unroll
     for (int j = kMaxS - 1; j >= 0; --j) {
       if (STAGES) {
-        const bool act = j < S && i0 + j < T;
+        const bool act = j < cnt;
         g0[j] = act ? ex[j] + g0[j] : R(0);  // g = edx + bdx
         g1[j] = act ? ey[j] + g1[j] : R(0);
       }
@@ -877,7 +1083,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   // ---- u_i = clamp(-Rinv B(x_i)^T rho_i)  (ergodic_control.hpp:438-451) ---------------------------------
 #pragma unroll
   for (int j = 0; j < kMaxS; ++j) {
-    if (j < S && i0 + j < T) {
+    if (j < cnt) {
       const int i = i0 + j;
       R v0, v1, v2;
       if (MODEL == kModelOmni) {  // omni.hpp:205-212

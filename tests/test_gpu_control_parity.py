@@ -29,7 +29,10 @@ def dev(a, dtype=torch.float64):
 
 
 def run_batch_vs_oracle(model, K, horizon, dt, B, n_mem, calls, seed, precision=capi.PREC_F64,
-                        tol=TOL, tol_ck=TOL_CK, bounds=MAP_BOUNDS, means=MEANS, sigmas=SIGMAS):
+                        tol=TOL, tol_ck=TOL_CK, bounds=MAP_BOUNDS, means=MEANS, sigmas=SIGMAS, tol_u_rho=0.0):
+    """tol_u_rho (fp32 runs only): u = clamp(-Rinv B^T rho) inherits the co-state's ABSOLUTE rounding error wherever
+    it is not clamped, so when the co-state is far from unit size (robot outside the map: |rho| ~ 1e3) the bar on the
+    controls is max(tol max(1, |u|), tol_u_rho |rho|max); fp64 runs keep the pure per-stage bar (tol_u_rho = 0)."""
     rng = np.random.default_rng(seed)
     eng, ors = make_pair(model, K, horizon, dt=dt, precision=precision, n_oracles=B, bounds=bounds,
                          means=means, sigmas=sigmas)
@@ -86,8 +89,10 @@ def run_batch_vs_oracle(model, K, horizon, dt, B, n_mem, calls, seed, precision=
         print("worst", model, K, T, n_mem, "dt=%g" % dt, "f32" if precision == capi.PREC_F32 else "f64",
               {k: "%.2e (|stage| %.1e)" % (worst[k], magn[k]) for k in worst})
     assert scaled["ck"] <= tol_ck, (worst, magn)
-    for k in ("traj_xy", "traj_th", "edx", "bdx", "rhot", "ut", "u0"):
+    for k in ("traj_xy", "traj_th", "edx", "bdx", "rhot"):
         assert scaled[k] <= tol, (k, worst, magn)
+    for k in ("ut", "u0"):
+        assert scaled[k] <= tol or worst[k] <= tol_u_rho * magn["rhot"], (k, worst, magn)
     return worst
 
 
@@ -142,7 +147,7 @@ def test_contraction_row_group_boundaries(steps):
     # fp32 against the fp64 oracle (<= 5e-4 on the co-state; every bar relative to max(1, |stage|): with
     # dt = 0.125 the longer horizons leave the 12 m map and the barrier gradient / co-state reach 1e2-1e3)
     run_batch_vs_oracle("omni", 10, steps * 0.125, 0.125, B=2, n_mem=33, calls=2, seed=64, precision=capi.PREC_F32,
-                        tol=5e-4, tol_ck=1e-5)
+                        tol=5e-4, tol_ck=1e-5, tol_u_rho=2e-6)
 
 
 @pytest.mark.parametrize("dt", [0.1, 1.0, 2.0])
