@@ -65,8 +65,11 @@ def parse():
                     help="skip the exchange legs (consensus all-reduce, c_k all-gather)")
     ap.add_argument("--force-exchange", "--force-gather", dest="force_exchange", action="store_true",
                     help="run the all-gather leg even with one rank (single-rank RCCL communicator)")
-    ap.add_argument("--consensus-lag", type=int, default=2, choices=[1, 2],
-                    help="passes between producing c_k and consuming its consensus (2: the exchange overlaps a pass)")
+    ap.add_argument("--consensus-lag", type=int, default=4, choices=[1, 2, 3, 4, 5],
+                    help="passes between producing c_k and consuming its consensus: the record sum of pass i gets its "
+                         "execution slots when the kernels of pass i + 1 finish, and the host issues the exchange calls "
+                         "about as fast as the device runs a pass (tools/ck_cost.py: 50 / 38 / 34.5 us per pass at lag "
+                         "2 / 3 / 4 on one GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per leg; 0 = skip")
     ap.add_argument("--no-latency", action="store_true", help="skip the B = 1 dependent-call leg")
     ap.add_argument("--no-phik", action="store_true", help="skip the phi_k legs (roofline_phik)")
@@ -339,7 +342,7 @@ def main():
 
     compute = torch.cuda.Stream()
     torch.cuda.set_stream(compute)  # once, not per pass: the loop must out-run a ~40 us kernel
-    xstream = torch.cuda.Stream()   # exchange steps run beside the next pass
+    xstream = torch.cuda.Stream(priority=-1)   # exchange steps run beside the next pass (host-staged / all-gather legs)
     # agent groups: contiguous slices of the batch, group 0 on the compute stream
     G = max(1, min(args.agent_groups, B))
     gb = [(g * B) // G for g in range(G + 1)]
@@ -352,38 +355,53 @@ def main():
                   mem_cols=sl(d_mem, g), n_mem=sl(d_nmem, g), stream=gstreams[g].cuda_stream) for g in range(G)]
 
     # ---- exchange plumbing -------------------------------------------------------------------------------
-    NB = 3  # c_k / consensus buffers in flight
-    d_ck = [torch.empty((B, K2), dtype=tdt, device="cuda") for _ in range(NB)]
-    d_cbar = [torch.zeros((K2,), dtype=tdt, device="cuda") for _ in range(NB)]
-    ev_ck = [torch.cuda.Event() for _ in range(NB)]
+    # consensus leg: the control kernels leave per-agent sum records (eea_batch_io::d_ck_rec: [c_k, 1]); ONE small
+    # launch on the exchange stream adds them (eea_ck_records_sum: sums + agent count), ONE collective adds the ranks'
+    # records (nothing with one rank), and pass i + lag divides sum by count inside the kernel (ck_shared_parts = 1):
+    # one launch of 2 wavefronts per 64 agents beside the compute streams instead of three dependent launches.
+    NB = args.consensus_lag + 2  # record buffers in flight: pass i writes buffer i % NB and reads (i - lag) % NB; the
+    #                              earlier readers of buffer i % NB (pass i - 2) have finished before pass i starts (it
+    #                              waits for the exchange of pass i - lag >= their own)
+    L = eng.ck_record_len
+    d_arec = [torch.empty((B, L), dtype=tdt, device="cuda") for _ in range(NB)]   # per-agent records of a pass
+    d_rec = [torch.zeros((L,), dtype=tdt, device="cuda") for _ in range(NB)]      # their sum (over all ranks)
+    ev_grp = [[torch.cuda.Event() for _ in range(G)] for _ in range(NB)]
     ev_x = [torch.cuda.Event() for _ in range(NB)]
+    d_ck = [torch.empty((B, K2), dtype=tdt, device="cuda") for _ in range(3)]   # all-gather leg
+    ev_ck = [torch.cuda.Event() for _ in range(3)]
+    ev_ag = [torch.cuda.Event() for _ in range(3)]
     # the communicator is created AFTER the headline leg, under a watchdog (setup_exchange below): a collective
     # library that cannot start on some node must not take the driver-timed line with it
-    comm = None
-    comm_local = None
-    cabi_comm = None
+    comm = None          # RCCL communicator behind the C ABI (ranks > 1, or --force-exchange)
+    xcomm = None         # the communicator the consensus leg's exchange calls go through (a local one with one rank)
+    host_staged = False  # plumbing run: collectives over gloo, staged through the host
     exchange_backend = "local (1 rank)"
     d_all = None
 
-    def exchange_consensus(slot, xslot):
-        """c_bar of the c_k in d_ck[slot] over ALL agents of all ranks -> d_cbar[xslot], beside the compute stream"""
-        if cabi_comm is not None:
-            # one call: the communicator's own stream waits for the pass, runs eea_ck_sum + all-reduce + divide
-            cabi_comm.consensus_ck_async(eng, B, d_ck[slot], d_cbar[xslot], compute.cuda_stream, xslot)
+    xcalls = {}
+
+    def exchange_records(slot):
+        """sum of the pass's per-agent records and its all-reduce over the ranks, on the exchange stream, after EVERY
+        group's launch of that pass -- ONE C-ABI call (eea_comm_records_exchange_async); the consuming passes of all
+        group streams wait for its completion slot (eea_comm_wait)"""
+        if not host_staged:
+            call = xcalls.get(slot)
+            if call is None:
+                call = xcalls[slot] = xcomm.prepared_records_exchange(eng, B, d_arec[slot], d_rec[slot],
+                                                                      [st.cuda_stream for st in gstreams], slot)
+            call()
             return
-        xstream.wait_event(ev_ck[slot])
-        if use_dist and backend == "nccl":
-            with torch.cuda.stream(xstream):
-                sums = torch.cat([d_ck[slot].sum(0), torch.tensor([float(B)], dtype=tdt, device="cuda")])
-                dist.all_reduce(sums)
-                d_cbar[xslot].copy_(sums[:-1] / sums[-1])
-        elif use_dist:
-            with torch.cuda.stream(xstream):
-                sums = torch.cat([d_ck[slot].sum(0), torch.tensor([float(B)], dtype=tdt, device="cuda")]).cpu()
-            dist.all_reduce(sums)
-            with torch.cuda.stream(xstream):
-                d_cbar[xslot].copy_((sums[:-1] / sums[-1]).cuda(), non_blocking=False)
-        ev_x[xslot].record(xstream)
+        # plumbing run (ranks share a GPU, gloo): the record sum on the device, the all-reduce staged through the host
+        for g in range(G):
+            ev_grp[slot][g].record(gstreams[g])
+            xstream.wait_event(ev_grp[slot][g])
+        eng.ck_records_sum(B, d_arec[slot], d_rec[slot], stream=xstream.cuda_stream)
+        with torch.cuda.stream(xstream):
+            h = d_rec[slot].cpu()
+        dist.all_reduce(h)
+        with torch.cuda.stream(xstream):
+            d_rec[slot].copy_(h)
+        ev_x[slot].record(xstream)
 
     def exchange_allgather(slot, i):
         dst = d_all[i % 2]  # consecutive gathers alternate between the two receive buffers
@@ -401,51 +419,53 @@ def main():
             dist.all_gather_into_tensor(hall, h)
             with torch.cuda.stream(xstream):
                 dst.copy_(hall)
-        ev_x[slot].record(xstream)
+        ev_ag[slot].record(xstream)
 
     def setup_exchange():
-        nonlocal comm, comm_local, cabi_comm, exchange_backend
-        if use_dist and not args.no_exchange or args.force_exchange:
-            if backend == "nccl" or not use_dist:
-                # the C ABI's own RCCL communicator: rank 0 creates the id, torch.distributed only carries it.  If that
-                # fails on some rank, every rank falls back to torch.distributed's collectives (the run must not die
-                # with a secondary leg)
-                ok = 1
-                uid = [None]
-                if rank == 0:
-                    try:
-                        uid = [capi.comm_unique_id()]
-                    except Exception as exc:  # noqa: BLE001
-                        sys.stderr.write("rank 0: eea_comm_get_unique_id failed (%r)\n" % (exc,))
-                if use_dist:
-                    dist.broadcast_object_list(uid, src=0, device=torch.device("cpu"))   # every rank takes part (over gloo)
-                try:
-                    if uid[0] is None:
-                        raise RuntimeError("no RCCL id")
-                    comm = capi.Comm(device, world, rank, uid[0])
-                except Exception as exc:  # noqa: BLE001
-                    sys.stderr.write("rank %d: eea_comm_create failed (%r); torch.distributed collectives instead\n" % (rank, exc))
-                    ok = 0
-                if use_dist:
-                    flag = torch.tensor([ok], dtype=torch.int32)  # host tensor: gloo
-                    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                    ok = int(flag.item())
-                if ok:
-                    exchange_backend = "rccl through the C ABI (eea_comm_*)"
-                else:
-                    if comm is not None:
-                        comm.close()
-                    comm = None
-                    exchange_backend = "rccl through torch.distributed (eea_comm_create failed)"
-            else:
-                exchange_backend = "gloo, staged through the host (ranks share a GPU: plumbing run)"
-        if comm is None:
-            comm_local = capi.Comm(device, 1, 0, None)
-        cabi_comm = comm if comm is not None else (None if use_dist else comm_local)
+        nonlocal comm, xcomm, host_staged, exchange_backend
+        if not use_dist:
+            if args.force_exchange:   # single-rank RCCL communicator: the collectives run, over one rank
+                comm = capi.Comm(device, 1, 0, capi.comm_unique_id())
+                exchange_backend = "rccl through the C ABI (eea_comm_*), one rank"
+            xcomm = comm if comm is not None else capi.Comm(device, 1, 0, None)
+            return
+        if args.no_exchange:
+            return
+        if backend != "nccl":
+            exchange_backend = "gloo, staged through the host (ranks share a GPU: plumbing run)"
+            host_staged = True
+            return
+        # the C ABI's own RCCL communicator: rank 0 creates the id, torch.distributed only carries it.  If that fails on
+        # some rank, every rank falls back to torch.distributed's collectives (the run must not die with a secondary leg)
+        ok = 1
+        uid = [None]
+        if rank == 0:
+            try:
+                uid = [capi.comm_unique_id()]
+            except Exception as exc:  # noqa: BLE001
+                sys.stderr.write("rank 0: eea_comm_get_unique_id failed (%r)\n" % (exc,))
+        dist.broadcast_object_list(uid, src=0, device=torch.device("cpu"))   # every rank takes part (over gloo)
+        try:
+            if uid[0] is None:
+                raise RuntimeError("no RCCL id")
+            comm = capi.Comm(device, world, rank, uid[0])
+        except Exception as exc:  # noqa: BLE001
+            sys.stderr.write("rank %d: eea_comm_create failed (%r); torch.distributed collectives instead\n" % (rank, exc))
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32)  # host tensor: gloo
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()):
+            exchange_backend = "rccl through the C ABI (eea_comm_*)"
+            xcomm = comm
+        else:
+            if comm is not None:
+                comm.close()
+            comm = None
+            exchange_backend = "rccl through torch.distributed, staged (eea_comm_create failed)"
+            host_staged = True
 
-
-    state = {"i": 0, "every": 1}
-    # eea_batch_io structs are built once per distinct buffer set, a pass is one ctypes call
+    state = {"i": 0}
+    # eea_batch_io structs are built once per distinct buffer set, a pass is one ctypes call per group
     shard_calls = [eng.prepared_batch(a["B"], a["pose"], a["ut"], a["u0"], mem_cols=a["mem_cols"], n_mem=a["n_mem"],
                                       mem_stride=args.n_mem, stream=a["stream"]) for a in gargs]
     exch_calls = {}
@@ -453,50 +473,56 @@ def main():
     def one_pass(leg):
         i = state["i"]
         state["i"] = i + 1
-        slot = i % NB
         if leg == "shard":
             for call in shard_calls:
                 call()
             return
-        shared, src = None, None
-        in_c = (cabi_comm is not None) if leg == "consensus" else (comm is not None)  # events live in the C ABI
         if leg == "consensus":
-            # exchange number x is started after pass x * every; a pass consumes the consensus of exchange i - lag
-            # (every pass) or of the exchange BEFORE the most recent one (every n-th pass: the most recent may still
-            # be in flight, and a control kernel holds every SIMD, so waiting for it would stall the pass)
-            every = state["every"]
-            x = (i - args.consensus_lag) if every == 1 else (i // every - 1)
-            if x >= 0:
-                src = x % NB
-                if in_c:
-                    cabi_comm.wait(src, compute.cuda_stream)
-                else:
-                    compute.wait_event(ev_x[src])
-                shared = d_cbar[src]
-        if leg == "allgather" and i >= 2:
+            slot = i % NB
+            src = (i - args.consensus_lag) % NB if i >= args.consensus_lag else None
+            if not host_staged:
+                # two C-ABI calls per pass: the groups' control launches (each behind the exchange it consumes), then
+                # the exchange of this pass
+                call = exch_calls.get((slot, src))
+                if call is None:
+                    groups = [dict(B=a["B"], pose=a["pose"], ut=a["ut"], u0=a["u0"], mem_cols=a["mem_cols"],
+                                   n_mem=a["n_mem"], mem_stride=args.n_mem, stream=a["stream"],
+                                   ck_rec=d_arec[slot][gb[g]:gb[g + 1]],
+                                   ck_shared=None if src is None else d_rec[src],
+                                   ck_shared_parts=0 if src is None else 1) for g, a in enumerate(gargs)]
+                    call = exch_calls[(slot, src)] = xcomm.prepared_control_groups(eng, groups, -1 if src is None else src)
+                call()
+                exchange_records(slot)
+                return
+            for g, a in enumerate(gargs):
+                if src is not None:   # the sum record of pass i - lag is complete (on every rank)
+                    gstreams[g].wait_event(ev_x[src])
+                call = exch_calls.get((g, slot, src))
+                if call is None:
+                    call = exch_calls[(g, slot, src)] = eng.prepared_batch(
+                        a["B"], a["pose"], a["ut"], a["u0"], mem_cols=a["mem_cols"], n_mem=a["n_mem"],
+                        mem_stride=args.n_mem, stream=a["stream"], ck_rec=d_arec[slot][gb[g]:gb[g + 1]],
+                        ck_shared=None if src is None else d_rec[src], ck_shared_parts=0 if src is None else 1)
+                call()
+            exchange_records(slot)
+            return
+        # all-gather leg: one launch per pass that writes every agent's c_k, one ncclAllGather beside the next pass
+        slot = i % 3
+        in_c = comm is not None   # the completion events then live in the C ABI
+        if i >= 2:
             if in_c:
-                comm.wait((i - 2) % NB, compute.cuda_stream)  # the gather that read this slot's predecessor is done
+                comm.wait((i - 2) % 3, compute.cuda_stream)  # the gather that read this slot's predecessor is done
             else:
-                compute.wait_event(ev_x[(i - 2) % NB])
-        # c_k leaves the kernel only on the passes that feed an exchange (every n-th pass: into the buffer of that
-        # exchange, which its predecessor of NB exchanges ago has long finished reading)
-        feeds = leg != "consensus" or i % state["every"] == 0
-        if leg == "consensus" and state["every"] > 1:
-            slot = (i // state["every"]) % NB
-        key = (slot if feeds else None, None if shared is None else src)
-        call = exch_calls.get(key)
+                compute.wait_event(ev_ag[(i - 2) % 3])
+        call = exch_calls.get(("ag", slot))
         if call is None:
-            call = exch_calls[key] = eng.prepared_batch(B, d_pose, d_ut, d_u0, mem_cols=d_mem, n_mem=d_nmem,
-                                                        mem_stride=args.n_mem, ck=d_ck[slot] if feeds else None,
-                                                        ck_shared=shared, stream=compute.cuda_stream)
+            call = exch_calls[("ag", slot)] = eng.prepared_batch(B, d_pose, d_ut, d_u0, mem_cols=d_mem, n_mem=d_nmem,
+                                                                 mem_stride=args.n_mem, ck=d_ck[slot],
+                                                                 stream=compute.cuda_stream)
         call()
         if not in_c:
             ev_ck[slot].record(compute)
-        if leg == "consensus":
-            if feeds:   # exchange every n-th pass; the passes in between reuse an earlier consensus
-                exchange_consensus(slot, (i // state["every"]) % NB)
-        else:
-            exchange_allgather(slot, i)
+        exchange_allgather(slot, i)
 
     def host_barrier():
         """a barrier every rank leaves together, as a host collective (gloo): independent of the device library"""
@@ -516,11 +542,10 @@ def main():
             ev_join[g].record(gstreams[g])
             compute.wait_event(ev_join[g])
 
-    def timed(leg, steps, warmup, every=1, passes=None):
+    def timed(leg, steps, warmup, passes=None):
         """EXACTLY `steps` steps (of `passes` passes each) between barrier + synchronize on both sides; max over ranks"""
         Rl = R if passes is None else passes
         state["i"] = 0
-        state["every"] = every
         d_ut.zero_()      # on the compute stream ...
         fork_groups()     # ... and ordered before the first pass of every agent group
         # device spin-up, not part of any count: the shader clock needs a few tens of milliseconds of load to reach
@@ -740,20 +765,17 @@ def main():
         threading.Thread(target=watchdog, daemon=True).start()
         try:
             setup_exchange()
-            exchange = {"backend": exchange_backend, "consumer": "eea_batch_io::d_ck_shared (gradient uses c_bar)"}
+            exchange = {"backend": exchange_backend,
+                        "consumer": "eea_batch_io::d_ck_shared as a sum record, ck_shared_parts = 1 (the gradient uses c_bar)"}
             e_s, p_ms, q_s = timed("consensus", args.steps, args.warmup, passes=RX)
             exchange["consensus_allreduce"] = {
                 "host_enqueue_us_per_pass": 1e6 * q_s / (args.steps * RX),
                 "value": world * B * RX * args.steps / e_s, "unit": "optimisations/s", "ms_per_step": 1e3 * e_s / args.steps,
-                "pass_ms": p_ms, "lag_passes": args.consensus_lag,
-                "bytes_per_rank_per_pass": rs * (K2 + 1),
-                "note": "every pass: eea_ck_sum + ncclAllReduce(K^2+1 reals) + divide on a second stream; pass i uses the "
-                        "consensus of pass i - lag"}
-            e_s, p_ms, q_s = timed("consensus", args.steps, args.warmup, every=8, passes=RX)
-            exchange["consensus_allreduce_every_8_passes"] = {
-                "host_enqueue_us_per_pass": 1e6 * q_s / (args.steps * RX),
-                "value": world * B * RX * args.steps / e_s, "unit": "optimisations/s", "ms_per_step": 1e3 * e_s / args.steps,
-                "pass_ms": p_ms, "note": "the same exchange on every 8th pass; the passes in between use the last consensus"}
+                "pass_ms": p_ms, "pass_ms_vs_headline": p_ms / pass_ms, "lag_passes": args.consensus_lag,
+                "agent_groups": G, "bytes_per_rank_per_pass": rs * L,
+                "note": "every pass: the control kernels write per-agent sum records, one small launch on the exchange "
+                        "stream adds them (eea_ck_records_sum), one all-reduce of the record over the ranks (none with one "
+                        "rank); pass i divides the sums of pass i - lag by their count inside the kernel"}
             if use_dist or args.force_exchange:
                 d_all = [torch.empty((world * B, K2), dtype=tdt, device="cuda") for _ in range(2)]
                 e_s, p_ms, _ = timed("allgather", args.steps, args.warmup, passes=RX)
@@ -781,10 +803,10 @@ def main():
             out["grid_tile"] = grid_tile_leg()
         except Exception as exc:  # noqa: BLE001
             out["grid_tile"] = {"error": repr(exc)}
+    if xcomm is not None and xcomm is not comm:
+        xcomm.close()
     if comm is not None:
         comm.close()
-    if comm_local is not None:
-        comm_local.close()
     eng.close()
     if use_dist:
         dist.destroy_process_group()

@@ -40,7 +40,7 @@ class BatchIO(C.Structure):
                 ("d_n_mem", C.c_void_p), ("mem_stride", C.c_uint), ("d_u0", C.c_void_p),
                 ("d_traj", C.c_void_p), ("d_ck", C.c_void_p), ("d_edx", C.c_void_p),
                 ("d_bdx", C.c_void_p), ("d_rhot", C.c_void_p), ("d_status", C.c_void_p),
-                ("d_ck_shared", C.c_void_p)]
+                ("d_ck_shared", C.c_void_p), ("d_ck_rec", C.c_void_p), ("ck_shared_parts", C.c_uint)]
 
 
 class CollisionCfg(C.Structure):
@@ -98,6 +98,9 @@ def lib():
         L.eea_real_size.restype = C.c_size_t
         L.eea_time_step.restype = C.c_double
         L.eea_abi_version.restype = C.c_uint
+        L.eea_ck_record_len.restype = C.c_uint
+        L.eea_ck_record_len.argtypes = [C.c_void_p]
+        L.eea_ck_records_sum.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
         for name in ("eea_steps", "eea_num_modes", "eea_real_size", "eea_time_step", "eea_destroy"):
             getattr(L, name).argtypes = [C.c_void_p]
         L.eea_destroy.restype = None
@@ -133,6 +136,11 @@ def lib():
         L.eea_ck_sum.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
         L.eea_comm_allgather_ck.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
         L.eea_comm_consensus_ck.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.eea_comm_allreduce_sum_async.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_int]
+        L.eea_comm_records_exchange_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p,
+                                                      C.c_void_p, C.c_uint, C.c_int]
+        L.eea_comm_wait.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.eea_comm_control_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.eea_comm_allreduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
         L.eea_comm_consensus_ck_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.eea_comm_allgather_ck_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -275,9 +283,11 @@ class Engine:
         return out, nx.value, ny.value
 
     def control_batch(self, B, pose, ut, u0, mem_cols=None, n_mem=None, mem_stride=0, traj=None,
-                      ck=None, edx=None, bdx=None, rhot=None, status=None, stream=None, ck_shared=None):
+                      ck=None, edx=None, bdx=None, rhot=None, status=None, stream=None, ck_shared=None,
+                      ck_rec=None, ck_shared_parts=0):
         io = BatchIO()
         io.d_ck_shared = _ptr(ck_shared)
+        io.d_ck_rec, io.ck_shared_parts = _ptr(ck_rec), ck_shared_parts
         io.d_pose, io.d_ut, io.d_u0 = _ptr(pose), _ptr(ut), _ptr(u0)
         io.d_mem_cols, io.d_n_mem, io.mem_stride = _ptr(mem_cols), _ptr(n_mem), mem_stride
         io.d_traj, io.d_ck, io.d_edx, io.d_bdx = _ptr(traj), _ptr(ck), _ptr(edx), _ptr(bdx)
@@ -285,7 +295,7 @@ class Engine:
         check(lib().eea_control_batch(self.h, B, C.byref(io), C.c_void_p(stream or 0)))
 
     def prepared_batch(self, B, pose, ut, u0, mem_cols=None, n_mem=None, mem_stride=0, ck=None, ck_shared=None,
-                       stream=None):
+                       stream=None, ck_rec=None, ck_shared_parts=0):
         """A callable that issues eea_control_batch with these (fixed) device buffers: one ctypes call per pass, the
         eea_batch_io is built once (a pass of 4096 agents takes ~30 us on the device; building the struct from
         tensors every pass costs about as much on the host)."""
@@ -294,14 +304,24 @@ class Engine:
         io.d_pose, io.d_ut, io.d_u0 = _ptr(pose), _ptr(ut), _ptr(u0)
         io.d_mem_cols, io.d_n_mem, io.mem_stride = _ptr(mem_cols), _ptr(n_mem), mem_stride
         io.d_ck = _ptr(ck)
+        io.d_ck_rec, io.ck_shared_parts = _ptr(ck_rec), ck_shared_parts
         fn, h, ref, st = lib().eea_control_batch, self.h, C.byref(io), C.c_void_p(stream or 0)
-        keep = (io, pose, ut, u0, mem_cols, n_mem, ck, ck_shared)
+        keep = (io, pose, ut, u0, mem_cols, n_mem, ck, ck_shared, ck_rec)
 
         def call(_keep=keep):
             rc = fn(h, B, ref, st)
             if rc != 0:
                 check(rc)
         return call
+
+    @property
+    def ck_record_len(self):
+        """reals per sum record (eea_batch_io::d_ck_rec): K^2 + 1 rounded up to even"""
+        return int(lib().eea_ck_record_len(self.h))
+
+    def ck_records_sum(self, B, recs, out, stream=None):
+        """out[record_len] = sum of the B per-agent records (one launch, fixed order)"""
+        check(lib().eea_ck_records_sum(self.h, B, _ptr(recs), _ptr(out), C.c_void_p(stream or 0)))
 
     def ck_sum(self, B, ck, sums, stream=None):
         """sums[:K2] = sum over the B agents of ck, sums[K2] = B (device tensors)"""
@@ -481,6 +501,59 @@ class Comm:
 
     def wait(self, slot, stream=None):
         check(lib().eea_comm_wait(self.h, slot, C.c_void_p(stream or 0)))
+
+    def records_exchange_async(self, eng, B_local, ck_rec, out_sum, group_streams, slot):
+        """eea_comm_records_exchange_async: record sum + all-reduce on the communicator's stream, after every group stream"""
+        arr = (C.c_void_p * len(group_streams))(*[C.c_void_p(s or 0) for s in group_streams])
+        check(lib().eea_comm_records_exchange_async(eng.h, self.h, B_local, _ptr(ck_rec), _ptr(out_sum), arr,
+                                                    len(group_streams), slot))
+
+    def prepared_records_exchange(self, eng, B_local, ck_rec, out_sum, group_streams, slot):
+        """the same as a callable with the argument marshalling done once (bench.py's per-pass call)"""
+        arr = (C.c_void_p * len(group_streams))(*[C.c_void_p(s or 0) for s in group_streams])
+        fn, args = lib().eea_comm_records_exchange_async, (eng.h, self.h, B_local, _ptr(ck_rec), _ptr(out_sum), arr,
+                                                           len(group_streams), slot)
+        keep = (ck_rec, out_sum, arr)
+
+        def call(_keep=keep):
+            rc = fn(*args)
+            if rc != 0:
+                check(rc)
+        return call
+
+    def prepared_control_groups(self, eng, groups, wait_slot):
+        """eea_comm_control_groups as a callable: groups = [dict(B, pose, ut, u0, stream, mem_cols, n_mem, mem_stride, ck,
+        ck_rec, ck_shared, ck_shared_parts)]; the eea_batch_io array is built once"""
+        n = len(groups)
+        ios = (BatchIO * n)()
+        Bs = (C.c_uint * n)(*[g["B"] for g in groups])
+        streams = (C.c_void_p * n)(*[C.c_void_p(g.get("stream") or 0) for g in groups])
+        keep = [ios, Bs, streams]
+        for io, g in zip(ios, groups):
+            io.d_pose, io.d_ut, io.d_u0 = _ptr(g["pose"]), _ptr(g["ut"]), _ptr(g["u0"])
+            io.d_mem_cols, io.d_n_mem, io.mem_stride = _ptr(g.get("mem_cols")), _ptr(g.get("n_mem")), g.get("mem_stride", 0)
+            io.d_ck, io.d_ck_rec = _ptr(g.get("ck")), _ptr(g.get("ck_rec"))
+            io.d_ck_shared, io.ck_shared_parts = _ptr(g.get("ck_shared")), g.get("ck_shared_parts", 0)
+            keep.append(dict(g))
+        fn, args = lib().eea_comm_control_groups, (eng.h, self.h, n, Bs, ios, streams, wait_slot)
+
+        def call(_keep=keep):
+            rc = fn(*args)
+            if rc != 0:
+                check(rc)
+        return call
+
+    def prepared_wait(self, slot, stream):
+        fn, args = lib().eea_comm_wait, (self.h, slot, C.c_void_p(stream or 0))
+
+        def call():
+            rc = fn(*args)
+            if rc != 0:
+                check(rc)
+        return call
+
+    def allreduce_sum_async(self, eng, buf, n, compute_stream, slot):
+        check(lib().eea_comm_allreduce_sum_async(eng.h, self.h, _ptr(buf), n, C.c_void_p(compute_stream or 0), slot))
 
     def allreduce_sum(self, eng, buf, n, stream=None):
         check(lib().eea_comm_allreduce_sum(eng.h, self.h, _ptr(buf), n, C.c_void_p(stream or 0)))

@@ -270,7 +270,11 @@ eea_status async_begin(eea_comm* c, void* compute_stream, int slot)
   if (c == nullptr || slot < 0 || slot >= EEA_COMM_SLOTS) return fail(EEA_ERR_INVALID_ARGUMENT, "bad communicator / slot");
   EEA_HIP(hipSetDevice(c->device));
   if (c->xstream == nullptr) {
-    EEA_HIP(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+    // highest priority: the exchange steps are a handful of wavefronts that must get the first execution slots a
+    // finishing control kernel frees, not queue behind the next one's 2048 (measured: tools/ck_cost.py)
+    int least = 0, greatest = 0;
+    EEA_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    EEA_HIP(hipStreamCreateWithPriority(&c->xstream, hipStreamNonBlocking, greatest));
     EEA_HIP(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
   }
   if (c->ev_done[slot] == nullptr) EEA_HIP(hipEventCreateWithFlags(&c->ev_done[slot], hipEventDisableTiming));
@@ -300,6 +304,54 @@ eea_status eea_comm_allgather_ck_async(eea_engine* e, eea_comm* c, unsigned B_lo
   eea_status st = async_begin(c, compute_stream, slot);
   if (st != EEA_OK) return st;
   st = eea_comm_allgather_ck(e, c, B_local, d_ck_local, d_ck_all, c->xstream);
+  if (st != EEA_OK) return st;
+  EEA_HIP(hipEventRecord(c->ev_done[slot], c->xstream));
+  return EEA_OK;
+}
+
+eea_status eea_comm_allreduce_sum_async(eea_engine* e, eea_comm* c, void* d_buf, unsigned n, void* compute_stream,
+                                        int slot)
+{
+  eea_status st = async_begin(c, compute_stream, slot);
+  if (st != EEA_OK) return st;
+  st = eea_comm_allreduce_sum(e, c, d_buf, n, c->xstream);
+  if (st != EEA_OK) return st;
+  EEA_HIP(hipEventRecord(c->ev_done[slot], c->xstream));
+  return EEA_OK;
+}
+
+eea_status eea_comm_control_groups(eea_engine* e, eea_comm* c, unsigned n_groups, const unsigned* B,
+                                   const eea_batch_io* ios, void* const* group_streams, int wait_slot)
+{
+  if (e == nullptr || c == nullptr || B == nullptr || ios == nullptr || group_streams == nullptr) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  }
+  if (wait_slot >= EEA_COMM_SLOTS) return fail(EEA_ERR_INVALID_ARGUMENT, "bad slot");
+  for (unsigned g = 0; g < n_groups; ++g) {
+    if (B[g] == 0) continue;
+    hipStream_t s = static_cast<hipStream_t>(group_streams[g]);
+    if (wait_slot >= 0 && c->ev_done[wait_slot] != nullptr) EEA_HIP(hipStreamWaitEvent(s, c->ev_done[wait_slot], 0));
+    const eea_status st = eea_control_batch(e, B[g], &ios[g], group_streams[g]);
+    if (st != EEA_OK) return st;
+  }
+  return EEA_OK;
+}
+
+eea_status eea_comm_records_exchange_async(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_rec,
+                                           void* d_sum, void* const* group_streams, unsigned n_streams, int slot)
+{
+  if (e == nullptr || d_ck_rec == nullptr || d_sum == nullptr || (n_streams > 0 && group_streams == nullptr)) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  }
+  eea_status st = async_begin(c, n_streams > 0 ? group_streams[0] : nullptr, slot);
+  if (st != EEA_OK) return st;
+  for (unsigned g = 1; g < n_streams; ++g) {  // ... and after everything enqueued on the other group streams
+    EEA_HIP(hipEventRecord(c->ev_in, static_cast<hipStream_t>(group_streams[g])));
+    EEA_HIP(hipStreamWaitEvent(c->xstream, c->ev_in, 0));
+  }
+  st = eea_ck_records_sum(e, B_local, d_ck_rec, d_sum, c->xstream);
+  if (st != EEA_OK) return st;
+  st = eea_comm_allreduce_sum(e, c, d_sum, eea_ck_record_len(e), c->xstream);
   if (st != EEA_OK) return st;
   EEA_HIP(hipEventRecord(c->ev_done[slot], c->xstream));
   return EEA_OK;

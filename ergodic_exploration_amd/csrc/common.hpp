@@ -12,6 +12,8 @@ namespace eea
 constexpr int kBlock = 256;    // threads per workgroup: 4 wavefronts of 64 lanes
 constexpr int kWave = 64;
 constexpr int kMaxBasis = 32;  // K <= 32 (K^2 <= 1024 modes)
+constexpr unsigned kSumGroup = 64;  // agents per first-level group of the in-kernel c_k sums
+__host__ __device__ constexpr int ck_record_len(int K2) { return (K2 + 2) & ~1; }
 
 // numerics.hpp:59 of the reference
 constexpr double kPi = 3.14159265358979323846;
@@ -45,7 +47,12 @@ struct ControlParams
   R* u0;
   R* traj;
   R* ck;
-  const R* ck_shared;  // [K^2] optional: consensus c_k used in place of the agent's own (one per launch)
+  const R* ck_shared;  // [K^2] optional: consensus c_k used in place of the agent's own (one per launch); with
+                       // ck_shared_parts > 0: that many sum records of rec_len reals (c_bar = sum of sums / sum of counts)
+  int ck_shared_parts;
+  int rec_len;         // K^2 + 1 rounded up to even: [sums over agents of c_k, number of agents, pad]
+  // per-agent sum records (eea_batch_io::d_ck_rec): [B][rec_len] = [c_k, 1 (0 for a rejected agent), pad]; optional
+  R* ck_rec;
   R* edx;
   R* bdx;
   R* rhot;
@@ -73,7 +80,12 @@ bool control_wave_eligible(const ControlParams<R>& p, bool rollout_only);
 template <typename R>
 hipError_t launch_control_wave(const ControlParams<R>& p, unsigned B, int model, bool rollout_only,
                                hipStream_t stream);
-
+// sum of B per-agent records (ControlParams::ck_rec) in agent order: one launch, groups of kSumGroup agents per
+// workgroup, the last workgroup to arrive adds the group records in group order (deterministic).  d_ws: >=
+// ck_sum_ws_elems(B, K2) reals, d_ctr: one ticket (zero before the first use; it resets itself)
+inline size_t ck_sum_ws_elems(unsigned B, int K2) { return static_cast<size_t>((B + kSumGroup - 1) / kSumGroup) * ck_record_len(K2); }
+template <typename R>
+hipError_t launch_ck_records_sum(const R* d_rec, unsigned B, int K2, R* d_ws, unsigned* d_ctr, R* d_out, hipStream_t stream);
 
 // ---- phi_k path ----------------------------------------------------------------------
 // Gaussians of a target passed to the fill kernel by value: [mean x, mean y (Fourier frame), cov_inv xx, yy]
@@ -303,6 +315,32 @@ __device__ __forceinline__ R wrap_pi(R rad)
   rad = (rad + pi) - q * R(2) * pi;
   if (rad < R(0)) rad += R(2) * pi;
   return rad - pi;
+}
+
+// consensus c_k of mode m (eea_batch_io::d_ck_shared): the K^2 values themselves, or -- ck_shared_parts > 0 -- the
+// sum of that many sum records divided by the sum of their agent counts (element K^2 of a record)
+template <typename R>
+__device__ __forceinline__ R shared_ck_value(const ControlParams<R>& p, int m, int K2)
+{
+  if (p.ck_shared_parts <= 0) return p.ck_shared[m];
+  R s = R(0), n = R(0);
+  for (int i = 0; i < p.ck_shared_parts; ++i) {
+    s += p.ck_shared[static_cast<size_t>(i) * p.rec_len + m];
+    n += p.ck_shared[static_cast<size_t>(i) * p.rec_len + K2];
+  }
+  return s / n;
+}
+
+// agent-scope (sc1: write-through / L1-bypassing) accesses for data that crosses XCDs inside one launch
+template <typename R>
+__device__ __forceinline__ void store_agent(R* q, R v)
+{
+  __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename R>
+__device__ __forceinline__ R load_agent(const R* q)
+{
+  return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // std::clamp semantics (NaN passes through), ergodic_control.hpp:447-449

@@ -333,6 +333,9 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
         if (any_bad) {
           // the reference throws out of rk4_.solve; nothing else of this agent is touched
           if (tid == 0 && p.status != nullptr) p.status[b] = 2;  // EEA_ERR_INVALID_TWIST
+          if (p.ck_rec != nullptr && !rollout_only) {  // an all-zero sum record: the agent does not count
+            for (int m = tid; m < p.rec_len; m += BLK) p.ck_rec[static_cast<size_t>(b) * p.rec_len + m] = R(0);
+          }
           if (tid == 0 && p.done != nullptr && b == 0) {
             __hip_atomic_store(p.done, p.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
           }
@@ -648,12 +651,16 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
       }
       R c = invN * s;
       if (p.ck != nullptr) p.ck[static_cast<size_t>(b) * K2 + m] = c;
+      if (p.ck_rec != nullptr) p.ck_rec[static_cast<size_t>(b) * p.rec_len + m] = c;  // eea_batch_io::d_ck_rec
       // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
-      if (p.ck_shared != nullptr) c = p.ck_shared[m];
+      if (p.ck_shared != nullptr) c = shared_ck_value(p, m, K2);
       // fourier_diff = lamdak % (ck - phik)  (ergodic_control.hpp:422)
       const R lam = (m == tid) ? lam_m : p.lamdak[m];
       const R phi = (m == tid) ? phi_m : p.phik[m];
       s_D[m] = lam * (c - phi);
+    }
+    if (p.ck_rec != nullptr) {  // [c_k, 1 (this agent counts), pad]
+      for (int m = K2 + tid; m < p.rec_len; m += BLK) p.ck_rec[static_cast<size_t>(b) * p.rec_len + m] = (m == K2) ? R(1) : R(0);
     }
     __syncthreads();
     EEA_STAMP(7);

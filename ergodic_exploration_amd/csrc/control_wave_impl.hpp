@@ -243,8 +243,17 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
     }
   }
   const R x0 = pose[0], y0 = pose[1], th0 = pose[2];
+  // record elements per lane of an agent's sum record (K^2 + 1 reals rounded up to even)
+  constexpr int kRecRounds = (ck_record_len((KC == 16 ? 16 : KC) * (KC == 16 ? 16 : KC)) + kWave - 1) / kWave;
   if (__any(bad)) {
     // the reference throws out of rk4_.solve; nothing else of this agent is touched
+    if (p.ck_rec != nullptr && !rollout_only) {  // it does not count in the sum of the records: all-zero record
+#pragma unroll
+      for (int r = 0; r < kRecRounds; ++r) {
+        const int e = kWave * r + lane;
+        if (e < p.rec_len) p.ck_rec[static_cast<size_t>(b) * p.rec_len + e] = R(0);
+      }
+    }
     if (lane == 0 && p.status != nullptr) p.status[b] = 2;  // EEA_ERR_INVALID_TWIST
     if (lane == 0 && p.done != nullptr && b == 0) {
       __hip_atomic_store(p.done, p.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -762,6 +771,22 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
 
   if constexpr (!kBlock4) load_lam_phi();
   EEA_WSTAMP(5);
+  // the agent's sum record (eea_batch_io::d_ck_rec): c_k is in s_D [0, K^2) (before D takes the place), element K^2 = 1
+  // (this agent counts), pad 0; read back one element per lane: coalesced stores to p.ck_rec [b]
+  auto publish_record = [&]() {
+    if (lane == 0) {
+      s_D[K2] = R(1);
+      if (p.rec_len > K2 + 1) s_D[K2 + 1] = R(0);
+    }
+    lds_fence();
+    R* const rec = p.ck_rec + static_cast<size_t>(b) * p.rec_len;
+#pragma unroll
+    for (int r = 0; r < kRecRounds; ++r) {
+      const int e = kWave * r + lane;
+      if (e < p.rec_len) rec[e] = s_D[e];
+    }
+    lds_fence();
+  };
   // D = lambda (c - phi), fourier_diff of ergodic_control.hpp:422, in both orientations
   if constexpr (kBlock4) {
     // every accumulator holds, in the four blocks of its row of 16 lanes, four partial sums over different point
@@ -793,11 +818,18 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
       lamv[t] = p.lamdak[idx[t]];
       phiv[t] = p.phik[idx[t]];
       if (p.ck != nullptr && okv[t]) p.ck[static_cast<size_t>(b) * K2 + idx[t]] = cv[t];
-      // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
-      if (p.ck_shared != nullptr) cv[t] = p.ck_shared[idx[t]];
+    }
+    if (p.ck_rec != nullptr) {  // wavefront-uniform: this agent's record [c_k, 1, pad] through LDS, coalesced
+#pragma unroll
+      for (int t = 0; t < TS; ++t) {
+        if (okv[t]) s_D[idx[t]] = cv[t];
+      }
+      publish_record();
     }
 #pragma unroll
     for (int t = 0; t < TS; ++t) {
+      // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
+      if (p.ck_shared != nullptr) cv[t] = shared_ck_value(p, idx[t], K2);
       if (okv[t]) s_D[idx[t]] = lamv[t] * (cv[t] - phiv[t]);
     }
     lds_fence();
@@ -812,10 +844,23 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
         const int k1 = 16 * (t / NT) + M::row(lane, r);
         const int k2 = 16 * (t % NT) + mi;
         if (k1 < K && k2 < K) {
-          R c = invN * (*accs[t])[r];
+          const R c = invN * (*accs[t])[r];
           if (p.ck != nullptr) p.ck[static_cast<size_t>(b) * K2 + k2 * K + k1] = c;
+          if (p.ck_rec != nullptr) s_D[k2 * K + k1] = c;
+        }
+      }
+    }
+    if (p.ck_rec != nullptr) publish_record();  // wavefront-uniform
+#pragma unroll
+    for (int t = 0; t < NT * NT; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k1 = 16 * (t / NT) + M::row(lane, r);
+        const int k2 = 16 * (t % NT) + mi;
+        if (k1 < K && k2 < K) {
+          R c = invN * (*accs[t])[r];
           // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
-          if (p.ck_shared != nullptr) c = p.ck_shared[k2 * K + k1];
+          if (p.ck_shared != nullptr) c = shared_ck_value(p, k2 * K + k1, K2);
           s_D[k2 * K + k1] = lam[t][r] * (c - phi[t][r]);
         }
       }

@@ -101,6 +101,15 @@ struct eea_engine
   hipEvent_t ev_done = nullptr;  // completion of a rebuild: polled (a few microseconds earlier than a blocking wait)
   DevBuf d_lut, d_raw, d_occ;  // occupancy targets: decode table, un-normalised sums, staged cells
 
+  // workspaces of eea_ck_records_sum (group records + one ticket), one per distinct output buffer: concurrent calls
+  // on several streams must not share a ticket
+  struct SumWs
+  {
+    const void* key = nullptr;
+    DevBuf ws, ctr;
+  };
+  std::vector<SumWs> sum_ws;
+
   // single-agent path
   hipStream_t stream1 = nullptr;
   Mailbox* h_mail = nullptr;
@@ -380,6 +389,31 @@ void fill_params(const eea_engine* e, eea::ControlParams<R>& p)
   p.lamdak = static_cast<const R*>(e->d_lamdak.p);
 }
 
+// workspace of the sum written to `key` for up to B records (allocated on first use: one synchronisation, then none)
+template <typename R>
+eea_status sum_workspace(eea_engine* e, const void* key, unsigned B, eea_engine::SumWs** out)
+{
+  eea_engine::SumWs* w = nullptr;
+  for (auto& cand : e->sum_ws) {
+    if (cand.key == key) w = &cand;
+  }
+  if (w == nullptr) {
+    e->sum_ws.emplace_back();
+    w = &e->sum_ws.back();
+    w->key = key;
+  }
+  const size_t need_ws = sizeof(R) * eea::ck_sum_ws_elems(B, e->K2);
+  if (need_ws > w->ws.cap || w->ctr.cap == 0) {
+    EEA_HIP(hipDeviceSynchronize());  // an earlier launch may still use the buffer about to be replaced
+    EEA_HIP(w->ws.reserve(need_ws));
+    EEA_HIP(w->ctr.reserve(sizeof(unsigned)));
+    EEA_HIP(hipMemset(w->ctr.p, 0, sizeof(unsigned)));  // the ticket resets itself from here on
+    EEA_HIP(hipDeviceSynchronize());
+  }
+  *out = w;
+  return EEA_OK;
+}
+
 template <typename R>
 eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io, bool rollout_only,
                               hipStream_t s, long long* d_stamps = nullptr)
@@ -395,6 +429,8 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
   p.traj = static_cast<R*>(io->d_traj);
   p.ck = static_cast<R*>(io->d_ck);
   p.ck_shared = static_cast<const R*>(io->d_ck_shared);
+  p.ck_shared_parts = io->d_ck_shared != nullptr ? static_cast<int>(io->ck_shared_parts) : 0;
+  p.rec_len = eea::ck_record_len(e->K2);
   p.edx = static_cast<R*>(io->d_edx);
   p.bdx = static_cast<R*>(io->d_bdx);
   p.rhot = static_cast<R*>(io->d_rhot);
@@ -408,6 +444,7 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
   // wavefronts per agent; batches take the throughput kernel unless EEA_OPT_CONTROL_KERNEL says otherwise
   const bool use_wave = eea::option(EEA_OPT_CONTROL_KERNEL) == 0 && e->mail_done == nullptr &&
                         eea::control_wave_eligible<R>(p, rollout_only);
+  p.ck_rec = rollout_only ? nullptr : static_cast<R*>(io->d_ck_rec);
   if (use_wave) {
     EEA_HIP(eea::launch_control_wave<R>(p, B, e->cfg.model, rollout_only, s));
     return EEA_OK;
@@ -567,6 +604,10 @@ void eea_destroy(eea_engine* e)
                      &e->d_work, &e->d_gauss, &e->d_sum, &e->d_ut1, &e->d_traj1, &e->d_mem1,
                      &e->d_lut, &e->d_raw, &e->d_occ };
   for (DevBuf* b : bufs) b->release();
+  for (auto& w : e->sum_ws) {
+    w.ws.release();
+    w.ctr.release();
+  }
   if (e->ev_done) (void)hipEventDestroy(e->ev_done);
   if (e->h_mail) (void)hipHostFree(e->h_mail);
   if (e->h_stage) (void)hipHostFree(e->h_stage);
@@ -576,6 +617,7 @@ void eea_destroy(eea_engine* e)
 unsigned eea_steps(const eea_engine* e) { return e ? static_cast<unsigned>(e->T) : 0u; }
 unsigned eea_num_modes(const eea_engine* e) { return e ? static_cast<unsigned>(e->K2) : 0u; }
 size_t eea_real_size(const eea_engine* e) { return e ? e->rs : 0; }
+unsigned eea_ck_record_len(const eea_engine* e) { return e ? static_cast<unsigned>(eea::ck_record_len(e->K2)) : 0u; }
 double eea_time_step(const eea_engine* e) { return e ? e->cfg.dt : 0.0; }
 
 eea_status eea_set_target_gaussians(eea_engine* e, unsigned n, const double* mu, const double* sigma)
@@ -831,6 +873,26 @@ eea_status eea_control_batch(eea_engine* e, unsigned B, const eea_batch_io* io, 
   hipStream_t s = static_cast<hipStream_t>(stream);
   return e->f32 ? control_batch_impl<float>(e, B, io, false, s)
                 : control_batch_impl<double>(e, B, io, false, s);
+}
+
+eea_status eea_ck_records_sum(eea_engine* e, unsigned B, const void* d_ck_rec, void* d_sum, void* stream)
+{
+  if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (d_ck_rec == nullptr || d_sum == nullptr || B == 0) return fail(EEA_ERR_INVALID_ARGUMENT, "d_ck_rec, d_sum and B > 0 are required");
+  eea_status st = use_device(e);
+  if (st != EEA_OK) return st;
+  eea_engine::SumWs* w = nullptr;
+  st = e->f32 ? sum_workspace<float>(e, d_sum, B, &w) : sum_workspace<double>(e, d_sum, B, &w);
+  if (st != EEA_OK) return st;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (e->f32) {
+    EEA_HIP(eea::launch_ck_records_sum<float>(static_cast<const float*>(d_ck_rec), B, e->K2, static_cast<float*>(w->ws.p),
+                                              static_cast<unsigned*>(w->ctr.p), static_cast<float*>(d_sum), s));
+  } else {
+    EEA_HIP(eea::launch_ck_records_sum<double>(static_cast<const double*>(d_ck_rec), B, e->K2, static_cast<double*>(w->ws.p),
+                                               static_cast<unsigned*>(w->ctr.p), static_cast<double*>(d_sum), s));
+  }
+  return EEA_OK;
 }
 
 eea_status eea_rollout_batch(eea_engine* e, unsigned B, const void* d_pose, const void* d_ut,

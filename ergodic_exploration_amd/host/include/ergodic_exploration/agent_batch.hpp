@@ -52,13 +52,19 @@ public:
     alloc(d_ut_, sizeof(double) * 3 * steps_ * n_);
     alloc(d_u0_, sizeof(double) * 3 * n_);
     alloc(d_ck_, sizeof(double) * modes_ * n_);
-    alloc(d_cbar_, sizeof(double) * modes_);
+    rec_len_ = eea_ck_record_len(e);
+    alloc(d_agent_recs_, sizeof(double) * n_ * rec_len_);  // per-agent sum records of the current step
+    alloc(d_recs_, sizeof(double) * 2 * rec_len_);         // [2 steps][sum record of all agents of all ranks]
     hip_check(hipMemset(d_ut_.get(), 0, sizeof(double) * 3 * steps_ * n_));  // ut_ starts at zero (:201)
     for (unsigned int g = 0; g < groups_; ++g) {
       hipStream_t s = nullptr;
       hip_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
       streams_.push_back(s);
+      hipEvent_t ev = nullptr;
+      hip_check(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      ev_group_.push_back(ev);
     }
+    hip_check(hipEventCreateWithFlags(&ev_exchange_, hipEventDisableTiming));
     if (comm_ == nullptr) {  // local communicator: the consensus is the mean over this rank's agents
       eea_comm* c = nullptr;
       throw_on_error(eea_comm_create(device_ordinal(), 1, 0, nullptr, &c));
@@ -72,6 +78,8 @@ public:
       (void)hipStreamSynchronize(s);
       (void)hipStreamDestroy(s);
     }
+    for (hipEvent_t ev : ev_group_) (void)hipEventDestroy(ev);
+    if (ev_exchange_) (void)hipEventDestroy(ev_exchange_);
   }
   AgentBatch(const AgentBatch&) = delete;
   AgentBatch& operator=(const AgentBatch&) = delete;
@@ -96,27 +104,57 @@ public:
     hip_check(hipMemcpy(d_pose_.get(), poses.memptr(), sizeof(double) * 3 * n_, hipMemcpyHostToDevice));
   }
   // One receding-horizon optimisation of every agent (ErgodicControl::control per agent).  consensus: the
-  // gradient uses the mean c_k of ALL agents of all ranks from the previous step (decentralised ergodic control;
-  // one all-reduce of K^2 + 1 reals per step on its own ordering, overlapped with nothing here: latency ~ 10 us)
+  // gradient uses the mean c_k of ALL agents of all ranks from the previous step (decentralised ergodic control).
+  // The control kernels leave per-agent sum records (eea_batch_io::d_ck_rec); ONE small launch adds them
+  // (eea_ck_records_sum), ONE collective adds the ranks' records (nothing with one rank) and the next step's
+  // kernels divide sum by count themselves (ck_shared_parts = 1).  Everything is stream-ordered: no host
+  // synchronisation, and every stream that reads the record waits for the event behind the exchange.
   void control(bool consensus = false)
   {
-    const void* shared = (consensus && have_cbar_) ? d_cbar_.get() : nullptr;
+    double* const rec_now = static_cast<double*>(d_recs_.get()) + static_cast<size_t>(step_ & 1u) * rec_len_;
+    const double* const rec_prev = static_cast<const double*>(d_recs_.get()) + static_cast<size_t>((step_ + 1u) & 1u) * rec_len_;
+    const bool shared = consensus && have_records_;
     for (unsigned int g = 0; g < groups_; ++g) {
       const unsigned int first = (n_ * g) / groups_, last = (n_ * (g + 1)) / groups_;
       if (last == first) continue;
+      // the record this launch reads was completed (and all-reduced) on streams_[0]
+      if (shared && g > 0) hip_check(hipStreamWaitEvent(streams_[g], ev_exchange_, 0));
       eea_batch_io io{};
       io.d_pose = static_cast<const double*>(d_pose_.get()) + 3 * first;
       io.d_ut = static_cast<double*>(d_ut_.get()) + static_cast<size_t>(3) * steps_ * first;
       io.d_u0 = static_cast<double*>(d_u0_.get()) + 3 * first;
       io.d_ck = static_cast<double*>(d_ck_.get()) + static_cast<size_t>(modes_) * first;
-      io.d_ck_shared = shared;
+      if (shared) {
+        io.d_ck_shared = rec_prev;
+        io.ck_shared_parts = 1;
+      }
+      if (consensus) io.d_ck_rec = static_cast<double*>(d_agent_recs_.get()) + static_cast<size_t>(rec_len_) * first;
       throw_on_error(eea_control_batch(engine_.get(), last - first, &io, streams_[g]));
     }
     if (consensus) {
-      sync();  // every group's c_k is complete
-      throw_on_error(eea_comm_consensus_ck(engine_.get(), comm_, n_, d_ck_.get(), d_cbar_.get(), streams_[0]));
-      have_cbar_ = true;
+      // streams_[0] joins the other groups, then the sum and the exchange; the event orders the next step's readers
+      for (unsigned int g = 1; g < groups_; ++g) {
+        hip_check(hipEventRecord(ev_group_[g], streams_[g]));
+        hip_check(hipStreamWaitEvent(streams_[0], ev_group_[g], 0));
+      }
+      throw_on_error(eea_ck_records_sum(engine_.get(), n_, d_agent_recs_.get(), rec_now, streams_[0]));
+      throw_on_error(eea_comm_allreduce_sum(engine_.get(), comm_, rec_now, rec_len_, streams_[0]));
+      hip_check(hipEventRecord(ev_exchange_, streams_[0]));
+      have_records_ = true;
+      ++step_;
     }
+  }
+  // mean c_k of all agents of all ranks after the last control(true): K^2 values (for inspection / tests)
+  vec consensusTrajCoeff()
+  {
+    if (!have_records_) throw std::logic_error("no consensus step yet");
+    sync();
+    std::vector<double> h(rec_len_);
+    const double* const rec = static_cast<const double*>(d_recs_.get()) + static_cast<size_t>((step_ + 1u) & 1u) * rec_len_;
+    hip_check(hipMemcpy(h.data(), rec, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    vec c(modes_);
+    for (unsigned int m = 0; m < modes_; ++m) c(m) = h[m] / h[modes_];
+    return c;
   }
   // first twists of the updated control signals, 3 x n_agents
   mat controls()
@@ -160,8 +198,11 @@ private:
   std::shared_ptr<eea_comm> own_comm_;
   unsigned int groups_;
   std::shared_ptr<eea_engine> engine_;
-  Dev d_pose_, d_ut_, d_u0_, d_ck_, d_cbar_;
-  bool have_cbar_ = false;
+  Dev d_pose_, d_ut_, d_u0_, d_ck_, d_agent_recs_, d_recs_;
+  unsigned int rec_len_ = 0, step_ = 0;
+  bool have_records_ = false;
   std::vector<hipStream_t> streams_;
+  std::vector<hipEvent_t> ev_group_;
+  hipEvent_t ev_exchange_ = nullptr;
 };
 }  // namespace ergodic_exploration

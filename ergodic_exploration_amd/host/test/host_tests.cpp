@@ -4,6 +4,7 @@
 // the same inputs, expected values and tolerances.  `host_tests gpu` adds the device-backed
 // classes: RungeKutta::solve / Basis / Target against the host helpers, and ErgodicControl
 // against the end-to-end control() outputs of the reference recorded in SURVEY.md 8(c).
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -434,6 +435,37 @@ static void test_agent_batch()
   double diff = 0.0;
   for (unsigned int a = 0; a < N; ++a) diff += std::fabs(u_cons(0, a) - u_own(0, a)) + std::fabs(u_cons(2, a) - u_own(2, a));
   CHECK(diff > 1e-6);
+  // the consensus the records hold is the mean of the agents' own c_k of the last step
+  {
+    const vec cbar = batch.consensusTrajCoeff();
+    const mat ck2 = batch.gatherTrajCoeff();
+    double worst = 0.0;
+    for (unsigned int m = 0; m < 100; ++m) {
+      double mean = 0.0;
+      for (unsigned int a = 0; a < N; ++a) mean += ck2(m, a);
+      worst = std::max(worst, std::fabs(cbar(m) - mean / N));
+    }
+    CHECK(worst < 1e-14);
+  }
+  // Several consensus steps BACK TO BACK (no controls() / sync() in between: every group stream must be ordered
+  // behind the exchange that produced the record it reads) give the same controls with two agent groups on two
+  // streams as with one group on one stream: the per-agent records are added in agent order whatever the grouping.
+  {
+    mat us[2];
+    for (unsigned int groups = 1; groups <= 2; ++groups) {
+      AgentBatch<models::Omni> b2(N, 0.1, 5.0, 0.1, 1.0, 10, Rinv, umin, umax, nullptr, groups);
+      b2.setTarget(target);
+      b2.configTarget(grid);
+      b2.setPoses(poses);
+      for (int i = 0; i < 6; ++i) b2.control(true);
+      us[groups - 1] = b2.controls();
+    }
+    double worst = 0.0;
+    for (unsigned int a = 0; a < N; ++a) {
+      for (int r = 0; r < 3; ++r) worst = std::max(worst, std::fabs(us[0](r, a) - us[1](r, a)));
+    }
+    CHECK(worst == 0.0);
+  }
 }
 
 int main(int argc, char** argv)

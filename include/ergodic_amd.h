@@ -175,12 +175,34 @@ typedef struct {
   const void* d_ck_shared;/* [K^2]      in, optional (ABI 2): decentralised-consensus mode.
                                         When set, fourier_diff = lamdak % (ck - phik)
                                         (:422) is formed with this shared c_k (e.g. the mean
-                                        of all agents' c_k, eea_comm_consensus_ck) instead of
-                                        the agent's own; d_ck still receives the own c_k.
-                                        No counterpart in the single-agent reference: the
-                                        semantics are those of its README ref. [2]
-                                        (README.md:225-227).  NULL = reference behaviour      */
+                                        of all agents' c_k) instead of the agent's own; d_ck
+                                        still receives the own c_k.  No counterpart in the
+                                        single-agent reference: the semantics are those of its
+                                        README ref. [2] (README.md:225-227).  NULL = reference
+                                        behaviour.  With ck_shared_parts > 0 the buffer holds
+                                        sum records instead (below)                           */
+  void* d_ck_rec;         /* [B][eea_ck_record_len] out, optional (ABI 3): per-agent sum records
+                                        [c_k (K^2 reals), 1, zero padding to an even length]; an
+                                        agent rejected with EEA_ERR_INVALID_TWIST gets an all-zero
+                                        record.  eea_ck_records_sum adds the B records in ONE small
+                                        launch (fixed order); the result -- sums and agent count --
+                                        is what d_ck_shared takes with ck_shared_parts > 0        */
+  unsigned ck_shared_parts;/* ABI 3: 0 = d_ck_shared holds K^2 consensus values (ABI 2 form).
+                                        n >= 1 = d_ck_shared holds n consecutive sum records
+                                        (eea_ck_records_sum of earlier calls -- e.g. one per agent
+                                        group -- all-reduced over the ranks or not): the kernel uses
+                                        c_bar[m] = sum_i rec_i[m] / sum_i rec_i[K^2]: no divide
+                                        launch, and the exchange is one all-reduce of n records */
 } eea_batch_io;
+
+/* length in reals of one sum record (eea_batch_io::d_ck_rec): K^2 + 1 rounded up to an even number */
+unsigned eea_ck_record_len(const eea_engine* e);
+/* d_sum [eea_ck_record_len] = sum of the B per-agent records d_ck_rec [B][eea_ck_record_len] in agent order (element
+ * K^2 = number of agents that count): ONE launch of ceil(B / 64) small workgroups whose last arriver adds the group
+ * records -- fixed summation order, run-to-run deterministic.  Asynchronous on `stream` (typically an exchange stream
+ * beside the compute streams: the launch needs 2 wavefronts per 64 agents and fits into what the control kernels'
+ * finishing wavefronts leave free).  Concurrent calls on one engine must use distinct d_sum buffers. */
+eea_status eea_ck_records_sum(eea_engine* e, unsigned B, const void* d_ck_rec, void* d_sum, void* stream);
 
 /* One receding-horizon optimisation per agent (ergodic_control.hpp:224-311, without the
  * configTarget call: use eea_config_domain first).  Asynchronous on `stream`. */
@@ -223,12 +245,29 @@ eea_status eea_comm_consensus_ck(eea_engine* e, eea_comm* c, unsigned B_local, c
  * `compute_stream` so far (the pass that produced c_k), so that the next pass on the compute stream overlaps it;
  * eea_comm_wait makes a stream wait for the exchange started in `slot` (0 .. EEA_COMM_SLOTS - 1; the caller
  * rotates slots together with its c_k / result buffers). */
-#define EEA_COMM_SLOTS 4
+#define EEA_COMM_SLOTS 8
 eea_status eea_comm_consensus_ck_async(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_local,
                                        void* d_ck_shared, void* compute_stream, int slot);
 eea_status eea_comm_allgather_ck_async(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_local,
                                        void* d_ck_all, void* compute_stream, int slot);
 eea_status eea_comm_wait(eea_comm* c, int slot, void* stream);
+/* The whole exchange of one pass of an agent batch stepped as n_streams agent groups, in one call: on the
+ * communicator's own (highest-priority) stream, ordered after everything enqueued so far on EACH of the group streams:
+ * eea_ck_records_sum over the B_local per-agent records d_ck_rec (eea_batch_io::d_ck_rec of the groups' control calls),
+ * then the all-reduce of the sum record over the ranks (none with one rank).  d_sum [eea_ck_record_len] then feeds
+ * eea_batch_io::d_ck_shared with ck_shared_parts = 1 on every rank; the consuming streams call eea_comm_wait(c, slot, ..). */
+eea_status eea_comm_records_exchange_async(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_rec,
+                                           void* d_sum, void* const* group_streams, unsigned n_streams, int slot);
+/* The control calls of one pass of such a batch in one call (a pass of 4096 agents takes ~25 us on the device: the host
+ * must issue it in less): for every agent group g, eea_comm_wait(c, wait_slot, group_streams[g]) -- skipped when
+ * wait_slot < 0 -- and eea_control_batch(e, B[g], &ios[g], group_streams[g]). */
+eea_status eea_comm_control_groups(eea_engine* e, eea_comm* c, unsigned n_groups, const unsigned* B,
+                                   const eea_batch_io* ios, void* const* group_streams, int wait_slot);
+/* asynchronous in-place all-reduce (sum) of n reals on the communicator's own stream, ordered after `compute_stream`
+ * like the forms above: the sum records of the agent groups of one pass (eea_ck_records_sum) in ONE collective;
+ * one rank: no collective, only the ordering */
+eea_status eea_comm_allreduce_sum_async(eea_engine* e, eea_comm* c, void* d_buf, unsigned n, void* compute_stream,
+                                        int slot);
 /* in-place ncclAllReduce(sum) of n reals: the K^2 partial sums of a grid-tiled phi_k
  * (eea_spatial_coeff_rows / eea_spatial_coeff_occupancy_rows) */
 eea_status eea_comm_allreduce_sum(eea_engine* e, eea_comm* c, void* d_buf, unsigned n, void* stream);

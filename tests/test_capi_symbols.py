@@ -32,7 +32,7 @@ def test_library_exports_only_the_documented_abi():
 def test_struct_layouts_match_header():
     # sizes the C compiler gives the ABI structs (kept in sync with ergodic_amd.h by hand)
     assert C.sizeof(capi.Config) == 3 * 4 + 4 + 4 * 8 + 8 + 15 * 8  # ints, pad, doubles, K+pad, arrays
-    assert C.sizeof(capi.BatchIO) == 13 * 8
+    assert C.sizeof(capi.BatchIO) == 15 * 8  # 13 pointers / padded uint, d_ck_rec, ck_shared_parts (+ pad)
     assert C.sizeof(capi.CollisionCfg) == 3 * 8 + 2 * 4 + 4 * 8
 
 

@@ -134,6 +134,119 @@ def test_exchange_steps_on_single_rank_rccl():
     e32.close()
 
 
+def _sum_record_case(model, K, horizon, B, precision=capi.PREC_F64, n_mem=0, bad=(), dt=0.1):
+    """one control_batch with d_ck and d_ck_rec, then eea_ck_records_sum: (sum record, per-agent c_k, status) as numpy"""
+    rng = np.random.default_rng(100 + B + K)
+    eng, _ = make_pair(model, K, horizon, n_oracles=0, precision=precision, dt=dt)
+    T, K2 = eng.T, eng.K2
+    tdt = torch.float64 if precision == capi.PREC_F64 else torch.float32
+    poses = random_poses(rng, B)
+    ut0 = rng.uniform(-0.5, 0.5, (B, T, 3))
+    if model == "simple_cart":
+        ut0[:, :, 1] = 0.0
+        for b in bad:
+            ut0[b, T // 2, 1] = 0.3      # a lateral velocity: SimpleCart::operator() throws (cart.hpp:167-170)
+    mem = random_poses(rng, B * n_mem).reshape(B, n_mem, 3) if n_mem else None
+    d_pose, d_ut0 = dev(poses, tdt), dev(ut0, tdt)
+    d_u0 = torch.empty((B, 3), dtype=tdt, device="cuda")
+    d_ck = torch.zeros((B, K2), dtype=tdt, device="cuda")
+    d_status = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    d_mem = dev(mem, tdt) if n_mem else None
+    d_nmem = torch.full((B,), n_mem, dtype=torch.int32, device="cuda") if n_mem else None
+    L = eng.ck_record_len
+    assert L == ((K2 + 2) & ~1)
+    recs = []
+    for rep in range(2):   # twice from the same inputs: the record is run-to-run deterministic (fixed summation order)
+        d_ut = d_ut0.clone()
+        rec = torch.full((L,), float("nan"), dtype=tdt, device="cuda")
+        arec = torch.full((B, L), float("nan"), dtype=tdt, device="cuda")
+        eng.control_batch(B, d_pose, d_ut, d_u0, mem_cols=d_mem, n_mem=d_nmem, mem_stride=n_mem, ck=d_ck,
+                          status=d_status, ck_rec=arec)
+        eng.ck_records_sum(B, arec, rec)
+        torch.cuda.synchronize()
+        recs.append(rec.cpu().numpy().astype(np.float64))
+        # the per-agent records: [own c_k, 1, pad] -- all zero for an agent the model rejects
+        a = arec.cpu().numpy().astype(np.float64)
+        ok = d_status.cpu().numpy() == 0
+        assert np.array_equal(a[ok, :K2], d_ck.cpu().numpy().astype(np.float64)[ok]) and (a[ok, K2] == 1).all()
+        assert (a[:, K2 + 1:] == 0).all() and (a[~ok] == 0).all()
+    assert np.array_equal(recs[0], recs[1])
+    out = recs[0], d_ck.cpu().numpy().astype(np.float64), d_status.cpu().numpy(), K2
+    eng.close()
+    return out
+
+
+@pytest.mark.parametrize("model,K,horizon,B", [
+    ("simple_cart", 10, 20.0, 4096 + 3),   # the metric shape, 65 groups (the last one with 3 agents) + the ticket
+    ("omni", 10, 20.0, 64),                # exactly one group: no ticket
+    ("omni", 10, 5.0, 1),
+    ("omni", 5, 0.5, 130),                 # K = 5 (block contraction, one record element per lane)
+    ("omni", 12, 3.0, 200),                # generic K <= 16 instance
+    ("omni", 20, 5.0, 77),                 # K = 20: 402-element record, single-agent workgroups
+    ("omni", 30, 6.0, 150),                # workgroup-per-agent kernel
+])
+def test_sum_record_of_the_launch(model, K, horizon, B):
+    """eea_batch_io::d_ck_rec + eea_ck_records_sum (ABI 3): per-agent records out of the control kernel, ONE small
+    launch adds them to [sum_b c_k, number of agents, pad].  Against the per-agent c_k of the same call (d_ck):
+    summation order differs, so <= 1e-12 relative to the sum; count exact; pad zero; bitwise reproducible."""
+    rec, ck, status, K2 = _sum_record_case(model, K, horizon, B)
+    assert (status == 0).all()
+    assert rec[K2] == B and (rec[K2 + 1:] == 0).all()
+    ref = ck.sum(0)
+    assert np.abs(rec[:K2] - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
+
+
+def test_sum_record_skips_rejected_agents_and_fp32():
+    """agents SimpleCart rejects (EEA_ERR_INVALID_TWIST) contribute nothing and are not counted; fp32 engine"""
+    bad = (0, 5, 63, 64, 199)
+    rec, ck, status, K2 = _sum_record_case("simple_cart", 10, 20.0, 200, bad=bad)
+    assert sorted(np.nonzero(status == 2)[0]) == list(bad)
+    good = status == 0
+    assert rec[K2] == 200 - len(bad)
+    assert np.abs(rec[:K2] - ck[good].sum(0)).max() <= 1e-12 * np.abs(ck[good].sum(0)).max()
+    rec, ck, status, K2 = _sum_record_case("omni", 10, 20.0, 300, precision=capi.PREC_F32, n_mem=40)
+    assert rec[K2] == 300
+    assert np.abs(rec[:K2] - ck.sum(0)).max() <= 2e-5 * np.abs(ck.sum(0)).max()
+
+
+@pytest.mark.parametrize("K,horizon", [(10, 20.0), (30, 6.0)])
+def test_shared_ck_as_sum_records(K, horizon):
+    """ck_shared_parts = n (ABI 3): d_ck_shared holds n sum records and the kernel uses sum of sums / sum of counts --
+    bitwise the same controls as the ABI-2 form fed with that quotient, for both control kernels."""
+    rng = np.random.default_rng(8)
+    B = 150
+    eng, _ = make_pair("omni", K, horizon, n_oracles=0)
+    T, K2, L = eng.T, eng.K2, eng.ck_record_len
+    poses = random_poses(rng, B)
+    ut0 = rng.uniform(-0.5, 0.5, (B, T, 3))
+    d_pose, d_u0 = dev(poses), torch.empty((B, 3), dtype=torch.float64, device="cuda")
+    half = 70
+    recs = torch.zeros((2, L), dtype=torch.float64, device="cuda")
+    arec = torch.zeros((B, L), dtype=torch.float64, device="cuda")
+    d_ut = dev(ut0)
+    # pass 1: two agent groups, the records of each group added separately
+    eng.control_batch(half, d_pose[:half], d_ut[:half], d_u0[:half], ck_rec=arec[:half])
+    eng.control_batch(B - half, d_pose[half:], d_ut[half:], d_u0[half:], ck_rec=arec[half:])
+    eng.ck_records_sum(half, arec[:half], recs[0])
+    eng.ck_records_sum(B - half, arec[half:], recs[1])
+    torch.cuda.synchronize()
+    r = recs.cpu().numpy()
+    assert r[0, K2] == half and r[1, K2] == B - half
+    cbar = (r[0, :K2] + r[1, :K2]) / (r[0, K2] + r[1, K2])
+    # pass 2 consumes the two records ...
+    ut_a = d_ut.clone()
+    eng.control_batch(B, d_pose, ut_a, d_u0, ck_shared=recs, ck_shared_parts=2)
+    torch.cuda.synchronize()
+    u_a = d_u0.cpu().numpy().copy()
+    # ... or the quotient formed on the host (ABI-2 form)
+    ut_b = d_ut.clone()
+    eng.control_batch(B, d_pose, ut_b, d_u0, ck_shared=dev(cbar))
+    torch.cuda.synchronize()
+    assert np.array_equal(u_a, d_u0.cpu().numpy()) and torch.equal(ut_a, ut_b)
+    assert np.isfinite(u_a).all()
+    eng.close()
+
+
 @pytest.mark.parametrize("model", ["simple_cart", "omni"])
 def test_config4_full_size_against_oracle(model):
     """BASELINE config 4 at full size: every one of the 4096 agents' u0 and warm-start matrix ut after two
@@ -192,8 +305,8 @@ def test_config4_full_size_f32_against_f64_oracle():
         torch.cuda.synchronize()
         # the oracle sees the poses the fp32 engine was given (rounded to float)
         poses32 = poses.astype(np.float32).astype(np.float64)
-        u_ref, ut_ref = po.batch_control(cfg, MEANS, SIGMAS, MAP_BOUNDS, poses32, 0, min(threads, 64))
-        du = float(np.abs(d_u0.cpu().numpy().astype(np.float64) - u_ref).max())
+        _, ut_ref = po.batch_control(cfg, MEANS, SIGMAS, MAP_BOUNDS, poses32, 0, min(threads, 64))
+        du = float(np.abs(d_u0.cpu().numpy().astype(np.float64) - ut_ref[:, 0, :]).max())   # u0 = ut.col(0) (:310)
         dut = float(np.abs(d_ut.cpu().numpy().astype(np.float64) - ut_ref).max())
         worst[model] = (du, dut)
         eng.close()

@@ -1,41 +1,163 @@
 #!/usr/bin/env python3
-"""Cost of the optional c_k output / shared c_k input / exchange waits of eea_control_batch at the metric point
-(4096 agents, one launch per pass): none of them moves the pass time (profiles/r02_ablation.txt)."""
-import os, sys, time
+"""Where the consensus pass spends its time at the metric point (4096 agents): the optional record output / sum-record
+input of eea_control_batch, the one-launch record sum, the cross-stream choreography, each added in turn.  Two agent
+groups on two streams as in bench.py (profiles/r03_ablation.txt)."""
+import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.getcwd())
 from ergodic_exploration_amd import capi
-B=4096
+B, G = 4096, 2
 model = capi.MODEL_SIMPLE_CART
 lim = np.array([1.0, 0.0, 2.0])
 eng = capi.Engine(capi.make_config(model, 0.1, 20.0, 0.1, 1.0, 10, np.diag([1.0, 0.0, 2.0]), -lim, lim))
 eng.set_target_gaussians([[2.5, 2.5], [8.5, 2.5]], [[1.5, 1.5], [1.5, 1.5]])
 eng.config_domain((-1.0, 11.0, -1.0, 5.0))
-T, K2 = eng.T, eng.K2
+T, K2, L = eng.T, eng.K2, eng.ck_record_len
 rng = np.random.default_rng(1)
 poses = np.stack([rng.uniform(-0.5, 10.5, B), rng.uniform(-0.5, 4.5, B), rng.uniform(-3, 3, B)], 1)
 d_pose = torch.as_tensor(poses).cuda()
 d_ut = torch.zeros((B, T, 3), dtype=torch.float64, device="cuda")
 d_u0 = torch.empty((B, 3), dtype=torch.float64, device="cuda")
-d_ck = torch.empty((B, K2), dtype=torch.float64, device="cuda")
-d_cbar = torch.zeros((K2,), dtype=torch.float64, device="cuda")
-s = torch.cuda.Stream()
-comm = capi.Comm(0, 1, 0, None)
-def run(name, f, n=2000):
-    for _ in range(200): f()
+NB = 6
+d_arec = [torch.zeros((B, L), dtype=torch.float64, device="cuda") for _ in range(NB)]
+d_rec = [torch.zeros((L,), dtype=torch.float64, device="cuda") for _ in range(NB)]
+for r in d_rec:
+    r[K2] = 1.0
+streams = [torch.cuda.Stream() for _ in range(G)]
+xs = torch.cuda.Stream(priority=int(os.environ.get("XPRIO", "0")))
+gb = [(g * B) // G for g in range(G + 1)]
+ev_g = [[torch.cuda.Event() for _ in range(G)] for _ in range(NB)]
+ev_x = [torch.cuda.Event() for _ in range(NB)]
+calls = {}
+
+
+def call(g, rec_slot=None, src=None):
+    key = (g, rec_slot, src)
+    if key not in calls:
+        sl = slice(gb[g], gb[g + 1])
+        calls[key] = eng.prepared_batch(gb[g + 1] - gb[g], d_pose[sl], d_ut[sl], d_u0[sl], stream=streams[g].cuda_stream,
+                                        ck_rec=None if rec_slot is None else d_arec[rec_slot][sl],
+                                        ck_shared=None if src is None else d_rec[src],
+                                        ck_shared_parts=0 if src is None else 1)
+    calls[key]()
+
+
+def run(name, f, n=3000):
+    for i in range(400):
+        f(i)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(s)
-    for _ in range(n): f()
-    e1.record(s)
+    e0.record(streams[0])
+    import time
+    t0 = time.perf_counter()
+    for i in range(n):
+        f(i)
+    enq = time.perf_counter() - t0
+    for g in range(1, G):
+        e = torch.cuda.Event()
+        e.record(streams[g])
+        streams[0].wait_event(e)
+    e1.record(streams[0])
     torch.cuda.synchronize()
-    print("%-40s %.2f us/pass" % (name, 1e3 * e0.elapsed_time(e1) / n))
-run("plain", lambda: eng.control_batch(B, d_pose, d_ut, d_u0, stream=s.cuda_stream))
-run("ck out", lambda: eng.control_batch(B, d_pose, d_ut, d_u0, ck=d_ck, stream=s.cuda_stream))
-run("ck shared in", lambda: eng.control_batch(B, d_pose, d_ut, d_u0, ck_shared=d_cbar, stream=s.cuda_stream))
-run("ck out + shared in", lambda: eng.control_batch(B, d_pose, d_ut, d_u0, ck=d_ck, ck_shared=d_cbar, stream=s.cuda_stream))
-comm.consensus_ck_async(eng, B, d_ck, d_cbar, s.cuda_stream, 0)
-def f():
-    comm.wait(0, s.cuda_stream)
-    eng.control_batch(B, d_pose, d_ut, d_u0, ck=d_ck, ck_shared=d_cbar, stream=s.cuda_stream)
-run("wait + ck out + shared in", f)
+    print("%-58s %.2f us/pass  (host enqueue %.1f us/pass)" % (name, 1e3 * e0.elapsed_time(e1) / n, 1e6 * enq / n))
+
+
+def plain(i):
+    for g in range(G):
+        call(g)
+
+
+def rec_out(i):
+    for g in range(G):
+        call(g, i % NB)
+
+
+def rec_in(i):
+    for g in range(G):
+        call(g, None, 0)
+
+
+def rec_in_out(i):
+    for g in range(G):
+        call(g, i % NB, (i - 2) % NB)
+
+
+def with_sum_unordered(i):   # the sum launch on the exchange stream, nothing waits for anything
+    for g in range(G):
+        call(g, i % NB, (i - 2) % NB)
+    eng.ck_records_sum(B, d_arec[i % NB], d_rec[i % NB], stream=xs.cuda_stream)
+
+
+def with_sum_after_groups(i):  # the exchange stream waits for the groups' launches; consumers do not wait
+    s = i % NB
+    for g in range(G):
+        call(g, s, (i - 2) % NB)
+        ev_g[s][g].record(streams[g])
+        xs.wait_event(ev_g[s][g])
+    eng.ck_records_sum(B, d_arec[s], d_rec[s], stream=xs.cuda_stream)
+    ev_x[s].record(xs)
+
+
+def full(i, lag=2):
+    s = i % NB
+    src = (i - lag) % NB
+    for g in range(G):
+        if i >= lag:
+            streams[g].wait_event(ev_x[src])
+        call(g, s, src)
+        ev_g[s][g].record(streams[g])
+    for g in range(G):
+        xs.wait_event(ev_g[s][g])
+    eng.ck_records_sum(B, d_arec[s], d_rec[s], stream=xs.cuda_stream)
+    ev_x[s].record(xs)
+
+
+comm = capi.Comm(0, 1, 0, None)   # local communicator: its own highest-priority exchange stream, no RCCL
+xc = {}
+
+
+def full_c(i, lag=3, NBc=6):   # the same through ONE C-ABI call per pass (eea_comm_records_exchange_async) + eea_comm_wait
+    s, src = i % NBc, (i - lag) % NBc
+    for g in range(G):
+        if i >= lag:
+            w = xc.get(("w", g, src))
+            if w is None:
+                w = xc[("w", g, src)] = comm.prepared_wait(src, streams[g].cuda_stream)
+            w()
+        call(g, s, src)
+    x = xc.get(s)
+    if x is None:
+        x = xc[s] = comm.prepared_records_exchange(eng, B, d_arec[s], d_rec[s], [st.cuda_stream for st in streams], s)
+    x()
+
+
+def full_c2(i, lag=3, NBc=6):   # two C-ABI calls per pass: eea_comm_control_groups + eea_comm_records_exchange_async
+    s, src = i % NBc, (i - lag) % NBc
+    key = ("g", s, src if i >= lag else None)
+    c = xc.get(key)
+    if c is None:
+        groups = [dict(B=gb[g + 1] - gb[g], pose=d_pose[gb[g]:gb[g + 1]], ut=d_ut[gb[g]:gb[g + 1]], u0=d_u0[gb[g]:gb[g + 1]],
+                       stream=streams[g].cuda_stream, ck_rec=d_arec[s][gb[g]:gb[g + 1]],
+                       ck_shared=d_rec[src] if i >= lag else None, ck_shared_parts=1 if i >= lag else 0) for g in range(G)]
+        c = xc[key] = comm.prepared_control_groups(eng, groups, src if i >= lag else -1)
+    c()
+    x = xc.get(s)
+    if x is None:
+        x = xc[s] = comm.prepared_records_exchange(eng, B, d_arec[s], d_rec[s], [st.cuda_stream for st in streams], s)
+    x()
+
+
+run("plain (two groups)", plain)
+run("+ per-agent records out", rec_out)
+run("+ sum record in (ck_shared_parts = 1)", rec_in)
+run("+ both", rec_in_out)
+run("+ record sum on the exchange stream, unordered", with_sum_unordered)
+run("+ exchange stream ordered after the groups", with_sum_after_groups)
+run("+ consumers wait for the exchange (lag 2) = bench leg", full)
+run("  the same with lag 3", lambda i: full(i, 3))
+run("one C call per pass (records_exchange_async), lag 2", lambda i: full_c(i, 2))
+run("one C call per pass (records_exchange_async), lag 3", lambda i: full_c(i, 3))
+run("one C call per pass (records_exchange_async), lag 4", lambda i: full_c(i, 4))
+run("two C calls per pass (control_groups + exchange), lag 2", lambda i: full_c2(i, 2))
+run("two C calls per pass (control_groups + exchange), lag 3", lambda i: full_c2(i, 3))
+run("two C calls per pass (control_groups + exchange), lag 4", lambda i: full_c2(i, 4))
