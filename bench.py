@@ -65,7 +65,7 @@ def parse():
                     help="skip the exchange legs (consensus all-reduce, c_k all-gather)")
     ap.add_argument("--force-exchange", "--force-gather", dest="force_exchange", action="store_true",
                     help="run the all-gather leg even with one rank (single-rank RCCL communicator)")
-    ap.add_argument("--consensus-lag", type=int, default=4, choices=[1, 2, 3, 4, 5],
+    ap.add_argument("--consensus-lag", type=int, default=3, choices=[1, 2, 3, 4, 5],
                     help="passes between producing c_k and consuming its consensus: the record sum of pass i gets its "
                          "execution slots when the kernels of pass i + 1 finish, and the host issues the exchange calls "
                          "about as fast as the device runs a pass (tools/ck_cost.py: 50 / 38 / 34.5 us per pass at lag "
@@ -200,8 +200,11 @@ def phik_legs(args, torch, capi, np):
     eng.close()
     del phi, part
     torch.cuda.empty_cache()
-    # whole rebuild through the reference's entry (configTarget with a changed extent), Gaussian target
+    # whole rebuild through the reference's entry (configTarget with a changed extent), Gaussian target: the synchronous
+    # form (returns when phi_k is on the device) and the enqueue-only form (returns when the launches are on the
+    # stream; the next control call on that stream is ordered behind them)
     rebuild = []
+    st = torch.cuda.Stream()
     for Kc, lxc, lyc in ((10, 12.0, 6.0), (20, 25.5, 25.5), (30, 102.3, 102.3)):
         e2 = capi.Engine(capi.make_config(capi.MODEL_OMNI, 0.1, 2.0, 0.1, 1.0, Kc, np.eye(3), [-1] * 3, [1] * 3))
         e2.set_target_gaussians(MEANS, SIGMAS)
@@ -212,10 +215,30 @@ def phik_legs(args, torch, capi, np):
         for i in range(reps):
             e2.config_domain((0.0, lxc + 0.1 * (i % 2), 0.0, lyc))  # the extent changes on every call
         us = 1e6 * (time.perf_counter() - t0) / reps
-        rebuild.append({"K": Kc, "grid": "%dx%d" % (round(lxc / 0.1) + 1, round(lyc / 0.1) + 1), "wall_us": us})
+        torch.cuda.synchronize()
+        # enqueue-only: host time per call with the device keeping up (a stream synchronisation every 10 calls, timed
+        # apart), and the device time per rebuild from HIP events around a back-to-back run
+        enq = 0.0
+        for i in range(reps):
+            t0 = time.perf_counter()
+            e2.config_domain_async((0.0, lxc + 0.1 * (i % 2), 0.0, lyc), stream=st.cuda_stream)
+            enq += time.perf_counter() - t0
+            if i % 10 == 9:
+                st.synchronize()
+        st.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record(st)
+        for i in range(reps):
+            e2.config_domain_async((0.0, lxc + 0.1 * (i % 2), 0.0, lyc), stream=st.cuda_stream)
+        ev1.record(st)
+        st.synchronize()
+        rebuild.append({"K": Kc, "grid": "%dx%d" % (round(lxc / 0.1) + 1, round(lyc / 0.1) + 1), "wall_us": us,
+                        "enqueue_only_wall_us": 1e6 * enq / reps, "device_us_back_to_back": 1e3 * ev0.elapsed_time(ev1) / reps})
         e2.close()
-    out["config_domain_rebuild"] = {"note": "wall time of one eea_config_domain with a changed extent (Target::fill + "
-                                            "normalisation + spatialCoeff on the device, one host synchronisation)",
+    out["config_domain_rebuild"] = {"note": "eea_config_domain with a changed extent (Target::fill + normalisation + spatialCoeff "
+                                            "on the device): wall_us = synchronous form (one host wait); enqueue_only_wall_us = "
+                                            "eea_config_domain_async (the caller's thread is free again; the next control call on "
+                                            "the stream is ordered behind the rebuild); device_us = stream time per rebuild",
                                     "cases": rebuild}
     return out
 

@@ -118,6 +118,7 @@ def lib():
         L.eea_set_phik.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double]
         L.eea_set_phik_from_sums.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p]
         L.eea_config_domain.argtypes = [C.c_void_p] + [C.c_double] * 4 + [C.POINTER(C.c_int), C.c_void_p]
+        L.eea_config_domain_async.argtypes = [C.c_void_p] + [C.c_double] * 4 + [C.POINTER(C.c_int), C.c_void_p]
         L.eea_get_phik.argtypes = [C.c_void_p, C.c_void_p]
         L.eea_get_lamdak.argtypes = [C.c_void_p, C.c_void_p]
         L.eea_target_grid_size.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
@@ -260,6 +261,13 @@ class Engine:
         rebuilt = C.c_int(0)
         check(lib().eea_config_domain(self.h, *[float(b) for b in bounds], C.byref(rebuilt),
                                       C.c_void_p(stream or 0)))
+        return bool(rebuilt.value)
+
+    def config_domain_async(self, bounds, stream=None):
+        """enqueue-only form: returns once the rebuild's launches are on the stream"""
+        rebuilt = C.c_int(0)
+        check(lib().eea_config_domain_async(self.h, *[float(b) for b in bounds], C.byref(rebuilt),
+                                            C.c_void_p(stream or 0)))
         return bool(rebuilt.value)
 
     def phik(self):

@@ -123,6 +123,11 @@ struct eea_comm
   hipStream_t xstream = nullptr;
   hipEvent_t ev_in = nullptr;
   hipEvent_t ev_done[EEA_COMM_SLOTS] = {};
+  // completion of the agent groups' control launches of the current pass (eea_comm_control_groups): what the exchange
+  // of that pass waits for; bound to the kernels themselves, not recorded separately
+  static constexpr unsigned kMaxGroups = 8;
+  hipEvent_t ev_group[kMaxGroups] = {};
+  unsigned groups_launched = 0;
 };
 
 namespace
@@ -199,6 +204,9 @@ void eea_comm_destroy(eea_comm* c)
   for (hipEvent_t ev : c->ev_done) {
     if (ev) (void)hipEventDestroy(ev);
   }
+  for (hipEvent_t ev : c->ev_group) {
+    if (ev) (void)hipEventDestroy(ev);
+  }
   if (c->comm != nullptr && rccl().ok) (void)rccl().CommDestroy(c->comm);
   if (c->d_sums) (void)hipFree(c->d_sums);
   delete c;
@@ -265,7 +273,7 @@ eea_status eea_comm_consensus_ck(eea_engine* e, eea_comm* c, unsigned B_local, c
 
 namespace
 {
-eea_status async_begin(eea_comm* c, void* compute_stream, int slot)
+eea_status async_begin(eea_comm* c, void* compute_stream, int slot, bool order_after_compute = true)
 {
   if (c == nullptr || slot < 0 || slot >= EEA_COMM_SLOTS) return fail(EEA_ERR_INVALID_ARGUMENT, "bad communicator / slot");
   EEA_HIP(hipSetDevice(c->device));
@@ -278,6 +286,7 @@ eea_status async_begin(eea_comm* c, void* compute_stream, int slot)
     EEA_HIP(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
   }
   if (c->ev_done[slot] == nullptr) EEA_HIP(hipEventCreateWithFlags(&c->ev_done[slot], hipEventDisableTiming));
+  if (!order_after_compute) return EEA_OK;
   // everything enqueued on the compute stream so far (the pass that produced c_k) comes first
   EEA_HIP(hipEventRecord(c->ev_in, static_cast<hipStream_t>(compute_stream)));
   EEA_HIP(hipStreamWaitEvent(c->xstream, c->ev_in, 0));
@@ -326,13 +335,19 @@ eea_status eea_comm_control_groups(eea_engine* e, eea_comm* c, unsigned n_groups
   if (e == nullptr || c == nullptr || B == nullptr || ios == nullptr || group_streams == nullptr) {
     return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
   }
-  if (wait_slot >= EEA_COMM_SLOTS) return fail(EEA_ERR_INVALID_ARGUMENT, "bad slot");
+  if (wait_slot >= EEA_COMM_SLOTS || n_groups > eea_comm::kMaxGroups) return fail(EEA_ERR_INVALID_ARGUMENT, "bad slot / group count");
+  EEA_HIP(hipSetDevice(c->device));
+  c->groups_launched = 0;
   for (unsigned g = 0; g < n_groups; ++g) {
+    if (c->ev_group[g] == nullptr) EEA_HIP(hipEventCreateWithFlags(&c->ev_group[g], hipEventDisableTiming));
     if (B[g] == 0) continue;
     hipStream_t s = static_cast<hipStream_t>(group_streams[g]);
     if (wait_slot >= 0 && c->ev_done[wait_slot] != nullptr) EEA_HIP(hipStreamWaitEvent(s, c->ev_done[wait_slot], 0));
+    eea::set_stop_event(c->ev_group[g]);  // bound to the control kernel of this call
     const eea_status st = eea_control_batch(e, B[g], &ios[g], group_streams[g]);
+    (void)eea::take_stop_event();         // (not consumed if the call failed before its launch)
     if (st != EEA_OK) return st;
+    c->groups_launched |= 1u << g;
   }
   return EEA_OK;
 }
@@ -343,17 +358,34 @@ eea_status eea_comm_records_exchange_async(eea_engine* e, eea_comm* c, unsigned 
   if (e == nullptr || d_ck_rec == nullptr || d_sum == nullptr || (n_streams > 0 && group_streams == nullptr)) {
     return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
   }
-  eea_status st = async_begin(c, n_streams > 0 ? group_streams[0] : nullptr, slot);
-  if (st != EEA_OK) return st;
-  for (unsigned g = 1; g < n_streams; ++g) {  // ... and after everything enqueued on the other group streams
-    EEA_HIP(hipEventRecord(c->ev_in, static_cast<hipStream_t>(group_streams[g])));
-    EEA_HIP(hipStreamWaitEvent(c->xstream, c->ev_in, 0));
+  if (c == nullptr || slot < 0 || slot >= EEA_COMM_SLOTS) return fail(EEA_ERR_INVALID_ARGUMENT, "bad communicator / slot");
+  eea_status st = EEA_OK;
+  if (c->groups_launched != 0) {
+    // the groups' control kernels of this pass came through eea_comm_control_groups: their completion events exist
+    st = async_begin(c, nullptr, slot, false);
+    if (st != EEA_OK) return st;
+    for (unsigned g = 0; g < eea_comm::kMaxGroups; ++g) {
+      if (c->groups_launched & (1u << g)) EEA_HIP(hipStreamWaitEvent(c->xstream, c->ev_group[g], 0));
+    }
+    c->groups_launched = 0;
+  } else {
+    st = async_begin(c, n_streams > 0 ? group_streams[0] : nullptr, slot);
+    if (st != EEA_OK) return st;
+    for (unsigned g = 1; g < n_streams; ++g) {  // ... and after everything enqueued on the other group streams
+      EEA_HIP(hipEventRecord(c->ev_in, static_cast<hipStream_t>(group_streams[g])));
+      EEA_HIP(hipStreamWaitEvent(c->xstream, c->ev_in, 0));
+    }
   }
+  const bool collective = c->comm != nullptr;
+  if (!collective) eea::set_stop_event(c->ev_done[slot]);  // the record sum is the last step: its kernel carries the event
   st = eea_ck_records_sum(e, B_local, d_ck_rec, d_sum, c->xstream);
+  (void)eea::take_stop_event();
   if (st != EEA_OK) return st;
-  st = eea_comm_allreduce_sum(e, c, d_sum, eea_ck_record_len(e), c->xstream);
-  if (st != EEA_OK) return st;
-  EEA_HIP(hipEventRecord(c->ev_done[slot], c->xstream));
+  if (collective) {
+    st = eea_comm_allreduce_sum(e, c, d_sum, eea_ck_record_len(e), c->xstream);
+    if (st != EEA_OK) return st;
+    EEA_HIP(hipEventRecord(c->ev_done[slot], c->xstream));
+  }
   return EEA_OK;
 }
 

@@ -22,6 +22,12 @@ enum : int { kModelOmni = 0, kModelSimpleCart = 1 };
 
 // process-wide dispatch option (eea_set_option, EEA_OPT_* of include/ergodic_amd.h); defined in engine.cpp
 int option(int id);
+// Completion event for the NEXT control / record-sum launch of the calling thread (internal: the exchange entry points
+// of comm.hip set it right before they call eea_control_batch / eea_ck_records_sum).  The launch site takes it and binds
+// it to the kernel itself (hipExtLaunchKernelGGL's stop event: the kernel's own completion signal instead of a separate
+// event-record packet -- an event operation costs the host ~3 us, as much as a launch).  Defined in engine.cpp.
+void set_stop_event(hipEvent_t ev);
+hipEvent_t take_stop_event();
 
 // Everything one control launch needs; passed by value (kernarg).
 template <typename R>
@@ -108,11 +114,11 @@ template <typename R>
 hipError_t launch_target_fill_args(const R* d_coord, int nx, int ny, const GaussArgs<R>& ga, R* d_phi,
                                    R* d_partials, int K, R pi_lx, R pi_ly, R* d_cx, R* d_cy, hipStream_t s);
 // spatialCoeff of an UN-normalised grid divided by its mass (the sum of d_mass_partials); d_mass[0] receives
-// the mass
+// the mass.  stop (optional): an event bound to the completion of the last launch
 template <typename R>
 hipError_t launch_spatial_coeff_normalised(const R* d_phi_raw, int nx, int ny, int K, const R* d_cx, const R* d_cy,
                                            R* d_work, R* d_phik, const R* d_mass_partials, int n_mass, R* d_mass,
-                                           hipStream_t s);
+                                           hipStream_t s, hipEvent_t stop = nullptr);
 // cos tables: out[k * n + i] = cos((k * pi_over_l) * coord[i]), k < K
 template <typename R>
 hipError_t launch_cos_tables(const R* d_coord, int n, int K, R pi_over_l, R* d_out, hipStream_t s);

@@ -141,8 +141,13 @@ hipError_t launch_ck_records_sum(const R* d_rec, unsigned B, int K2, R* d_ws, un
 {
   if (B == 0) return hipSuccess;
   const unsigned ngroups = (B + kSumGroup - 1) / kSumGroup;
-  hipLaunchKernelGGL(ck_records_sum_kernel<R>, dim3(ngroups), dim3(kSumThreads), 0, stream, d_rec, B, ck_record_len(K2), d_ws,
-                     d_ctr, d_out);
+  if (const hipEvent_t stop = take_stop_event()) {
+    hipExtLaunchKernelGGL(ck_records_sum_kernel<R>, dim3(ngroups), dim3(kSumThreads), 0, stream, nullptr, stop, 0, d_rec, B,
+                          ck_record_len(K2), d_ws, d_ctr, d_out);
+  } else {
+    hipLaunchKernelGGL(ck_records_sum_kernel<R>, dim3(ngroups), dim3(kSumThreads), 0, stream, d_rec, B, ck_record_len(K2),
+                       d_ws, d_ctr, d_out);
+  }
   return hipGetLastError();
 }
 

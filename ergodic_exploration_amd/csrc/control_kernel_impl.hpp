@@ -28,6 +28,8 @@
 //   * sin(pi t) / cos(pi t) evaluation (exact argument reduction) for headings and basis angles;
 //   * LDS regions with disjoint lifetimes are aliased: 32 KB per agent at K=10, T=200 (fp64),
 //     4 workgroups per CU.
+#include <hip/hip_ext.h>
+
 #include "common.hpp"
 
 // Phase markers EEA_STAMP(n): nothing in the product; tools/ab/control_kernel_timing.hip (A/B library) defines them
@@ -875,7 +877,11 @@ hipError_t launch_one(const ControlParams<R>& p, unsigned B, int Nmax, bool roll
                                              static_cast<int>(lds));
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3(B), dim3(BLK), lds, stream, p, Nmax, rollout_only ? 1 : 0);
+  if (const hipEvent_t stop = take_stop_event()) {
+    hipExtLaunchKernelGGL(kern, dim3(B), dim3(BLK), lds, stream, nullptr, stop, 0, p, Nmax, rollout_only ? 1 : 0);
+  } else {
+    hipLaunchKernelGGL(kern, dim3(B), dim3(BLK), lds, stream, p, Nmax, rollout_only ? 1 : 0);
+  }
   return hipGetLastError();
 }
 

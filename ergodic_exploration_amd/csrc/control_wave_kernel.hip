@@ -1,4 +1,6 @@
 // Instantiations and dispatch of the wavefront-per-agent control kernel (control_wave_impl.hpp).
+#include <hip/hip_ext.h>
+
 #include "control_wave_impl.hpp"
 
 // wavefronts (agents) per workgroup: they share nothing; 4 keeps the dispatch count low
@@ -24,8 +26,13 @@ hipError_t launch_wave_one(const ControlParams<R>& p, unsigned B, bool rollout_o
                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(kern, dim3((B + WPB - 1) / WPB), dim3(WPB * kWave), lds, stream, p, B, S,
-                     rollout_only ? 1 : 0);
+  if (const hipEvent_t stop = take_stop_event()) {
+    hipExtLaunchKernelGGL(kern, dim3((B + WPB - 1) / WPB), dim3(WPB * kWave), lds, stream, nullptr, stop, 0, p, B, S,
+                          rollout_only ? 1 : 0);
+  } else {
+    hipLaunchKernelGGL(kern, dim3((B + WPB - 1) / WPB), dim3(WPB * kWave), lds, stream, p, B, S,
+                       rollout_only ? 1 : 0);
+  }
   return hipGetLastError();
 }
 

@@ -27,6 +27,17 @@ std::atomic<int> g_options[EEA_OPT_COUNT] = { { 0 }, { 0 }, { 0 }, { 1 } };
 namespace eea
 {
 int option(int id) { return (id >= 0 && id < EEA_OPT_COUNT) ? g_options[id].load(std::memory_order_relaxed) : 0; }
+namespace
+{
+thread_local hipEvent_t tl_stop_event = nullptr;
+}
+void set_stop_event(hipEvent_t ev) { tl_stop_event = ev; }
+hipEvent_t take_stop_event()
+{
+  const hipEvent_t ev = tl_stop_event;
+  tl_stop_event = nullptr;
+  return ev;
+}
 }  // namespace eea
 
 namespace
@@ -99,6 +110,10 @@ struct eea_engine
   double tab_lx = 0.0, tab_ly = 0.0;
   bool have_lut = false;  // the entropy decode table is uploaded once
   hipEvent_t ev_done = nullptr;  // completion of a rebuild: polled (a few microseconds earlier than a blocking wait)
+  // a rebuild that was only enqueued (eea_config_domain_async): control calls on OTHER streams wait for this event
+  hipEvent_t ev_rebuild = nullptr;
+  hipStream_t rebuild_stream = nullptr;
+  bool rebuild_pending = false;
   DevBuf d_lut, d_raw, d_occ;  // occupancy targets: decode table, un-normalised sums, staged cells
 
   // workspaces of eea_ck_records_sum (group records + one ticket), one per distinct output buffer: concurrent calls
@@ -254,9 +269,33 @@ eea_status reserve_tile_work(eea_engine* e, unsigned nx, unsigned ny_total, unsi
 
 // Target::fill + Basis::spatialCoeff on the device: three launches (tables + fill, streaming pass, final sums
 // with the normalisation folded in) and ONE host synchronisation at the end
-template <typename R>
-eea_status rebuild_phik(eea_engine* e, hipStream_t s)
+// orders stream s behind a rebuild that was only enqueued on another stream (no-op once it has completed)
+eea_status order_after_rebuild(eea_engine* e, hipStream_t s)
 {
+  if (!e->rebuild_pending || s == e->rebuild_stream) return EEA_OK;
+  if (hipEventQuery(e->ev_rebuild) == hipSuccess) {
+    e->rebuild_pending = false;
+    return EEA_OK;
+  }
+  EEA_HIP(hipStreamWaitEvent(s, e->ev_rebuild, 0));
+  return EEA_OK;
+}
+// host-side readers of what a rebuild writes
+eea_status finish_rebuild(eea_engine* e)
+{
+  if (!e->rebuild_pending) return EEA_OK;
+  EEA_HIP(hipEventSynchronize(e->ev_rebuild));
+  e->rebuild_pending = false;
+  return EEA_OK;
+}
+
+template <typename R>
+eea_status rebuild_phik(eea_engine* e, hipStream_t s, bool wait)
+{
+  {  // the engine's grid / table / phi_k buffers: behind a rebuild still in flight on another stream
+    const eea_status st0 = order_after_rebuild(e, s);
+    if (st0 != EEA_OK) return st0;
+  }
   // Add 1 to include the boundary (ergodic_control.hpp:383-385)
   const unsigned nx = axis_length(0.0, e->lx, e->cfg.resolution) + 1;
   const unsigned ny = axis_length(0.0, e->ly, e->cfg.resolution) + 1;
@@ -324,12 +363,21 @@ eea_status rebuild_phik(eea_engine* e, hipStream_t s)
                                        static_cast<R*>(e->d_phi.p), d_partials, &n_partials, s));
   }
   // phi_k = spatialCoeff(phi / sum(phi)) = spatialCoeff(phi) / sum(phi)  (target.cpp:87, basis.cpp:122-133)
+  // enqueue-only form: the event other streams (and the getters) wait for is bound to the last launch itself
+  if (!wait && e->ev_rebuild == nullptr) EEA_HIP(hipEventCreateWithFlags(&e->ev_rebuild, hipEventDisableTiming));
   EEA_HIP(eea::launch_spatial_coeff_normalised<R>(static_cast<const R*>(e->d_phi.p), nx, ny, e->K,
                                                   static_cast<const R*>(e->d_cx.p), static_cast<const R*>(e->d_cy.p),
                                                   static_cast<R*>(e->d_work.p), static_cast<R*>(e->d_phik.p),
-                                                  d_partials, n_partials, d_mass, s));
-  st = wait_stream_spin(e, s);
-  if (st != EEA_OK) return st;
+                                                  d_partials, n_partials, d_mass, s, wait ? nullptr : e->ev_rebuild));
+  if (wait) {
+    st = wait_stream_spin(e, s);
+    if (st != EEA_OK) return st;
+    e->rebuild_pending = false;
+  } else {
+    // enqueue only: whatever follows on s is ordered by the stream; other streams wait for the event
+    e->rebuild_stream = s;
+    e->rebuild_pending = true;
+  }
   e->have_phik = true;
   e->have_fill_grid = true;
   e->phi_is_raw = true;
@@ -596,6 +644,7 @@ void eea_destroy(eea_engine* e)
 {
   if (e == nullptr) return;
   (void)hipSetDevice(e->cfg.device);
+  (void)finish_rebuild(e);
   if (e->stream1) {
     (void)hipStreamSynchronize(e->stream1);
     (void)hipStreamDestroy(e->stream1);
@@ -609,6 +658,7 @@ void eea_destroy(eea_engine* e)
     w.ctr.release();
   }
   if (e->ev_done) (void)hipEventDestroy(e->ev_done);
+  if (e->ev_rebuild) (void)hipEventDestroy(e->ev_rebuild);
   if (e->h_mail) (void)hipHostFree(e->h_mail);
   if (e->h_stage) (void)hipHostFree(e->h_stage);
   delete e;
@@ -634,6 +684,7 @@ eea_status eea_set_target_grid(eea_engine* e, unsigned nx, unsigned ny, const vo
                                int on_device, double lx, double ly, void* stream)
 {
   if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (finish_rebuild(e) != EEA_OK) return EEA_ERR_HIP;  // a rebuild that was only enqueued owns the buffers below
   if (phi_vals == nullptr || nx == 0 || ny == 0 || !(lx > 0.0) || !(ly > 0.0)) {
     return fail(EEA_ERR_INVALID_ARGUMENT, "bad target grid");
   }
@@ -651,6 +702,7 @@ eea_status eea_spatial_coeff_rows(eea_engine* e, unsigned nx, unsigned ny_total,
                                   void* d_phik_partial, void* stream)
 {
   if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (finish_rebuild(e) != EEA_OK) return EEA_ERR_HIP;  // a rebuild that was only enqueued owns the buffers below
   if (d_phi_rows == nullptr || d_phik_partial == nullptr || nx == 0 || ny_total == 0 || nrows == 0 ||
       row0 + nrows > ny_total || !(lx > 0.0) || !(ly > 0.0)) {
     return fail(EEA_ERR_INVALID_ARGUMENT, "bad grid tile");
@@ -685,6 +737,7 @@ eea_status eea_set_target_occupancy(eea_engine* e, unsigned nx, unsigned ny, con
                                     int on_device, double lx, double ly, void* stream)
 {
   if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (finish_rebuild(e) != EEA_OK) return EEA_ERR_HIP;  // a rebuild that was only enqueued owns the buffers below
   if (occ == nullptr || nx == 0 || ny == 0 || !(lx > 0.0) || !(ly > 0.0)) {
     return fail(EEA_ERR_INVALID_ARGUMENT, "bad occupancy grid");
   }
@@ -725,6 +778,7 @@ eea_status eea_spatial_coeff_occupancy_rows(eea_engine* e, unsigned nx, unsigned
                                             void* d_sums_partial, void* stream)
 {
   if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (finish_rebuild(e) != EEA_OK) return EEA_ERR_HIP;  // a rebuild that was only enqueued owns the buffers below
   if (d_occ_rows == nullptr || d_sums_partial == nullptr || nx == 0 || ny_total == 0 || nrows == 0 ||
       row0 + nrows > ny_total || !(lx > 0.0) || !(ly > 0.0)) {
     return fail(EEA_ERR_INVALID_ARGUMENT, "bad occupancy tile");
@@ -745,6 +799,7 @@ eea_status eea_spatial_coeff_occupancy_rows(eea_engine* e, unsigned nx, unsigned
 eea_status eea_set_phik(eea_engine* e, const void* phik, int on_device, double lx, double ly)
 {
   if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (finish_rebuild(e) != EEA_OK) return EEA_ERR_HIP;  // a rebuild that was only enqueued owns the buffers below
   if (phik == nullptr || !(lx > 0.0) || !(ly > 0.0)) return fail(EEA_ERR_INVALID_ARGUMENT, "bad phi_k");
   eea_status st = use_device(e);
   if (st != EEA_OK) return st;
@@ -758,6 +813,7 @@ eea_status eea_set_phik(eea_engine* e, const void* phik, int on_device, double l
 eea_status eea_set_phik_from_sums(eea_engine* e, const void* d_sums, double lx, double ly, void* stream)
 {
   if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (finish_rebuild(e) != EEA_OK) return EEA_ERR_HIP;  // a rebuild that was only enqueued owns the buffers below
   if (d_sums == nullptr || !(lx > 0.0) || !(ly > 0.0)) return fail(EEA_ERR_INVALID_ARGUMENT, "bad sums");
   eea_status st = use_device(e);
   if (st != EEA_OK) return st;
@@ -775,8 +831,8 @@ eea_status eea_set_phik_from_sums(eea_engine* e, const void* d_sums, double lx, 
   return EEA_OK;
 }
 
-eea_status eea_config_domain(eea_engine* e, double xmin, double xmax, double ymin, double ymax,
-                             int* rebuilt, void* stream)
+static eea_status config_domain_impl(eea_engine* e, double xmin, double xmax, double ymin, double ymax, int* rebuilt,
+                                     void* stream, bool wait)
 {
   if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
   if (rebuilt) *rebuilt = 0;
@@ -793,7 +849,7 @@ eea_status eea_config_domain(eea_engine* e, double xmin, double xmax, double ymi
   e->lx = mx;
   e->ly = my;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  st = e->f32 ? rebuild_phik<float>(e, s) : rebuild_phik<double>(e, s);
+  st = e->f32 ? rebuild_phik<float>(e, s, wait) : rebuild_phik<double>(e, s, wait);
   if (st != EEA_OK) {
     // the reference throws out of the controller here; a failed rebuild must not leave the new extent
     // behind (the next call would take the almost_equal early return with a stale phi_k)
@@ -803,6 +859,18 @@ eea_status eea_config_domain(eea_engine* e, double xmin, double xmax, double ymi
   }
   if (rebuilt) *rebuilt = 1;
   return st;
+}
+
+eea_status eea_config_domain(eea_engine* e, double xmin, double xmax, double ymin, double ymax,
+                             int* rebuilt, void* stream)
+{
+  return config_domain_impl(e, xmin, xmax, ymin, ymax, rebuilt, stream, true);
+}
+
+eea_status eea_config_domain_async(eea_engine* e, double xmin, double xmax, double ymin, double ymax,
+                                   int* rebuilt, void* stream)
+{
+  return config_domain_impl(e, xmin, xmax, ymin, ymax, rebuilt, stream, false);
 }
 
 static eea_status download_reals(eea_engine* e, const void* d, size_t n, double* out)
@@ -822,6 +890,7 @@ static eea_status download_reals(eea_engine* e, const void* d, size_t n, double*
 eea_status eea_get_phik(eea_engine* e, double* h_phik)
 {
   if (check_engine(e) != EEA_OK || h_phik == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  if (finish_rebuild(e) != EEA_OK) return EEA_ERR_HIP;
   return download_reals(e, e->d_phik.p, e->K2, h_phik);
 }
 
@@ -845,6 +914,7 @@ eea_status eea_get_target_grid(eea_engine* e, double* h_phi_vals)
   if (e->d_phi.p == nullptr || e->nx == 0 || !e->have_fill_grid) {
     return fail(EEA_ERR_NO_TARGET, "no Target::fill grid on the device (explicit / occupancy targets are not kept)");
   }
+  if (finish_rebuild(e) != EEA_OK) return EEA_ERR_HIP;
   const size_t P = static_cast<size_t>(e->nx) * e->ny;
   eea_status st = download_reals(e, e->d_phi.p, P, h_phi_vals);
   if (st != EEA_OK || !e->phi_is_raw) return st;
@@ -871,6 +941,8 @@ eea_status eea_control_batch(eea_engine* e, unsigned B, const eea_batch_io* io, 
   eea_status st = use_device(e);
   if (st != EEA_OK) return st;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  st = order_after_rebuild(e, s);  // a phi_k rebuild that was only enqueued on another stream (eea_config_domain_async)
+  if (st != EEA_OK) return st;
   return e->f32 ? control_batch_impl<float>(e, B, io, false, s)
                 : control_batch_impl<double>(e, B, io, false, s);
 }
@@ -923,8 +995,8 @@ eea_status eea_control(eea_engine* e, double xmin, double xmax, double ymin, dou
   if (n_mem > 0 && h_mem_cols == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null mem_cols");
   eea_status st = use_device(e);
   if (st != EEA_OK) return st;
-  // pose_ = x; configTarget(grid)  (:227-230)
-  st = eea_config_domain(e, xmin, xmax, ymin, ymax, nullptr, e->stream1);
+  // pose_ = x; configTarget(grid)  (:227-230): enqueued on the same stream as the control kernel, no host wait
+  st = eea_config_domain_async(e, xmin, xmax, ymin, ymax, nullptr, e->stream1);
   if (st != EEA_OK) return st;
   if (!e->have_phik) return fail(EEA_ERR_NO_TARGET, "no target set");
   for (int i = 0; i < 3; ++i) e->last_pose[i] = x[i];

@@ -16,6 +16,8 @@
 #include <string>
 #include <type_traits>
 
+#include <hip/hip_ext.h>
+
 #include "common.hpp"
 
 // grid rows whose loads are issued before the first is consumed (memory-level parallelism per lane)
@@ -737,8 +739,16 @@ namespace
 template <typename R, typename IN>
 hipError_t launch_spatial_generic(const IN* d_in, int nx, int ny, int K, const R* d_cx, const R* d_cy,
                                   const R* d_lut, R* d_work, R* d_phik, hipStream_t s,
-                                  const R* d_mass_partials = nullptr, int n_mass = 0, R* d_mass = nullptr)
+                                  const R* d_mass_partials = nullptr, int n_mass = 0, R* d_mass = nullptr,
+                                  hipEvent_t stop = nullptr)
 {
+  // `stop` (optional) is bound to the completion of the LAST launch (hipExtLaunchKernelGGL: the kernel's own
+  // completion signal, no separate event-record packet on the stream)
+#define EEA_LAUNCH_MAYBE_LAST(last, kernel, grid, block, lds, ...)                                      \
+  do {                                                                                                  \
+    if ((last) && stop != nullptr) hipExtLaunchKernelGGL(kernel, grid, block, lds, s, nullptr, stop, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel, grid, block, lds, s, __VA_ARGS__);                                  \
+  } while (0)
   constexpr bool kCells = !std::is_same<IN, R>::value;
   constexpr int kind = kCells ? kKindCells : (sizeof(R) == 8 ? kKindF64 : kKindF32);
   const int K2 = K * K;
@@ -758,24 +768,24 @@ hipError_t launch_spatial_generic(const IN* d_in, int nx, int ny, int K, const R
     R* const d_direct = direct ? d_phik : nullptr;
     R* const d_direct_mass = direct ? d_mass : nullptr;
     if (NT == 1) {
-      hipLaunchKernelGGL((spatial_stream_kernel<R, 1, IN>), grid, dim3(kBlock), lds, s, d_in, nx, ny, K, rpt,
-                         d_cx, d_cy, d_lut, d_work, d_direct, d_direct_mass);
+      EEA_LAUNCH_MAYBE_LAST(direct, (spatial_stream_kernel<R, 1, IN>), grid, dim3(kBlock), lds, d_in, nx, ny, K, rpt,
+                            d_cx, d_cy, d_lut, d_work, d_direct, d_direct_mass);
     } else {
-      hipLaunchKernelGGL((spatial_stream_kernel<R, 2, IN>), grid, dim3(kBlock), lds, s, d_in, nx, ny, K, rpt,
-                         d_cx, d_cy, d_lut, d_work, d_direct, d_direct_mass);
+      EEA_LAUNCH_MAYBE_LAST(direct, (spatial_stream_kernel<R, 2, IN>), grid, dim3(kBlock), lds, d_in, nx, ny, K, rpt,
+                            d_cx, d_cy, d_lut, d_work, d_direct, d_direct_mass);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess || direct) return e;
     if (d_mass_partials != nullptr) {
-      hipLaunchKernelGGL(sum_partials_norm_kernel<R>, dim3((K2 + kModesPerSumBlock - 1) / kModesPerSumBlock),
-                         dim3(kBlock), 0, s, d_work, col_tiles * row_tiles, K2, d_mass_partials, n_mass, d_phik,
-                         d_mass);
+      EEA_LAUNCH_MAYBE_LAST(true, sum_partials_norm_kernel<R>, dim3((K2 + kModesPerSumBlock - 1) / kModesPerSumBlock),
+                            dim3(kBlock), 0, d_work, col_tiles * row_tiles, K2, d_mass_partials, n_mass, d_phik, d_mass);
     } else {
-      hipLaunchKernelGGL(sum_partials_kernel<R>, dim3((K2 + kModesPerSumBlock - 1) / kModesPerSumBlock), dim3(kBlock), 0, s,
-                         d_work, col_tiles * row_tiles, K2, R(1), d_phik);
+      EEA_LAUNCH_MAYBE_LAST(true, sum_partials_kernel<R>, dim3((K2 + kModesPerSumBlock - 1) / kModesPerSumBlock),
+                            dim3(kBlock), 0, d_work, col_tiles * row_tiles, K2, R(1), d_phik);
     }
     return hipGetLastError();
   }
+#undef EEA_LAUNCH_MAYBE_LAST
 }
 
 // out[m] = raw[m] / raw[0]: the (0,0) mode of the un-normalised sums is the sum of the target
@@ -799,10 +809,10 @@ hipError_t launch_spatial_coeff(const R* d_phi, int nx, int ny, int K, const R* 
 template <typename R>
 hipError_t launch_spatial_coeff_normalised(const R* d_phi_raw, int nx, int ny, int K, const R* d_cx, const R* d_cy,
                                            R* d_work, R* d_phik, const R* d_mass_partials, int n_mass, R* d_mass,
-                                           hipStream_t s)
+                                           hipStream_t s, hipEvent_t stop)
 {
   return launch_spatial_generic<R, R>(d_phi_raw, nx, ny, K, d_cx, d_cy, nullptr, d_work, d_phik, s, d_mass_partials,
-                                      n_mass, d_mass);
+                                      n_mass, d_mass, stop);
 }
 
 template <typename R>
@@ -848,7 +858,7 @@ hipError_t launch_point_coeff(const R* d_x, const R* d_y, const R* d_w, unsigned
   template hipError_t launch_target_fill_args<R>(const R*, int, int, const GaussArgs<R>&, R*, R*,   \
                                                  int, R, R, R*, R*, hipStream_t);                   \
   template hipError_t launch_spatial_coeff_normalised<R>(const R*, int, int, int, const R*, const R*, R*, R*, \
-                                                         const R*, int, R*, hipStream_t);           \
+                                                         const R*, int, R*, hipStream_t, hipEvent_t); \
   template hipError_t launch_cos_tables<R>(const R*, int, int, R, R*, hipStream_t);                 \
   template hipError_t launch_cos_tables_t<R>(const R*, int, int, R, R*, hipStream_t);               \
   template hipError_t launch_target_fill<R>(const R*, const R*, int, int, const R*, int, R*, R*,    \

@@ -143,6 +143,13 @@ eea_status eea_set_phik_from_sums(eea_engine* e, const void* d_sums, double lx, 
  * by >= 1e-12.  *rebuilt (optional) reports whether the rebuild ran. */
 eea_status eea_config_domain(eea_engine* e, double xmin, double xmax, double ymin, double ymax,
                              int* rebuilt, void* stream);
+/* The same without the host wait: a rebuild (two or three launches) is only ENQUEUED on `stream` and the call returns;
+ * control calls on the same stream afterwards are ordered by the stream, control calls on other streams are made to
+ * wait for it by the engine (one hipStreamWaitEvent while it is in flight), the host-side getters wait for it.  The
+ * caller orders the rebuild behind control calls still in flight on OTHER streams (they read the phi_k it replaces).
+ * eea_control (single agent) uses this form internally. */
+eea_status eea_config_domain_async(eea_engine* e, double xmin, double xmax, double ymin, double ymax,
+                                   int* rebuilt, void* stream);
 
 /* phi_k / lambda_k (basis.cpp:69-75) as doubles on the host, K^2 entries, col = k2*K + k1 */
 eea_status eea_get_phik(eea_engine* e, double* h_phik);

@@ -106,6 +106,49 @@ def test_rebuild_rule():
     eng.close()
 
 
+@pytest.mark.parametrize("K,bounds", [(10, (-1.0, 11.0, -1.0, 5.0)), (20, (0.0, 25.5, 0.0, 25.5))])
+def test_rebuild_enqueued_only(K, bounds):
+    """eea_config_domain_async: the rebuild is only enqueued.  Control calls on the SAME stream are ordered by the
+    stream, control calls on ANOTHER stream are made to wait by the engine, the getters wait: phi_k and the controls
+    are bitwise those of the synchronous form."""
+    means, sigmas = [[2.5, 2.5], [8.5, 2.5]], [[1.5, 1.5], [1.5, 1.5]]
+    rng = np.random.default_rng(4)
+    B = 64
+    res = {}
+    for form in ("sync", "async_same_stream", "async_other_stream"):
+        eng = capi.Engine(capi.make_config(capi.MODEL_OMNI, 0.1, 2.0, 0.1, 1.0, K, np.diag([1.0, 1.0, 2.0]), [-1, -1, -2], [1, 1, 2]))
+        eng.set_target_gaussians(means, sigmas)
+        T = eng.T
+        rs = np.random.default_rng(9)
+        poses = np.stack([rs.uniform(bounds[0] + 1, bounds[1] - 1, B), rs.uniform(bounds[2] + 1, bounds[3] - 1, B),
+                          rs.uniform(-3, 3, B)], 1)
+        d_pose = torch.as_tensor(poses).cuda()
+        d_ut = torch.zeros((B, T, 3), dtype=torch.float64, device="cuda")
+        d_u0 = torch.empty((B, 3), dtype=torch.float64, device="cuda")
+        sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+        torch.cuda.synchronize()
+        for step in range(3):   # the map grows on every step: a rebuild each time, then a control pass
+            b = (bounds[0], bounds[1] + 0.1 * step, bounds[2], bounds[3])
+            if form == "sync":
+                assert eng.config_domain(b, stream=sa.cuda_stream) is True
+                eng.control_batch(B, d_pose, d_ut, d_u0, stream=sa.cuda_stream)
+            elif form == "async_same_stream":
+                assert eng.config_domain_async(b, stream=sa.cuda_stream) is True
+                eng.control_batch(B, d_pose, d_ut, d_u0, stream=sa.cuda_stream)
+            else:
+                sa.wait_stream(sb)     # the caller's part: the rebuild follows the control pass still reading phi_k
+                assert eng.config_domain_async(b, stream=sa.cuda_stream) is True
+                eng.control_batch(B, d_pose, d_ut, d_u0, stream=sb.cuda_stream)
+        pk = eng.phik()                # waits for the last rebuild
+        torch.cuda.synchronize()
+        res[form] = (pk, d_u0.cpu().numpy().copy(), d_ut.cpu().numpy().copy())
+        eng.close()
+    for form in ("async_same_stream", "async_other_stream"):
+        for a, b_ in zip(res["sync"], res[form]):
+            assert np.array_equal(a, b_), form
+    assert np.isfinite(res["sync"][1]).all()
+
+
 def test_set_target_grid_entropy_surrogate():
     """BASELINE config 5 entry (reduced): explicit target grid from an int8 occupancy map through
     entropy() (numerics.hpp:164-179), normalised to sum 1 -> Basis::spatialCoeff."""
