@@ -191,9 +191,19 @@ def phik_legs(args, torch, capi, np):
     ms = ev0.elapsed_time(ev1) / reps
     nbytes = n * n * 8
     gbs = nbytes / (ms * 1e-3) / 1e9
+    traffic, traffic_source = None, "profiles/ (rocprofv3 --pmc passes, not collected in-run)"
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_phik_pmc.json")) as f:
+            rec = json.load(f)
+        if rec.get("grid") == n and rec.get("K") == K and rec.get("precision") == "f64":
+            traffic = rec["hbm_read_bytes_x2_corrected"]
+            traffic_source = ("profiles/r03_phik_pmc.json (separate rocprofv3 --pmc FETCH_SIZE pass of this workload, x2 "
+                              "gfx950 correction; NOT measured in this run)")
+    except Exception:
+        pass
     out["roofline_phik"] = {"bound": "hbm", "kernel": "spatial_stream_kernel (+ sum_partials_kernel)",
                             "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                            "traffic": None, "traffic_source": "profiles/ (rocprofv3 --pmc passes, not collected in-run)",
+                            "traffic": traffic, "traffic_source": traffic_source,
                             "bytes_per_launch": nbytes, "launch_ms": ms,
                             "workload": "Basis::spatialCoeff, %dx%d fp64 target grid (%.2f GB) resident in HBM, K=%d"
                                         % (n, n, nbytes / 1e9, K)}
@@ -619,7 +629,7 @@ def main():
         hbm_gbs = G * bytes_per_opt * Bl / launch_s / 1e9
         tflops = G * flops_per_opt * Bl / launch_s / 1e12
         traffic, traffic_source = None, None
-        for name in ("r02_control_pmc.json", "r01_control_pmc.json"):
+        for name in ("r03_control_pmc.json", "r02_control_pmc.json", "r01_control_pmc.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(pmc):
                 continue
@@ -634,6 +644,24 @@ def main():
                     break
             except Exception:
                 pass
+        # the rocprofv3 view of the same command shape (profiles/r03_bench_profile.json, written by
+        # tools/make_r03_profiles.py from a separate profiled run: NOT measured in this run)
+        profiled = {}
+        try:
+            with open(os.path.join(ROOT, "profiles", "r03_bench_profile.json")) as f:
+                rec = json.load(f)
+            if (rec.get("agents") == B and rec.get("T") == T and rec.get("K") == K and rec.get("precision") == args.precision
+                    and rec.get("concurrent_launches") == G and args.model == "simple_cart" and not args.n_mem):
+                profiled = {"kernel_avg_us_profiled": rec["kernel_avg_us_profiled"],
+                            "pass_period_us_profiled": rec["pass_period_us_from_trace"],
+                            "frac_profiled": G * flops_per_opt * rec["agents_per_launch"] /
+                                             (rec["kernel_avg_us_profiled"] * 1e-6) / 1e12 / VALU_F64_PEAK_TF,
+                            "effective_clock_ghz_profiled": rec.get("effective_clock_ghz"),
+                            "profiled_source": "profiles/r03_bench_profile.json (rocprofv3 --kernel-trace --stats of this "
+                                               "command shape, timed-region dispatches only; clock from the A/B library's "
+                                               "phase stamps; separate runs on another box of the pool)"}
+        except Exception:
+            pass
         vpeak = VALU_F32_PEAK_TF if f32 else VALU_F64_PEAK_TF
         out = {
             "metric": "receding-horizon optimisations/sec at K=10x10, T=200; 1/2/4/8-GPU agent-batch",
@@ -660,7 +688,7 @@ def main():
                          "achieved": tflops, "peak": vpeak, "unit": "TFLOP/s", "frac": tflops / vpeak,
                          "traffic": traffic, "traffic_source": traffic_source,
                          "flops_per_launch": flops_per_opt * Bl, "launch_ms": pass_ms, "agents_per_launch": Bl,
-                         "concurrent_launches": G, "achieved_per_launch": tflops / G,
+                         "concurrent_launches": G, "achieved_per_launch": tflops / G, **profiled,
                          "note": "the control kernel is vector-ALU / transcendental bound, not HBM bound (SURVEY.md "
                                  "8(d)); W = 2K^2N + 4K^2T + (4K+140)T flop per optimisation (reference formulation)"},
             "roofline_hbm": {"bound": "hbm", "kernel": "control kernel", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS,

@@ -794,15 +794,25 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
     // (I, J) with (I NB + J) % 4 == d: lane l = 16 i + 4 d + j holds c(k1 = 4 I + i, k2 = 4 J + j).
     const R invN = R(1) / static_cast<R>(N);
     const int di = lane >> 4, db = (lane >> 2) & 3, dj = lane & 3;
+    constexpr int TS = (NB * NB + 3) / 4;  // pairs per block copy
+    R cv[TS], lamv[TS], phiv[TS];
+    int idx[TS];
+    bool okv[TS];
+    // lambda_k, phi_k of this lane's entries first: the loads run under the rotations
+#pragma unroll
+    for (int t = 0; t < TS; ++t) {
+      const int pi = 4 * t + db, I = pi / NB, J = pi - NB * I;
+      const int k1 = 4 * I + di, k2 = 4 * J + dj;
+      okv[t] = pi < NB * NB && k1 < K && k2 < K;
+      idx[t] = okv[t] ? k2 * K + k1 : 0;
+      lamv[t] = p.lamdak[idx[t]];
+      phiv[t] = p.phik[idx[t]];
+    }
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
 #pragma unroll
       for (int J = 0; J < NB; ++J) cacc[I][J] = add_row_ror<8>(add_row_ror<4>(cacc[I][J]));
     }
-    constexpr int TS = (NB * NB + 3) / 4;  // pairs per block copy
-    R cv[TS], lamv[TS], phiv[TS];
-    int idx[TS];
-    bool okv[TS];
 #pragma unroll
     for (int t = 0; t < TS; ++t) {
       R v = cacc[(4 * t) / NB][(4 * t) % NB];
@@ -810,13 +820,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
       for (int d = 1; d < 4; ++d) {
         if (4 * t + d < NB * NB) v = (db == d) ? cacc[(4 * t + d) / NB][(4 * t + d) % NB] : v;
       }
-      const int pi = 4 * t + db, I = pi / NB, J = pi - NB * I;
-      const int k1 = 4 * I + di, k2 = 4 * J + dj;
-      okv[t] = pi < NB * NB && k1 < K && k2 < K;
-      idx[t] = okv[t] ? k2 * K + k1 : 0;
       cv[t] = invN * v;
-      lamv[t] = p.lamdak[idx[t]];
-      phiv[t] = p.phik[idx[t]];
       if (p.ck != nullptr && okv[t]) p.ck[static_cast<size_t>(b) * K2 + idx[t]] = cv[t];
     }
     if (p.ck_rec != nullptr) {  // wavefront-uniform: this agent's record [c_k, 1, pad] through LDS, coalesced

@@ -1,8 +1,9 @@
 #!/bin/bash
 # Round-3 evidence run (on the GPU box through gpurun): the default bench line, rocprofv3 kernel stats + PMC passes
 # of the SAME command shape (spin-up on, two agent groups) and of one launch per pass, the shader clock under
-# sustained load (phase stamps of the A/B library), phi_k counters at the bench's 16384^2 grid, parity report.
-# Output: gpurun_out/r03_evidence/  (copy what is to be judged into profiles/)
+# sustained load (phase stamps of the A/B library), phi_k counters at the bench's 16384^2 grid, parity report,
+# exchange cost breakdown, the other BASELINE shapes.
+# Output: gpurun_out/r03_evidence/  (tools/make_r03_profiles.py copies what is to be judged into profiles/)
 set -u
 OUT=gpurun_out/r03_evidence
 mkdir -p "$OUT"
@@ -19,5 +20,7 @@ EEA_PHASE_WARMUP=1000 python3 tools/phase_timing.py 4096 > "$OUT/phase_timing.tx
 EEA_PHASE_WARMUP=1000 python3 tools/phase_timing.py 2048 >> "$OUT/phase_timing.txt" 2>&1
 PHIK_CASES="16384:10:f64" bash tools/phik_pmc.sh > "$OUT/phik_pmc.txt" 2>&1
 python3 tools/parity_report.py > "$OUT/parity_report.txt" 2>&1
-python3 tools/rebuild_bench.py > "$OUT/rebuild.txt" 2>&1
+EEA_PRINT_WORST=1 python3 -m pytest tests/test_analytic_checks.py -m gpu -q -s 2>&1 | grep -E "digits|passed|failed" > "$OUT/analytic_checks.txt"
+python3 tools/ck_cost.py > "$OUT/ck_cost.txt" 2>&1
+bash tools/config_sweep.sh > "$OUT/config_sweep.txt" 2>&1
 ls -la "$OUT"
