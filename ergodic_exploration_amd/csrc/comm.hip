@@ -113,6 +113,11 @@ hipError_t launch_ck_mean(const void* d_sums, int K2, void* d_out, hipStream_t s
 }
 }  // namespace
 
+// Events that only order device streams among each other: no timing, and NO system-scope fence when they complete.
+// The default event makes the kernel in front of it write the device's caches back for the host's benefit -- behind a
+// control kernel that is 20 MB of dirty controls per completion (measured: tools/ck_cost.py).
+constexpr unsigned kDeviceEvent = hipEventDisableTiming | hipEventDisableSystemFence;
+
 struct eea_comm
 {
   ncclComm_t comm = nullptr;
@@ -283,9 +288,9 @@ eea_status async_begin(eea_comm* c, void* compute_stream, int slot, bool order_a
     int least = 0, greatest = 0;
     EEA_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
     EEA_HIP(hipStreamCreateWithPriority(&c->xstream, hipStreamNonBlocking, greatest));
-    EEA_HIP(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+    EEA_HIP(hipEventCreateWithFlags(&c->ev_in, kDeviceEvent));
   }
-  if (c->ev_done[slot] == nullptr) EEA_HIP(hipEventCreateWithFlags(&c->ev_done[slot], hipEventDisableTiming));
+  if (c->ev_done[slot] == nullptr) EEA_HIP(hipEventCreateWithFlags(&c->ev_done[slot], kDeviceEvent));
   if (!order_after_compute) return EEA_OK;
   // everything enqueued on the compute stream so far (the pass that produced c_k) comes first
   EEA_HIP(hipEventRecord(c->ev_in, static_cast<hipStream_t>(compute_stream)));
@@ -339,10 +344,14 @@ eea_status eea_comm_control_groups(eea_engine* e, eea_comm* c, unsigned n_groups
   EEA_HIP(hipSetDevice(c->device));
   c->groups_launched = 0;
   for (unsigned g = 0; g < n_groups; ++g) {
-    if (c->ev_group[g] == nullptr) EEA_HIP(hipEventCreateWithFlags(&c->ev_group[g], hipEventDisableTiming));
+    if (c->ev_group[g] == nullptr) EEA_HIP(hipEventCreateWithFlags(&c->ev_group[g], kDeviceEvent));
     if (B[g] == 0) continue;
     hipStream_t s = static_cast<hipStream_t>(group_streams[g]);
-    if (wait_slot >= 0 && c->ev_done[wait_slot] != nullptr) EEA_HIP(hipStreamWaitEvent(s, c->ev_done[wait_slot], 0));
+    // behind the exchange it consumes -- unless that has long finished (the usual case at a lag of 3 passes): a wait
+    // on a completed event still costs the host ~3 us and the stream a barrier packet in front of the kernel
+    if (wait_slot >= 0 && c->ev_done[wait_slot] != nullptr && hipEventQuery(c->ev_done[wait_slot]) != hipSuccess) {
+      EEA_HIP(hipStreamWaitEvent(s, c->ev_done[wait_slot], 0));
+    }
     eea::set_stop_event(c->ev_group[g]);  // bound to the control kernel of this call
     const eea_status st = eea_control_batch(e, B[g], &ios[g], group_streams[g]);
     (void)eea::take_stop_event();         // (not consumed if the call failed before its launch)
@@ -393,6 +402,7 @@ eea_status eea_comm_wait(eea_comm* c, int slot, void* stream)
 {
   if (c == nullptr || slot < 0 || slot >= EEA_COMM_SLOTS) return fail(EEA_ERR_INVALID_ARGUMENT, "bad communicator / slot");
   if (c->ev_done[slot] == nullptr) return EEA_OK;  // nothing was ever started in this slot
+  if (hipEventQuery(c->ev_done[slot]) == hipSuccess) return EEA_OK;  // already finished: nothing to wait for
   EEA_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), c->ev_done[slot], 0));
   return EEA_OK;
 }

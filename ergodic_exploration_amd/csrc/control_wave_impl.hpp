@@ -136,12 +136,8 @@ __device__ __forceinline__ float mfma4(float, float, float c) { return c; }  // 
 template <int N>
 __device__ __forceinline__ double add_row_ror(double v)
 {
-  int lo = __double2loint(v), hi = __double2hiint(v);
-  lo = __builtin_amdgcn_update_dpp(0, lo, 0x120 + N, 0xf, 0xf, false);
-  hi = __builtin_amdgcn_update_dpp(0, hi, 0x120 + N, 0xf, 0xf, false);
-  return v + __hiloint2double(hi, lo);
+  return v + dpp_or_zero<0x120 + N, 0xf>(v);  // row_ror:N, every lane has a source (bound_ctrl: no "old" operand to set up)
 }
-__device__ __forceinline__ float add_row_ror4(float v) { return v; }
 
 template <typename R, int MODEL>
 __device__ __forceinline__ void model_xy(R vx, R vy, R c, R s, R& fx, R& fy)

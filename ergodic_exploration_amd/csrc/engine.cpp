@@ -364,7 +364,7 @@ eea_status rebuild_phik(eea_engine* e, hipStream_t s, bool wait)
   }
   // phi_k = spatialCoeff(phi / sum(phi)) = spatialCoeff(phi) / sum(phi)  (target.cpp:87, basis.cpp:122-133)
   // enqueue-only form: the event other streams (and the getters) wait for is bound to the last launch itself
-  if (!wait && e->ev_rebuild == nullptr) EEA_HIP(hipEventCreateWithFlags(&e->ev_rebuild, hipEventDisableTiming));
+  if (!wait && e->ev_rebuild == nullptr) EEA_HIP(hipEventCreateWithFlags(&e->ev_rebuild, hipEventDisableTiming | hipEventDisableSystemFence));
   EEA_HIP(eea::launch_spatial_coeff_normalised<R>(static_cast<const R*>(e->d_phi.p), nx, ny, e->K,
                                                   static_cast<const R*>(e->d_cx.p), static_cast<const R*>(e->d_cy.p),
                                                   static_cast<R*>(e->d_work.p), static_cast<R*>(e->d_phik.p),

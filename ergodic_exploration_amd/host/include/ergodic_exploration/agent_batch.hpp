@@ -61,10 +61,10 @@ public:
       hip_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
       streams_.push_back(s);
       hipEvent_t ev = nullptr;
-      hip_check(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      hip_check(hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence));  // orders streams only
       ev_group_.push_back(ev);
     }
-    hip_check(hipEventCreateWithFlags(&ev_exchange_, hipEventDisableTiming));
+    hip_check(hipEventCreateWithFlags(&ev_exchange_, hipEventDisableTiming | hipEventDisableSystemFence));
     if (comm_ == nullptr) {  // local communicator: the consensus is the mean over this rank's agents
       eea_comm* c = nullptr;
       throw_on_error(eea_comm_create(device_ordinal(), 1, 0, nullptr, &c));
