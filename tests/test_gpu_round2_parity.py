@@ -247,6 +247,59 @@ def test_shared_ck_as_sum_records(K, horizon):
     eng.close()
 
 
+@pytest.mark.parametrize("lag", [1, 3])
+def test_consensus_pass_through_the_exchange_calls(lag):
+    """The consensus loop as bench.py and a C++ host issue it -- eea_comm_control_groups (two agent groups on two streams,
+    each launch behind the exchange it consumes) + eea_comm_records_exchange_async (record sum + all-reduce on the
+    communicator's own stream, completion slots) -- against the same passes issued one call at a time on one stream
+    with explicit synchronisation: bitwise the same controls and sum records after 7 passes."""
+    rng = np.random.default_rng(17)
+    B, K, G, NB, passes = 300, 10, 2, 6, 7
+    eng, _ = make_pair("omni", K, 20.0, n_oracles=0)
+    T, K2, L = eng.T, eng.K2, eng.ck_record_len
+    poses = random_poses(rng, B)
+    ut0 = rng.uniform(-0.3, 0.3, (B, T, 3))
+    d_pose = dev(poses)
+    gb = [0, 130, B]
+
+    # (a) reference sequence: one stream, synchronised after every call
+    ut_a, u0_a = dev(ut0), torch.empty((B, 3), dtype=torch.float64, device="cuda")
+    arec = torch.zeros((B, L), dtype=torch.float64, device="cuda")
+    sums_a = [torch.zeros((L,), dtype=torch.float64, device="cuda") for _ in range(passes)]
+    for i in range(passes):
+        src = i - lag
+        for g in range(G):
+            sl = slice(gb[g], gb[g + 1])
+            eng.control_batch(gb[g + 1] - gb[g], d_pose[sl], ut_a[sl], u0_a[sl], ck_rec=arec[sl],
+                              ck_shared=sums_a[src] if src >= 0 else None, ck_shared_parts=1 if src >= 0 else 0)
+        torch.cuda.synchronize()
+        eng.ck_records_sum(B, arec, sums_a[i])
+        torch.cuda.synchronize()
+
+    # (b) the exchange calls: nothing but the two C-ABI calls per pass, no host synchronisation in between
+    comm = capi.Comm(0, 1, 0, None)
+    streams = [torch.cuda.Stream() for _ in range(G)]
+    ut_b, u0_b = dev(ut0), torch.empty((B, 3), dtype=torch.float64, device="cuda")
+    arecs = [torch.zeros((B, L), dtype=torch.float64, device="cuda") for _ in range(NB)]
+    sums_b = [torch.zeros((L,), dtype=torch.float64, device="cuda") for _ in range(NB)]
+    torch.cuda.synchronize()
+    for i in range(passes):
+        slot, src = i % NB, (i - lag) % NB if i >= lag else None
+        groups = [dict(B=gb[g + 1] - gb[g], pose=d_pose[gb[g]:gb[g + 1]], ut=ut_b[gb[g]:gb[g + 1]], u0=u0_b[gb[g]:gb[g + 1]],
+                       stream=streams[g].cuda_stream, ck_rec=arecs[slot][gb[g]:gb[g + 1]],
+                       ck_shared=None if src is None else sums_b[src], ck_shared_parts=0 if src is None else 1)
+                  for g in range(G)]
+        comm.prepared_control_groups(eng, groups, -1 if src is None else src)()
+        comm.records_exchange_async(eng, B, arecs[slot], sums_b[slot], [st.cuda_stream for st in streams], slot)
+    torch.cuda.synchronize()
+    assert torch.equal(ut_a, ut_b) and torch.equal(u0_a, u0_b)
+    last = passes - 1
+    assert torch.equal(sums_a[last], sums_b[last % NB])
+    assert float(sums_a[last][K2]) == B
+    comm.close()
+    eng.close()
+
+
 @pytest.mark.parametrize("model", ["simple_cart", "omni"])
 def test_config4_full_size_against_oracle(model):
     """BASELINE config 4 at full size: every one of the 4096 agents' u0 and warm-start matrix ut after two
