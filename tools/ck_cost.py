@@ -24,7 +24,7 @@ d_rec = [torch.zeros((L,), dtype=torch.float64, device="cuda") for _ in range(NB
 for r in d_rec:
     r[K2] = 1.0
 streams = [torch.cuda.Stream() for _ in range(G)]
-xs = torch.cuda.Stream(priority=int(os.environ.get("XPRIO", "0")))
+xs = torch.cuda.Stream()   # the torch-stream variants below: normal priority first, highest priority afterwards
 gb = [(g * B) // G for g in range(G + 1)]
 ev_g = [[torch.cuda.Event() for _ in range(G)] for _ in range(NB)]
 ev_x = [torch.cuda.Event() for _ in range(NB)]
@@ -151,10 +151,13 @@ run("plain (two groups)", plain)
 run("+ per-agent records out", rec_out)
 run("+ sum record in (ck_shared_parts = 1)", rec_in)
 run("+ both", rec_in_out)
-run("+ record sum on the exchange stream, unordered", with_sum_unordered)
-run("+ exchange stream ordered after the groups", with_sum_after_groups)
-run("+ consumers wait for the exchange (lag 2) = bench leg", full)
-run("  the same with lag 3", lambda i: full(i, 3))
+for prio, label in ((0, "normal stream priority"), (-1, "highest stream priority")):
+    xs = torch.cuda.Stream(priority=prio)
+    run("+ record sum on the exchange stream, unordered [%s]" % label, with_sum_unordered)
+    run("+ exchange stream ordered after the groups (torch events) [%s]" % label, with_sum_after_groups)
+    run("+ consumers wait for the exchange, lag 2 (torch events) [%s]" % label, full)
+    run("  the same with lag 3 [%s]" % label, lambda i: full(i, 3))
+print("through the C ABI (the communicator's own highest-priority stream, completion events bound to the kernels):")
 run("one C call per pass (records_exchange_async), lag 2", lambda i: full_c(i, 2))
 run("one C call per pass (records_exchange_async), lag 3", lambda i: full_c(i, 3))
 run("one C call per pass (records_exchange_async), lag 4", lambda i: full_c(i, 4))
