@@ -461,6 +461,7 @@ def main():
                 comm = capi.Comm(device, 1, 0, capi.comm_unique_id())
                 exchange_backend = "rccl through the C ABI (eea_comm_*), one rank"
             xcomm = comm if comm is not None else capi.Comm(device, 1, 0, None)
+            xcomm.host_thread(True)   # the exchange's HIP calls on the communicator's own host thread
             return
         if args.no_exchange:
             return
@@ -490,6 +491,7 @@ def main():
         if int(flag.item()):
             exchange_backend = "rccl through the C ABI (eea_comm_*)"
             xcomm = comm
+            xcomm.host_thread(True)
         else:
             if comm is not None:
                 comm.close()
@@ -523,7 +525,7 @@ def main():
                                    ck_rec=d_arec[slot][gb[g]:gb[g + 1]],
                                    ck_shared=None if src is None else d_rec[src],
                                    ck_shared_parts=0 if src is None else 1) for g, a in enumerate(gargs)]
-                    call = exch_calls[(slot, src)] = xcomm.prepared_control_groups(eng, groups, -1 if src is None else src)
+                    call = exch_calls[(slot, src)] = xcomm.prepared_control_groups(eng, groups, -1 if src is None else src, slot)
                 call()
                 exchange_records(slot)
                 return
@@ -598,6 +600,8 @@ def main():
         for _ in range(steps * Rl):
             one_pass(leg)
         join_groups()         # the end event follows the last pass of EVERY agent group
+        if leg == "consensus" and xcomm is not None:
+            xcomm.flush()     # exchanges still queued on the communicator's host thread are issued
         ev1.record(compute)
         enqueue_s = time.perf_counter() - t0
         torch.cuda.synchronize()  # all streams of the device

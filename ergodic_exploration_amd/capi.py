@@ -141,7 +141,10 @@ def lib():
         L.eea_comm_records_exchange_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p,
                                                       C.c_void_p, C.c_uint, C.c_int]
         L.eea_comm_wait.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-        L.eea_comm_control_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.eea_comm_control_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                              C.c_int]
+        L.eea_comm_host_thread.argtypes = [C.c_void_p, C.c_int]
+        L.eea_comm_flush.argtypes = [C.c_void_p]
         L.eea_comm_allreduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
         L.eea_comm_consensus_ck_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.eea_comm_allgather_ck_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -529,7 +532,15 @@ class Comm:
                 check(rc)
         return call
 
-    def prepared_control_groups(self, eng, groups, wait_slot):
+    def host_thread(self, on=True):
+        """eea_comm_host_thread: the exchange's HIP calls issued by a thread the communicator owns"""
+        check(lib().eea_comm_host_thread(self.h, 1 if on else 0))
+
+    def flush(self):
+        """eea_comm_flush: every queued exchange has been issued to the device (call before a host synchronisation)"""
+        check(lib().eea_comm_flush(self.h))
+
+    def prepared_control_groups(self, eng, groups, wait_slot, exchange_slot=-1):
         """eea_comm_control_groups as a callable: groups = [dict(B, pose, ut, u0, stream, mem_cols, n_mem, mem_stride, ck,
         ck_rec, ck_shared, ck_shared_parts)]; the eea_batch_io array is built once"""
         n = len(groups)
@@ -543,7 +554,7 @@ class Comm:
             io.d_ck, io.d_ck_rec = _ptr(g.get("ck")), _ptr(g.get("ck_rec"))
             io.d_ck_shared, io.ck_shared_parts = _ptr(g.get("ck_shared")), g.get("ck_shared_parts", 0)
             keep.append(dict(g))
-        fn, args = lib().eea_comm_control_groups, (eng.h, self.h, n, Bs, ios, streams, wait_slot)
+        fn, args = lib().eea_comm_control_groups, (eng.h, self.h, n, Bs, ios, streams, wait_slot, exchange_slot)
 
         def call(_keep=keep):
             rc = fn(*args)

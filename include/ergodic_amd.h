@@ -267,17 +267,25 @@ eea_status eea_comm_records_exchange_async(eea_engine* e, eea_comm* c, unsigned 
                                            void* d_sum, void* const* group_streams, unsigned n_streams, int slot);
 /* The control calls of one pass of such a batch in one call (a pass of 4096 agents takes ~25 us on the device: the host
  * must issue it in less): for every agent group g, eea_comm_wait(c, wait_slot, group_streams[g]) -- skipped when
- * wait_slot < 0 -- and eea_control_batch(e, B[g], &ios[g], group_streams[g]). */
+ * wait_slot < 0 -- and eea_control_batch(e, B[g], &ios[g], group_streams[g]).  exchange_slot >= 0: the slot of the
+ * eea_comm_records_exchange_async call that follows for this pass; the groups' kernels then carry the completion events
+ * that exchange waits for (no separate event records). */
 eea_status eea_comm_control_groups(eea_engine* e, eea_comm* c, unsigned n_groups, const unsigned* B,
-                                   const eea_batch_io* ios, void* const* group_streams, int wait_slot);
-/* asynchronous in-place all-reduce (sum) of n reals on the communicator's own stream, ordered after `compute_stream`
- * like the forms above: the sum records of the agent groups of one pass (eea_ck_records_sum) in ONE collective;
- * one rank: no collective, only the ordering */
-eea_status eea_comm_allreduce_sum_async(eea_engine* e, eea_comm* c, void* d_buf, unsigned n, void* compute_stream,
-                                        int slot);
+                                   const eea_batch_io* ios, void* const* group_streams, int wait_slot, int exchange_slot);
+/* on != 0: the HIP calls of eea_comm_records_exchange_async are issued by a host thread the communicator owns (the call
+ * itself only queues a request), so that the caller's thread spends its time on the control launches; eea_comm_wait and
+ * eea_comm_control_groups make sure the thread has issued the exchange they refer to.  The thread spins while exchanges
+ * keep coming and yields when idle; on == 0 (default) stops it. */
+eea_status eea_comm_host_thread(eea_comm* c, int on);
+/* returns once every exchange queued so far has been ISSUED to the device (a no-op without the host thread): call it
+ * before a host-side synchronisation (hipStreamSynchronize / hipDeviceSynchronize) that is meant to cover them */
+eea_status eea_comm_flush(eea_comm* c);
 /* in-place ncclAllReduce(sum) of n reals: the K^2 partial sums of a grid-tiled phi_k
  * (eea_spatial_coeff_rows / eea_spatial_coeff_occupancy_rows) */
 eea_status eea_comm_allreduce_sum(eea_engine* e, eea_comm* c, void* d_buf, unsigned n, void* stream);
+/* the same on the communicator's own stream, ordered after `compute_stream` like the asynchronous forms above */
+eea_status eea_comm_allreduce_sum_async(eea_engine* e, eea_comm* c, void* d_buf, unsigned n, void* compute_stream,
+                                        int slot);
 
 /* ---- single agent, host pointers (what ErgodicControl<ModelT>::control binds to) ---- */
 /* vec control(const GridMap& grid, const vec& x) (ergodic_control.hpp:224-311) including

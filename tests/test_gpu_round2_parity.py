@@ -247,8 +247,8 @@ def test_shared_ck_as_sum_records(K, horizon):
     eng.close()
 
 
-@pytest.mark.parametrize("lag", [1, 3])
-def test_consensus_pass_through_the_exchange_calls(lag):
+@pytest.mark.parametrize("lag,host_thread", [(1, False), (3, False), (1, True), (3, True)])
+def test_consensus_pass_through_the_exchange_calls(lag, host_thread):
     """The consensus loop as bench.py and a C++ host issue it -- eea_comm_control_groups (two agent groups on two streams,
     each launch behind the exchange it consumes) + eea_comm_records_exchange_async (record sum + all-reduce on the
     communicator's own stream, completion slots) -- against the same passes issued one call at a time on one stream
@@ -278,6 +278,8 @@ def test_consensus_pass_through_the_exchange_calls(lag):
 
     # (b) the exchange calls: nothing but the two C-ABI calls per pass, no host synchronisation in between
     comm = capi.Comm(0, 1, 0, None)
+    if host_thread:
+        comm.host_thread(True)   # the exchange's HIP calls issued by the communicator's own thread
     streams = [torch.cuda.Stream() for _ in range(G)]
     ut_b, u0_b = dev(ut0), torch.empty((B, 3), dtype=torch.float64, device="cuda")
     arecs = [torch.zeros((B, L), dtype=torch.float64, device="cuda") for _ in range(NB)]
@@ -289,8 +291,9 @@ def test_consensus_pass_through_the_exchange_calls(lag):
                        stream=streams[g].cuda_stream, ck_rec=arecs[slot][gb[g]:gb[g + 1]],
                        ck_shared=None if src is None else sums_b[src], ck_shared_parts=0 if src is None else 1)
                   for g in range(G)]
-        comm.prepared_control_groups(eng, groups, -1 if src is None else src)()
+        comm.prepared_control_groups(eng, groups, -1 if src is None else src, slot)()
         comm.records_exchange_async(eng, B, arecs[slot], sums_b[slot], [st.cuda_stream for st in streams], slot)
+    comm.flush()               # (host thread: the last exchanges may still be queued on the host side)
     torch.cuda.synchronize()
     assert torch.equal(ut_a, ut_b) and torch.equal(u0_a, u0_b)
     last = passes - 1

@@ -18,11 +18,12 @@ poses = np.stack([rng.uniform(-0.5, 10.5, B), rng.uniform(-0.5, 4.5, B), rng.uni
 d_pose = torch.as_tensor(poses).cuda()
 d_ut = torch.zeros((B, T, 3), dtype=torch.float64, device="cuda")
 d_u0 = torch.empty((B, 3), dtype=torch.float64, device="cuda")
-NB = 6
+NB = 8
 d_arec = [torch.zeros((B, L), dtype=torch.float64, device="cuda") for _ in range(NB)]
 d_rec = [torch.zeros((L,), dtype=torch.float64, device="cuda") for _ in range(NB)]
 for r in d_rec:
     r[K2] = 1.0
+comm = capi.Comm(0, 1, 0, None)   # local communicator: its own highest-priority exchange stream, no RCCL
 streams = [torch.cuda.Stream() for _ in range(G)]
 xs = torch.cuda.Stream()   # the torch-stream variants below: normal priority first, highest priority afterwards
 gb = [(g * B) // G for g in range(G + 1)]
@@ -53,6 +54,7 @@ def run(name, f, n=3000):
     for i in range(n):
         f(i)
     enq = time.perf_counter() - t0
+    comm.flush()
     for g in range(1, G):
         e = torch.cuda.Event()
         e.record(streams[g])
@@ -112,7 +114,6 @@ def full(i, lag=2):
     ev_x[s].record(xs)
 
 
-comm = capi.Comm(0, 1, 0, None)   # local communicator: its own highest-priority exchange stream, no RCCL
 xc = {}
 
 
@@ -131,16 +132,22 @@ def full_c(i, lag=3, NBc=6):   # the same through ONE C-ABI call per pass (eea_c
     x()
 
 
-def full_c2(i, lag=3, NBc=6):   # two C-ABI calls per pass: eea_comm_control_groups + eea_comm_records_exchange_async
+def full_c2(i, lag=3, NBc=8, events=True, exchange=True, wait=True):
+    """two C-ABI calls per pass: eea_comm_control_groups + eea_comm_records_exchange_async; the flags take pieces out:
+    events = the groups' kernels carry completion events, exchange = the exchange call is made, wait = the groups'
+    launches wait for the exchange they consume"""
     s, src = i % NBc, (i - lag) % NBc
-    key = ("g", s, src if i >= lag else None)
+    use = i >= lag
+    key = ("g", s, src if use else None, events, wait)
     c = xc.get(key)
     if c is None:
         groups = [dict(B=gb[g + 1] - gb[g], pose=d_pose[gb[g]:gb[g + 1]], ut=d_ut[gb[g]:gb[g + 1]], u0=d_u0[gb[g]:gb[g + 1]],
                        stream=streams[g].cuda_stream, ck_rec=d_arec[s][gb[g]:gb[g + 1]],
-                       ck_shared=d_rec[src] if i >= lag else None, ck_shared_parts=1 if i >= lag else 0) for g in range(G)]
-        c = xc[key] = comm.prepared_control_groups(eng, groups, src if i >= lag else -1)
+                       ck_shared=d_rec[src] if use else None, ck_shared_parts=1 if use else 0) for g in range(G)]
+        c = xc[key] = comm.prepared_control_groups(eng, groups, src if (use and wait) else -1, s if events else -1)
     c()
+    if not exchange:
+        return
     x = xc.get(s)
     if x is None:
         x = xc[s] = comm.prepared_records_exchange(eng, B, d_arec[s], d_rec[s], [st.cuda_stream for st in streams], s)
@@ -161,6 +168,18 @@ print("through the C ABI (the communicator's own highest-priority stream, comple
 run("one C call per pass (records_exchange_async), lag 2", lambda i: full_c(i, 2))
 run("one C call per pass (records_exchange_async), lag 3", lambda i: full_c(i, 3))
 run("one C call per pass (records_exchange_async), lag 4", lambda i: full_c(i, 4))
+run("control_groups only, plain launches (no events, no exchange)", lambda i: full_c2(i, 3, events=False, exchange=False, wait=False))
+run("control_groups only, kernels carry completion events", lambda i: full_c2(i, 3, exchange=False, wait=False))
+run("+ exchange (ordered after the groups), nobody waits for it", lambda i: full_c2(i, 3, wait=False))
 run("two C calls per pass (control_groups + exchange), lag 2", lambda i: full_c2(i, 2))
 run("two C calls per pass (control_groups + exchange), lag 3", lambda i: full_c2(i, 3))
 run("two C calls per pass (control_groups + exchange), lag 4", lambda i: full_c2(i, 4))
+comm.host_thread(True)
+xc.clear()
+print("the same with the exchange's HIP calls on the communicator's host thread (eea_comm_host_thread):")
+run("two C calls per pass + host thread, lag 2", lambda i: full_c2(i, 2))
+run("two C calls per pass + host thread, lag 3", lambda i: full_c2(i, 3))
+run("two C calls per pass + host thread, lag 4", lambda i: full_c2(i, 4))
+run("two C calls per pass + host thread, lag 5", lambda i: full_c2(i, 5))
+run("two C calls per pass + host thread, lag 6", lambda i: full_c2(i, 6))
+comm.host_thread(False)
