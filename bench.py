@@ -70,6 +70,8 @@ def parse():
                          "execution slots when the kernels of pass i + 1 finish, and the host issues the exchange calls "
                          "about as fast as the device runs a pass (tools/ck_cost.py: 50 / 38 / 34.5 us per pass at lag "
                          "2 / 3 / 4 on one GPU)")
+    ap.add_argument("--consensus-buffers", type=int, default=8, choices=range(3, 9),
+                    help="record / sum buffers (and exchange slots) the consensus leg rotates through")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per leg; 0 = skip")
     ap.add_argument("--no-latency", action="store_true", help="skip the B = 1 dependent-call leg")
     ap.add_argument("--no-phik", action="store_true", help="skip the phi_k legs (roofline_phik)")
@@ -392,7 +394,7 @@ def main():
     # launch on the exchange stream adds them (eea_ck_records_sum: sums + agent count), ONE collective adds the ranks'
     # records (nothing with one rank), and pass i + lag divides sum by count inside the kernel (ck_shared_parts = 1):
     # one launch of 2 wavefronts per 64 agents beside the compute streams instead of three dependent launches.
-    NB = args.consensus_lag + 2  # record buffers in flight: pass i writes buffer i % NB and reads (i - lag) % NB; the
+    NB = max(args.consensus_lag + 2, args.consensus_buffers)  # record buffers in flight: pass i writes buffer i % NB and reads (i - lag) % NB; the
     #                              earlier readers of buffer i % NB (pass i - 2) have finished before pass i starts (it
     #                              waits for the exchange of pass i - lag >= their own)
     L = eng.ck_record_len
