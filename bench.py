@@ -65,11 +65,10 @@ def parse():
                     help="skip the exchange legs (consensus all-reduce, c_k all-gather)")
     ap.add_argument("--force-exchange", "--force-gather", dest="force_exchange", action="store_true",
                     help="run the all-gather leg even with one rank (single-rank RCCL communicator)")
-    ap.add_argument("--consensus-lag", type=int, default=3, choices=[1, 2, 3, 4, 5],
+    ap.add_argument("--consensus-lag", type=int, default=4, choices=[1, 2, 3, 4, 5],
                     help="passes between producing c_k and consuming its consensus: the record sum of pass i gets its "
-                         "execution slots when the kernels of pass i + 1 finish, and the host issues the exchange calls "
-                         "about as fast as the device runs a pass (tools/ck_cost.py: 50 / 38 / 34.5 us per pass at lag "
-                         "2 / 3 / 4 on one GPU)")
+                         "execution slots when the kernels of pass i + 1 finish, and the host launches pass i + lag only "
+                         "once that exchange has completed (tools/ck_cost.py: 34 / 30 / 30 us per pass at lag 2 / 3 / 4)")
     ap.add_argument("--consensus-buffers", type=int, default=8, choices=range(3, 9),
                     help="record / sum buffers (and exchange slots) the consensus leg rotates through")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per leg; 0 = skip")
@@ -394,7 +393,7 @@ def main():
     # launch on the exchange stream adds them (eea_ck_records_sum: sums + agent count), ONE collective adds the ranks'
     # records (nothing with one rank), and pass i + lag divides sum by count inside the kernel (ck_shared_parts = 1):
     # one launch of 2 wavefronts per 64 agents beside the compute streams instead of three dependent launches.
-    NB = max(args.consensus_lag + 2, args.consensus_buffers)  # record buffers in flight: pass i writes buffer i % NB and reads (i - lag) % NB; the
+    NB = min(8, max(args.consensus_lag + 2, args.consensus_buffers))  # record buffers in flight: pass i writes buffer i % NB and reads (i - lag) % NB; the
     #                              earlier readers of buffer i % NB (pass i - 2) have finished before pass i starts (it
     #                              waits for the exchange of pass i - lag >= their own)
     L = eng.ck_record_len
