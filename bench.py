@@ -491,8 +491,7 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()):
             exchange_backend = "rccl through the C ABI (eea_comm_*)"
-            xcomm = comm
-            xcomm.host_thread(True)
+            xcomm = comm   # (no host thread here: every RCCL call of this process stays on the thread that made the communicator)
         else:
             if comm is not None:
                 comm.close()
