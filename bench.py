@@ -69,6 +69,8 @@ def parse():
                     help="passes between producing c_k and consuming its consensus: the record sum of pass i gets its "
                          "execution slots when the kernels of pass i + 1 finish, and the host launches pass i + lag only "
                          "once that exchange has completed (tools/ck_cost.py: 34 / 30 / 30 us per pass at lag 2 / 3 / 4)")
+    ap.add_argument("--exchange-host-thread", action="store_true",
+                    help="one rank: the exchange's HIP calls on the communicator's host thread (eea_comm_host_thread)")
     ap.add_argument("--consensus-buffers", type=int, default=8, choices=range(3, 9),
                     help="record / sum buffers (and exchange slots) the consensus leg rotates through")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per leg; 0 = skip")
@@ -462,7 +464,8 @@ def main():
                 comm = capi.Comm(device, 1, 0, capi.comm_unique_id())
                 exchange_backend = "rccl through the C ABI (eea_comm_*), one rank"
             xcomm = comm if comm is not None else capi.Comm(device, 1, 0, None)
-            xcomm.host_thread(True)   # the exchange's HIP calls on the communicator's own host thread
+            if args.exchange_host_thread:   # the exchange's HIP calls on the communicator's own host thread
+                xcomm.host_thread(True)
             return
         if args.no_exchange:
             return

@@ -380,11 +380,21 @@ void ensure_issued(eea_comm* c, int slot)
   while (c->issued.load(std::memory_order_acquire) < want) __builtin_ia32_pause();
 }
 
-// the HIP calls of one exchange: the exchange stream behind the groups' kernels, record sum, all-reduce, completion event
-eea_status issue_exchange(eea_comm* c, const eea_comm::Req& r)
+// the HIP calls of one exchange: the exchange stream behind the groups' kernels, record sum, all-reduce, completion event.
+// paced (the communicator's host thread): the thread polls the completion of the groups' kernels itself -- it has nothing
+// else to do -- and the exchange stream carries no barrier packet either; a group that is very late gets a stream wait
+eea_status issue_exchange(eea_comm* c, const eea_comm::Req& r, bool paced)
 {
   for (unsigned g = 0; g < eea_comm::kMaxGroups; ++g) {
-    if (r.mask & (1u << g)) EEA_HIP(hipStreamWaitEvent(c->xstream, c->ev_group[r.slot][g], 0));
+    if (!(r.mask & (1u << g))) continue;
+    bool done = false;
+    for (int spin = 0; paced && spin < 4000 && !done; ++spin) {
+      done = hipEventQuery(c->ev_group[r.slot][g]) == hipSuccess;
+      if (!done) {
+        for (int k = 0; k < 16; ++k) __builtin_ia32_pause();  // leave the runtime's locks to the launching thread
+      }
+    }
+    if (!done) EEA_HIP(hipStreamWaitEvent(c->xstream, c->ev_group[r.slot][g], 0));
   }
   const bool collective = c->comm != nullptr;
   if (!collective) eea::set_stop_event(c->ev_done[r.slot]);  // the record sum is the last step: its kernel carries the event
@@ -406,7 +416,7 @@ void worker_main(eea_comm* c)
   while (!c->stop.load(std::memory_order_acquire)) {
     const unsigned long n = c->issued.load(std::memory_order_relaxed);
     if (c->submitted.load(std::memory_order_acquire) > n) {
-      const eea_status st = issue_exchange(c, c->ring[n % eea_comm::kRing]);
+      const eea_status st = issue_exchange(c, c->ring[n % eea_comm::kRing], true);
       if (st != EEA_OK) c->worker_status.store(st, std::memory_order_relaxed);
       c->issued.store(n + 1, std::memory_order_release);
       idle = 0;
@@ -519,7 +529,7 @@ eea_status eea_comm_records_exchange_async(eea_engine* e, eea_comm* c, unsigned 
       r.mask |= 1u << g;
     }
   }
-  if (!c->host_thread) return issue_exchange(c, r);
+  if (!c->host_thread) return issue_exchange(c, r, false);
   // hand the HIP calls to the worker thread
   const unsigned long n = c->submitted.load(std::memory_order_relaxed);
   while (n - c->issued.load(std::memory_order_acquire) >= eea_comm::kRing) __builtin_ia32_pause();

@@ -12,7 +12,7 @@ namespace eea
 constexpr int kBlock = 256;    // threads per workgroup: 4 wavefronts of 64 lanes
 constexpr int kWave = 64;
 constexpr int kMaxBasis = 32;  // K <= 32 (K^2 <= 1024 modes)
-constexpr unsigned kSumGroup = 64;  // agents per first-level group of the in-kernel c_k sums
+constexpr unsigned kSumGroup = 32, kSumFan = 8;  // record sum: agents per level-0 unit, level-0 records per level-1 record
 __host__ __device__ constexpr int ck_record_len(int K2) { return (K2 + 2) & ~1; }
 
 // numerics.hpp:59 of the reference
@@ -86,10 +86,22 @@ bool control_wave_eligible(const ControlParams<R>& p, bool rollout_only);
 template <typename R>
 hipError_t launch_control_wave(const ControlParams<R>& p, unsigned B, int model, bool rollout_only,
                                hipStream_t stream);
-// sum of B per-agent records (ControlParams::ck_rec) in agent order: one launch, groups of kSumGroup agents per
-// workgroup, the last workgroup to arrive adds the group records in group order (deterministic).  d_ws: >=
-// ck_sum_ws_elems(B, K2) reals, d_ctr: one ticket (zero before the first use; it resets itself)
-inline size_t ck_sum_ws_elems(unsigned B, int K2) { return static_cast<size_t>((B + kSumGroup - 1) / kSumGroup) * ck_record_len(K2); }
+// sum of B per-agent records (ControlParams::ck_rec): one launch, a fixed tree (groups of kSumGroup agents in agent
+// order, kSumFan group records per level-1 record, the level-1 records in order), finished by ticket inside the launch.
+// d_ws: >= ck_sum_ws_elems(B, K2) reals, d_ctr: ck_sum_tickets(B, K2) tickets (zero before the first use; they reset
+// themselves)
+inline unsigned ck_sum_groups(unsigned B) { return (B + kSumGroup - 1) / kSumGroup; }
+inline unsigned ck_sum_slices(int K2) { return static_cast<unsigned>(ck_record_len(K2) + 63) / 64u; }
+inline size_t ck_sum_ws_elems(unsigned B, int K2)
+{
+  const size_t g0 = ck_sum_groups(B), g1 = (g0 + kSumFan - 1) / kSumFan;
+  return (g0 + g1) * static_cast<size_t>(ck_record_len(K2));
+}
+inline size_t ck_sum_tickets(unsigned B, int K2)
+{
+  const size_t g1 = (ck_sum_groups(B) + kSumFan - 1) / kSumFan;
+  return ck_sum_slices(K2) * (g1 + 1);
+}
 template <typename R>
 hipError_t launch_ck_records_sum(const R* d_rec, unsigned B, int K2, R* d_ws, unsigned* d_ctr, R* d_out, hipStream_t stream);
 

@@ -69,70 +69,90 @@ hipError_t launch_control(const ControlParams<R>& p, unsigned B, int model, int 
 // ---- sum of the per-agent records (eea_ck_records_sum) ---------------------------------------------------------------
 namespace
 {
-// One workgroup of 256 threads per group of kSumGroup = 64 agents: thread (h, m) adds element m of the records of the
-// group's agents 32 h .. 32 h + 31 in agent order -- all 32 loads in flight at once: the records were just written by
-// control kernels on other XCDs, every load is a trip to memory -- and the two halves are added in LDS (h = 0 first).
-// The group record goes to the workspace with agent-scope (write-through) stores; the last workgroup to arrive (one
-// ticket, atomicInc wraps at the group count: it resets itself) adds the group records in group order, 64 loads in
-// flight, and writes the result: one launch, fixed summation order.  Hand-off protocol: MI355X_MICROARCH.md
-// (write-through payload -> s_waitcnt vmcnt(0) -> agent-scope ticket; the reader's loads bypass its L1).
-constexpr int kSumThreads = 256, kSumHalf = kSumGroup / 2;
-template <typename R>
-__global__ __launch_bounds__(kSumThreads) void ck_records_sum_kernel(const R* __restrict__ rec, unsigned B, int rec_len,
-                                                                      R* groups, unsigned* ctr, R* __restrict__ out)
+// One WAVEFRONT per unit (g0, e): the elements [64 e, 64 e + 64) of the records of the kSumGroup = 32 agents of group
+// g0, added in agent order, 8 loads in flight (the records were just written by control kernels on other XCDs: every
+// load is a trip to memory).  A tree of tickets finishes the sum in the same launch, per element slice e: the last
+// of the kSumFan = 8 units of a level-1 group adds their records in group order, the last level-1 group adds the
+// level-1 records in order -- fixed summation order whatever the arrival order.  Tickets are atomicInc with the
+// member count as the wrap value: they reset themselves.  Hand-off protocol: MI355X_MICROARCH.md (write-through
+// payload -> s_waitcnt vmcnt(0) -> agent-scope ticket; the reader's loads bypass its L1).
+//
+// No LDS, one wavefront per workgroup and <= 32 VGPRs (the request is in register pairs on gfx90a+): the wavefronts of
+// this kernel fit BESIDE a fully resident fp64 K <= 10 control kernel (4 wavefronts x 120 VGPRs per SIMD, all of the
+// LDS) instead of waiting for one of its workgroups to retire -- the exchange of a consensus pass runs under the
+// control kernels of the next passes.
+constexpr int kSumBatch = 8;
+
+// the record slice of up to `n` rows of `rows` (row stride rec_len), added in row order; AGENT: agent-scope loads
+template <typename R, bool AGENT>
+__device__ __forceinline__ R sum_rows(const R* rows, unsigned n, int rec_len, int m)
 {
-  __shared__ unsigned s_old;
-  __shared__ R s_half[kSumThreads / 2];
-  const unsigned ngroups = gridDim.x, g = blockIdx.x;
-  const unsigned first = g * kSumGroup, n = (B - first) < kSumGroup ? (B - first) : kSumGroup;
-  const int h = threadIdx.x / (kSumThreads / 2), lane_m = threadIdx.x % (kSumThreads / 2);
-  for (int m0 = 0; m0 < rec_len; m0 += kSumThreads / 2) {
-    const int m = m0 + lane_m;
-    R acc = R(0);
-    if (m < rec_len) {
-      const R* const col = rec + (static_cast<size_t>(first) + kSumHalf * h) * rec_len + m;
-      const unsigned nh = n > kSumHalf * static_cast<unsigned>(h) ? n - kSumHalf * h : 0u;  // agents of this half
-      R v[kSumHalf];
+  R acc = R(0);
+  unsigned q = 0;
+#pragma unroll 1
+  for (; q + kSumBatch <= n; q += kSumBatch) {
+    R v[kSumBatch];
 #pragma unroll
-      for (int i = 0; i < kSumHalf; ++i) v[i] = (static_cast<unsigned>(i) < nh) ? col[static_cast<size_t>(i) * rec_len] : R(0);
+    for (int i = 0; i < kSumBatch; ++i) {
+      const R* const src = rows + static_cast<size_t>(q + i) * rec_len;  // wavefront-uniform row pointer + lane offset
+      v[i] = AGENT ? load_agent(src + m) : src[m];
+    }
 #pragma unroll
-      for (int i = 0; i < kSumHalf; ++i) acc += v[i];
-    }
-    if (m0 > 0) __syncthreads();  // the previous round's halves have been read
-    if (h == 1) s_half[lane_m] = acc;
-    __syncthreads();
-    if (h == 0 && m < rec_len) {
-      acc += s_half[lane_m];
-      if (ngroups == 1) out[m] = acc;
-      else store_agent(groups + static_cast<size_t>(g) * rec_len + m, acc);
-    }
+    for (int i = 0; i < kSumBatch; ++i) acc += v[i];
   }
-  if (ngroups == 1) return;
+#pragma unroll 1
+  for (; q < n; ++q) {
+    const R* const src = rows + static_cast<size_t>(q) * rec_len;
+    acc += AGENT ? load_agent(src + m) : src[m];
+  }
+  return acc;
+}
+
+// the wavefront's payload has left, then one ticket: true for the last of `members` arrivals
+__device__ __forceinline__ bool last_arrival(unsigned* ticket, unsigned members)
+{
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();  // every thread's part of the group record has left
-  if (threadIdx.x == 0) s_old = atomicInc(ctr, ngroups - 1);
-  __syncthreads();
-  if (s_old != ngroups - 1) return;
-  for (int m = threadIdx.x; m < rec_len; m += kSumThreads) {
-    R acc = R(0);
-    unsigned q = 0;
-    for (; q + 64 <= ngroups; q += 64) {
-      R v[64];
-#pragma unroll
-      for (int i = 0; i < 64; ++i) v[i] = load_agent(groups + static_cast<size_t>(q + i) * rec_len + m);
-#pragma unroll
-      for (int i = 0; i < 64; ++i) acc += v[i];
-    }
-    for (; q + 8 <= ngroups; q += 8) {
-      R v[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = load_agent(groups + static_cast<size_t>(q + i) * rec_len + m);
-#pragma unroll
-      for (int i = 0; i < 8; ++i) acc += v[i];
-    }
-    for (; q < ngroups; ++q) acc += load_agent(groups + static_cast<size_t>(q) * rec_len + m);
-    out[m] = acc;
+  unsigned old = 0;
+  if (threadIdx.x == 0) old = atomicInc(ticket, members - 1);
+  old = __builtin_amdgcn_readfirstlane(old);
+  if (old != members - 1) return false;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  return true;
+}
+
+template <typename R>
+__global__ __launch_bounds__(kWave) __attribute__((amdgpu_num_vgpr(16))) void ck_records_sum_kernel(
+    const R* __restrict__ rec, unsigned B, int rec_len, R* ws, unsigned* ctr, R* __restrict__ out)
+{
+  const unsigned ng0 = gridDim.x, ng1 = (ng0 + kSumFan - 1) / kSumFan;
+  const unsigned g0 = blockIdx.x, e = blockIdx.y;
+  const int m = static_cast<int>(kWave * e + threadIdx.x);
+  const bool active = m < rec_len;
+  const int mm = active ? m : 0;  // inactive lanes read element 0 and write nothing
+  R* const ws0 = ws;                                        // [ng0][rec_len]
+  R* const ws1 = ws + static_cast<size_t>(ng0) * rec_len;   // [ng1][rec_len]
+  unsigned* const tickets = ctr + static_cast<size_t>(e) * (ng1 + 1);  // [ng1] level-1 tickets, then the level-2 ticket
+
+  const unsigned first = g0 * kSumGroup, n0 = (B - first) < kSumGroup ? (B - first) : kSumGroup;
+  R acc = sum_rows<R, false>(rec + static_cast<size_t>(first) * rec_len, n0, rec_len, mm);
+  if (ng0 == 1) {
+    if (active) out[m] = acc;
+    return;
   }
+  if (active) store_agent(ws0 + static_cast<size_t>(g0) * rec_len + m, acc);
+  const unsigned g1 = g0 / kSumFan, n1 = (ng0 - g1 * kSumFan) < kSumFan ? (ng0 - g1 * kSumFan) : kSumFan;
+  if (!last_arrival(tickets + g1, n1)) return;
+
+  acc = sum_rows<R, true>(ws0 + static_cast<size_t>(g1) * kSumFan * rec_len, n1, rec_len, mm);
+  if (ng1 == 1) {
+    if (active) out[m] = acc;
+    return;
+  }
+  if (active) store_agent(ws1 + static_cast<size_t>(g1) * rec_len + m, acc);
+  if (!last_arrival(tickets + ng1, ng1)) return;
+
+  acc = sum_rows<R, true>(ws1, ng1, rec_len, mm);
+  if (active) out[m] = acc;
 }
 }  // namespace
 
@@ -140,13 +160,13 @@ template <typename R>
 hipError_t launch_ck_records_sum(const R* d_rec, unsigned B, int K2, R* d_ws, unsigned* d_ctr, R* d_out, hipStream_t stream)
 {
   if (B == 0) return hipSuccess;
-  const unsigned ngroups = (B + kSumGroup - 1) / kSumGroup;
+  const dim3 grid(ck_sum_groups(B), ck_sum_slices(K2));
   if (const hipEvent_t stop = take_stop_event()) {
-    hipExtLaunchKernelGGL(ck_records_sum_kernel<R>, dim3(ngroups), dim3(kSumThreads), 0, stream, nullptr, stop, 0, d_rec, B,
+    hipExtLaunchKernelGGL(ck_records_sum_kernel<R>, grid, dim3(kWave), 0, stream, nullptr, stop, 0, d_rec, B,
                           ck_record_len(K2), d_ws, d_ctr, d_out);
   } else {
-    hipLaunchKernelGGL(ck_records_sum_kernel<R>, dim3(ngroups), dim3(kSumThreads), 0, stream, d_rec, B, ck_record_len(K2),
-                       d_ws, d_ctr, d_out);
+    hipLaunchKernelGGL(ck_records_sum_kernel<R>, grid, dim3(kWave), 0, stream, d_rec, B, ck_record_len(K2), d_ws, d_ctr,
+                       d_out);
   }
   return hipGetLastError();
 }

@@ -32,7 +32,12 @@
 // Steps beyond 256 and bases beyond K = 16 (other than 20) stay on the workgroup-per-agent kernel
 // (control_kernel_impl.hpp); the engine picks.  rollout_only (optTraj / path) stops after the forward half,
 // so a rollout and the trajectory a control call reports are bitwise the same function of (pose, controls).
-#pragma once
+//
+// This header has two parts: helpers (under the include guard) and the kernel itself, which can be included a second
+// time under another name with a register cap (control_wave_kernel.hip: the "lean" fp64 K <= 10 instance; the
+// attribute takes a literal only, so it cannot depend on the template arguments).
+#ifndef EEA_CONTROL_WAVE_HELPERS_HPP
+#define EEA_CONTROL_WAVE_HELPERS_HPP
 
 #include "common.hpp"
 
@@ -65,7 +70,12 @@ __host__ __device__ constexpr int tile_elems(int K)
   const int d = d_elems(K) + 2 * kMaxS * kWave;
   return ((t > d ? t : d) + 3) & ~3;
 }
-__host__ __device__ constexpr int wave_lds_elems(int K) { return park_elems() + tile_elems(K); }
+// the lean instance parks two more rows [64]: the x and y basis sines of the last slot
+__host__ __device__ constexpr int lean_park_elems() { return 2 * kWave; }
+__host__ __device__ constexpr int wave_lds_elems(int K, bool lean = false)
+{
+  return park_elems() + tile_elems(K) + (lean ? lean_park_elems() : 0);
+}
 
 // orders this wavefront's own LDS writes before its own LDS reads (DS operations of one wavefront execute in
 // order; this stops the compiler from moving them across)
@@ -169,13 +179,33 @@ constexpr int waves_per_simd(int KC, int real_size) { return (KC <= 10 || real_s
 // k1 block of the gradient: cosine and G arrays of this many modes are in registers at a time
 constexpr int grad_block(int KC) { return KC <= 12 ? KC : (KC == 16 ? 8 : 10); }
 
+}  // namespace wave
+}  // namespace eea
+#endif  // EEA_CONTROL_WAVE_HELPERS_HPP
+
+// ---- the kernel (re-includable: EEA_WAVE_KERNEL_NAME / _ATTR / _LEAN) ------------------------------------------------
+#ifndef EEA_WAVE_KERNEL_NAME
+#define EEA_WAVE_KERNEL_NAME control_wave_kernel
+#define EEA_WAVE_KERNEL_ATTR
+#define EEA_WAVE_KERNEL_LEAN false
+#endif
+
+namespace eea
+{
+namespace wave
+{
 // KC: compile-time K (5, 10, 20) or 16 = any K <= 16 at run time (loops unrolled to 16, guarded).
 // STAGES: the optional per-stage outputs (traj, edx, bdx, rhot) are compiled in.
 // WPB: wavefronts (= agents) per workgroup; they share nothing.
+// LEAN instance (fp64, K <= 10, no stage outputs): 120 registers instead of 122 -- the allocation granule is 8, so four
+// wavefronts per SIMD leave 32 registers free, room for the wavefronts of the record sum (control_kernel.hip) BESIDE a
+// fully resident control kernel.  The two registers come from parking the last slot's basis sines in LDS from the
+// basis phase to the end of the gradient (lean_park_elems: the workgroup then uses a quarter of the CU's LDS exactly).
 template <typename R, int MODEL, int KC, bool STAGES, int WPB>
-__global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void control_wave_kernel(
+__global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE_KERNEL_ATTR void EEA_WAVE_KERNEL_NAME(
     const ControlParams<R> p, const unsigned B, const int S, const int rollout_only)
 {
+  constexpr bool kParkSine = EEA_WAVE_KERNEL_LEAN;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   const int lane = threadIdx.x & (kWave - 1);
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -193,11 +223,12 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   const int K2 = K * K;
   constexpr int KS = (KC == 16) ? 16 : tab_stride(KC);
 
-  R* const sm = reinterpret_cast<R*>(smem_raw) + static_cast<size_t>(wv) * wave_lds_elems(KC == 16 ? 16 : KC);
+  R* const sm = reinterpret_cast<R*>(smem_raw) + static_cast<size_t>(wv) * wave_lds_elems(KC == 16 ? 16 : KC, kParkSine);
   R* const tabx = sm;                       // [32 rows][KS]
   R* const taby = tabx + kStageRows * KS;
   R* const s_cp = sm + tile_elems(KC == 16 ? 16 : KC);  // cos of the post-step heading, [j][lane]
   R* const s_sp = s_cp + kMaxS * kWave;                 // sin
+  R* const s_sine = s_sp + kMaxS * kWave;               // lean instance: [y, x][lane] basis sines of the last slot
   R* const s_D = tabx;                      // D[k2 * K + k1]   (after the contraction)
   R* const s_g = tabx + d_elems(KC == 16 ? 16 : KC);  // barrier gradient parked during the gradient, [2 j + r][lane]
 
@@ -390,6 +421,10 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
       } else {
         sincospi_r(x * p.inv_lx, &s1x[j], &c1x[j]);
         sincospi_r(y * p.inv_ly, &s1y[j], &c1y[j]);
+      }
+      if (kParkSine && j == kMaxS - 1) {  // not needed before the end of the gradient
+        s_sine[lane] = s1y[j];
+        s_sine[kWave + lane] = s1x[j];
       }
       // gradBarrier (:453-474): 25 * (2 [x > lx - eps] (x - (lx - eps)) + 2 [x < eps] (x - eps)) per axis.  The
       // indicator times the difference is max(difference, 0) / min(difference, 0) (x > a <=> x - a > 0 in IEEE
@@ -1009,8 +1044,10 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
           ub = un;
         }
       }
-      const R exj = (-p.pi_lx * s1x[j] * accx) * p.expl_weight;
-      const R eyj = (-p.pi_ly * s1y[j] * accy) * p.expl_weight;
+      const R sx = (kParkSine && j == kMaxS - 1) ? s_sine[kWave + lane] : s1x[j];
+      const R sy = (kParkSine && j == kMaxS - 1) ? s_sine[lane] : s1y[j];
+      const R exj = (-p.pi_lx * sx * accx) * p.expl_weight;
+      const R eyj = (-p.pi_ly * sy * accy) * p.expl_weight;
       if (STAGES) {
         ex[j] = exj;
         ey[j] = eyj;

@@ -451,11 +451,12 @@ eea_status sum_workspace(eea_engine* e, const void* key, unsigned B, eea_engine:
     w->key = key;
   }
   const size_t need_ws = sizeof(R) * eea::ck_sum_ws_elems(B, e->K2);
-  if (need_ws > w->ws.cap || w->ctr.cap == 0) {
-    EEA_HIP(hipDeviceSynchronize());  // an earlier launch may still use the buffer about to be replaced
+  const size_t need_ctr = sizeof(unsigned) * eea::ck_sum_tickets(B, e->K2);
+  if (need_ws > w->ws.cap || need_ctr > w->ctr.cap) {
+    EEA_HIP(hipDeviceSynchronize());  // an earlier launch may still use the buffers about to be replaced
     EEA_HIP(w->ws.reserve(need_ws));
-    EEA_HIP(w->ctr.reserve(sizeof(unsigned)));
-    EEA_HIP(hipMemset(w->ctr.p, 0, sizeof(unsigned)));  // the ticket resets itself from here on
+    EEA_HIP(w->ctr.reserve(need_ctr));
+    EEA_HIP(hipMemset(w->ctr.p, 0, w->ctr.cap));  // the tickets reset themselves from here on
     EEA_HIP(hipDeviceSynchronize());
   }
   *out = w;

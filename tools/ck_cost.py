@@ -154,7 +154,17 @@ def full_c2(i, lag=3, NBc=8, events=True, exchange=True, wait=True):
     x()
 
 
+QUICK = "--quick" in sys.argv
 run("plain (two groups)", plain)
+if QUICK:
+    run("+ both", rec_in_out)
+    xs = torch.cuda.Stream(priority=-1)
+    run("+ record sum on the exchange stream, unordered [highest stream priority]", with_sum_unordered)
+    run("control_groups only, kernels carry completion events", lambda i: full_c2(i, 3, exchange=False, wait=False))
+    run("+ exchange (ordered after the groups), nobody waits for it", lambda i: full_c2(i, 3, wait=False))
+    for lag in (2, 3, 4):
+        run("two C calls per pass (control_groups + exchange), lag %d" % lag, lambda i: full_c2(i, lag))
+    sys.exit(0)
 run("+ per-agent records out", rec_out)
 run("+ sum record in (ck_shared_parts = 1)", rec_in)
 run("+ both", rec_in_out)

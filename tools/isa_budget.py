@@ -74,7 +74,7 @@ def main():
            "-o", out, os.path.join(ROOT, "tools", "ab", "budget_kernel.hip")]
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     src = open(out).read().split("\n")
-    start = next(i for i, l in enumerate(src) if re.match(r"^_ZN3eea4wave19control_wave_kernelIdLi1ELi10ELb0ELi4E.*:", l))
+    start = next(i for i, l in enumerate(src) if re.match(r"^_ZN3eea4wave24control_wave_kernel_leanIdLi1ELi10ELb0ELi4E.*:", l))
     end = next(i for i, l in enumerate(src) if l.startswith(".Lfunc_end") and i > start)
     blocks, order, cur = {}, [], "entry"
     blocks[cur] = []
