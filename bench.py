@@ -69,8 +69,8 @@ def parse():
                     help="passes between producing c_k and consuming its consensus: the record sum of pass i gets its "
                          "execution slots when the kernels of pass i + 1 finish, and the host launches pass i + lag only "
                          "once that exchange has completed (tools/ck_cost.py: 34 / 30 / 30 us per pass at lag 2 / 3 / 4)")
-    ap.add_argument("--exchange-host-thread", action="store_true",
-                    help="one rank: the exchange's HIP calls on the communicator's host thread (eea_comm_host_thread)")
+    ap.add_argument("--no-exchange-host-thread", action="store_true",
+                    help="one rank: keep the exchange's HIP calls on the launching thread (default: eea_comm_host_thread)")
     ap.add_argument("--consensus-buffers", type=int, default=8, choices=range(3, 9),
                     help="record / sum buffers (and exchange slots) the consensus leg rotates through")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per leg; 0 = skip")
@@ -394,7 +394,7 @@ def main():
     # consensus leg: the control kernels leave per-agent sum records (eea_batch_io::d_ck_rec: [c_k, 1]); ONE small
     # launch on the exchange stream adds them (eea_ck_records_sum: sums + agent count), ONE collective adds the ranks'
     # records (nothing with one rank), and pass i + lag divides sum by count inside the kernel (ck_shared_parts = 1):
-    # one launch of 2 wavefronts per 64 agents beside the compute streams instead of three dependent launches.
+    # one launch of 2 wavefronts per 32 agents, resident beside the control kernels, instead of three dependent launches.
     NB = min(8, max(args.consensus_lag + 2, args.consensus_buffers))  # record buffers in flight: pass i writes buffer i % NB and reads (i - lag) % NB; the
     #                              earlier readers of buffer i % NB (pass i - 2) have finished before pass i starts (it
     #                              waits for the exchange of pass i - lag >= their own)
@@ -464,7 +464,9 @@ def main():
                 comm = capi.Comm(device, 1, 0, capi.comm_unique_id())
                 exchange_backend = "rccl through the C ABI (eea_comm_*), one rank"
             xcomm = comm if comm is not None else capi.Comm(device, 1, 0, None)
-            if args.exchange_host_thread:   # the exchange's HIP calls on the communicator's own host thread
+            if not args.no_exchange_host_thread:
+                # the exchange's HIP calls on the communicator's own host thread: the launching thread keeps its slack
+                # (five default runs on one box: 29.1-30.8 us per pass with it, 28.1-36.1 without)
                 xcomm.host_thread(True)
             return
         if args.no_exchange:

@@ -204,11 +204,12 @@ typedef struct {
 
 /* length in reals of one sum record (eea_batch_io::d_ck_rec): K^2 + 1 rounded up to an even number */
 unsigned eea_ck_record_len(const eea_engine* e);
-/* d_sum [eea_ck_record_len] = sum of the B per-agent records d_ck_rec [B][eea_ck_record_len] in agent order (element
- * K^2 = number of agents that count): ONE launch of ceil(B / 64) small workgroups whose last arriver adds the group
- * records -- fixed summation order, run-to-run deterministic.  Asynchronous on `stream` (typically an exchange stream
- * beside the compute streams: the launch needs 2 wavefronts per 64 agents and fits into what the control kernels'
- * finishing wavefronts leave free).  Concurrent calls on one engine must use distinct d_sum buffers. */
+/* d_sum [eea_ck_record_len] = sum of the B per-agent records d_ck_rec [B][eea_ck_record_len] (element K^2 = number
+ * of agents that count): ONE launch of single-wavefront workgroups -- groups of 32 agents in agent order, 8 group
+ * records per level-1 record, the level-1 records in order, finished by last-arrival tickets inside the launch -- a
+ * fixed summation tree, run-to-run deterministic.  Asynchronous on `stream` (typically an exchange stream beside the
+ * compute streams: the wavefronts use no LDS and <= 32 registers and are resident BESIDE a full fp64 K <= 10 control
+ * kernel).  Concurrent calls on one engine must use distinct d_sum buffers. */
 eea_status eea_ck_records_sum(eea_engine* e, unsigned B, const void* d_ck_rec, void* d_sum, void* stream);
 
 /* One receding-horizon optimisation per agent (ergodic_control.hpp:224-311, without the
@@ -277,8 +278,10 @@ eea_status eea_comm_control_groups(eea_engine* e, eea_comm* c, unsigned n_groups
                                    const eea_batch_io* ios, void* const* group_streams, int wait_slot, int exchange_slot);
 /* on != 0: the HIP calls of eea_comm_records_exchange_async are issued by a host thread the communicator owns (the call
  * itself only queues a request), so that the caller's thread spends its time on the control launches; eea_comm_wait and
- * eea_comm_control_groups make sure the thread has issued the exchange they refer to.  The thread spins while exchanges
- * keep coming and yields when idle; on == 0 (default) stops it. */
+ * eea_comm_control_groups make sure the thread has issued the exchange they refer to.  The thread also paces the exchange
+ * itself: it polls the completion of the groups' kernels (their events came through eea_comm_control_groups) and launches
+ * the record sum once they are there, so the exchange stream carries no wait either (a stream wait is the fall-back for a
+ * group that is milliseconds late).  It spins while exchanges keep coming and yields when idle; on == 0 (default) stops it. */
 eea_status eea_comm_host_thread(eea_comm* c, int on);
 /* returns once every exchange queued so far has been ISSUED to the device (a no-op without the host thread): call it
  * before a host-side synchronisation (hipStreamSynchronize / hipDeviceSynchronize) that is meant to cover them */

@@ -18,7 +18,10 @@ def cp(src, dst):
 
 
 def main():
-    line = open(os.path.join(EV, "bench.json")).read().strip().splitlines()[-1]
+    # bench_final.json: the default command once more AFTER this script ran on the box (tools/r03_evidence.sh), so that
+    # the roofline.*_profiled fields it reads back from profiles/ come from the same box and build as the line itself
+    name = "bench_final.json" if os.path.exists(os.path.join(EV, "bench_final.json")) else "bench.json"
+    line = open(os.path.join(EV, name)).read().strip().splitlines()[-1]
     bench = json.loads(line)
     with open(os.path.join(PR, "r03_bench.json"), "w") as f:
         f.write(line + "\n")
@@ -39,7 +42,7 @@ def main():
     tr = g2["timed_region"]
     rec = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --passes-per-step 1000 "
                       "(default shape: clock spin-up on, two agent groups; tools/profile_r.sh)",
-           "kernel": "control_wave_kernel<double, SimpleCart, 10>", "agents": bench["config"]["agents_per_gpu"],
+           "kernel": "control_wave_kernel_lean<double, SimpleCart, 10>", "agents": bench["config"]["agents_per_gpu"],
            "T": bench["config"]["horizon_steps"], "K": bench["config"]["num_basis"], "precision": bench["dtype"],
            "agents_per_launch": tr["agents_per_launch"], "concurrent_launches": tr["concurrent_launches"],
            "kernel_avg_us_profiled": tr["kernel_avg_us_timed_region"],
@@ -60,7 +63,7 @@ def main():
     if "hbm_bytes_per_launch" in g1:
         B, T = 4096, bench["config"]["horizon_steps"]
         pmc = {"agents": B, "T": T, "K": bench["config"]["num_basis"], "precision": bench["dtype"],
-               "kernel": "control_wave_kernel<double, SimpleCart, 10> (r03: 4x4-block contraction), one launch per pass",
+               "kernel": "control_wave_kernel_lean<double, SimpleCart, 10> (r03: 4x4-block contraction, 120 registers), one launch per pass",
                "fetch_size_kib": g1["pmc_mean_per_dispatch"].get("FETCH_SIZE"),
                "write_size_kib": g1["pmc_mean_per_dispatch"].get("WRITE_SIZE"),
                "hbm_read_bytes_x2_corrected": g1["hbm_read_bytes_x2_corrected"], "hbm_write_bytes": g1["hbm_write_bytes_raw"],

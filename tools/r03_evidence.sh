@@ -23,4 +23,8 @@ python3 tools/parity_report.py > "$OUT/parity_report.txt" 2>&1
 EEA_PRINT_WORST=1 python3 -m pytest tests/test_analytic_checks.py -m gpu -q -s 2>&1 | grep -E "digits|passed|failed" > "$OUT/analytic_checks.txt"
 python3 tools/ck_cost.py > "$OUT/ck_cost.txt" 2>&1
 bash tools/config_sweep.sh > "$OUT/config_sweep.txt" 2>&1
+# the profile records bench.py reads back, written on the box, then the default command once more: its
+# roofline.*_profiled fields then come from THIS box and build (profiles/ on the box is scratch; the files travel in $OUT)
+python3 tools/make_r03_profiles.py > /dev/null 2>&1
+python3 bench.py --steps 20 --warmup 5 > "$OUT/bench_final.json" 2> "$OUT/bench_final.err"
 ls -la "$OUT"
