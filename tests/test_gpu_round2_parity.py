@@ -196,6 +196,41 @@ def test_sum_record_of_the_launch(model, K, horizon, B):
     assert np.abs(rec[:K2] - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())
 
 
+@pytest.mark.parametrize("K,B", [(10, 1), (10, 32), (10, 33), (10, 256), (10, 257), (10, 288), (10, 2049), (10, 8200),
+                                 (5, 300), (20, 517), (3, 97)])
+def test_record_sum_tree_order(K, B):
+    """eea_ck_records_sum on synthetic records against the documented summation tree taken literally in numpy
+    (include/ergodic_amd.h: groups of 32 agents in agent order, 8 group records per level-1 record, the level-1 records
+    in order): BITWISE, for the tree's edge shapes -- one group, a level-1 group of one member (257 ... 288 agents), more
+    than 8 level-1 records (8200 agents), records that end inside an element slice of 64 (K = 5, 20, 3)."""
+    lim = np.array([1.0, 1.0, 2.0])
+    eng = capi.Engine(capi.make_config(capi.MODEL_OMNI, 0.1, 1.0, 0.1, 1.0, K, np.diag([1.0, 1.0, 2.0]), -lim, lim))
+    L = eng.ck_record_len
+    rng = np.random.default_rng(7 * B + K)
+    a = rng.standard_normal((B, L)) * 10.0 ** rng.integers(-3, 4, (B, 1))   # magnitudes that make the order matter
+    d_a = torch.as_tensor(a).cuda()
+    out = torch.full((L,), float("nan"), dtype=torch.float64, device="cuda")
+    for _ in range(3):   # the tickets reset themselves: back-to-back launches into the same output
+        eng.ck_records_sum(B, d_a, out)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+
+    def seq_sum(rows):
+        acc = np.zeros(L)
+        for r in rows:
+            acc = acc + r
+        return acc
+    g0 = [seq_sum(a[i:i + 32]) for i in range(0, B, 32)]
+    if len(g0) == 1:
+        ref = g0[0]
+    else:
+        g1 = [seq_sum(g0[i:i + 8]) for i in range(0, len(g0), 8)]
+        ref = g1[0] if len(g1) == 1 else seq_sum(g1)
+    assert np.array_equal(got, ref)
+    assert B <= 64 or not np.array_equal(ref, seq_sum(a))   # (the order does matter for these inputs)
+    eng.close()
+
+
 def test_sum_record_skips_rejected_agents_and_fp32():
     """agents SimpleCart rejects (EEA_ERR_INVALID_TWIST) contribute nothing and are not counted; fp32 engine"""
     bad = (0, 5, 63, 64, 199)
