@@ -55,6 +55,7 @@ namespace wave
 {
 constexpr int kMaxS = 4;        // steps per lane
 constexpr int kStageRows = 32;  // points staged per matrix-core pass (8 MFMAs)
+constexpr int kTailScratch = 24;  // [3][8]: cos a, cos b, sin b of the <= 8 points of a cooperative last slot
 
 __host__ __device__ constexpr int tab_stride(int K) { return (K + 1) & ~1; }  // even: 16-byte rows
 // LDS carve per wavefront, in elements: the region of the contraction's tiles (x / y, 32 rows each), which D and the
@@ -65,9 +66,10 @@ __host__ __device__ constexpr int park_elems() { return 2 * kMaxS * kWave; }
 __host__ __device__ constexpr int d_elems(int K) { return (K * K + 3) & ~3; }
 __host__ __device__ constexpr int tile_elems(int K)
 {
-  // the tiles of the contraction; afterwards D [K^2] and the parked barrier gradient [2][kMaxS][64]
+  // the tiles of the contraction; afterwards D [K^2], the parked barrier gradient [2][kMaxS][64] and kTailScratch reals
+  // of hand-over space for the cooperative last slot (inside the tiles' footprint at K = 10)
   const int t = 2 * kStageRows * tab_stride(K);
-  const int d = d_elems(K) + 2 * kMaxS * kWave;
+  const int d = d_elems(K) + 2 * kMaxS * kWave + kTailScratch;
   return ((t > d ? t : d) + 3) & ~3;
 }
 // the lean instance parks two more rows [64]: the x and y basis sines of the last slot
@@ -232,14 +234,19 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
   R* const s_D = tabx;                      // D[k2 * K + k1]   (after the contraction)
   R* const s_g = tabx + d_elems(KC == 16 ? 16 : KC);  // barrier gradient parked during the gradient, [2 j + r][lane]
 
-  // Lane -> horizon steps.  Lanes [0, q16) own S consecutive steps each, q16 = the number of full lanes rounded DOWN to
-  // a multiple of 16; what is left of the horizon (rem < 16 S steps) is spread over the next <= 16 lanes, sc =
-  // ceil(rem / 16) <= S steps each.  Lane order is step order (the scans need nothing else), and the valid lanes of a
-  // slot j are whole groups of 16 plus at most one partial group -- the contraction multiplies groups of 16 points
-  // (T = 200: lanes 0..47 own 4 steps, lanes 48..55 one: 13 groups instead of 16).
-  const int q16 = (T / S) & ~15;
+  // Lane -> horizon steps.  Lanes [0, q16) own S consecutive steps each, the following lanes sc < S steps each, the rest
+  // none.  Lane order is step order (the scans need nothing else), and the valid lanes of a slot j are whole groups of 16
+  // plus at most one partial group -- the contraction multiplies groups of 16 points.  Two shapes:
+  //  * T = 64 (S - 1) + r with r <= 8 (T = 200: S = 4, r = 8): the first r lanes own S steps, all others S - 1 -- the
+  //    slots 0 .. S-2 are full wavefronts and the last slot holds r steps in lanes 0 .. r-1, whose gradient is then
+  //    taken by all 64 lanes together (8 lanes per step, below) instead of a full pass at r / 64 lanes;
+  //  * otherwise: q16 = the number of lanes that can own S steps rounded DOWN to a multiple of 16, what is left of the
+  //    horizon (< 16 S steps) spread over the next <= 16 lanes, sc = ceil(rem / 16) steps each.
+  const int r_top = T - kWave * (S - 1);  // 1 .. 64
+  const bool top_heavy = S > 1 && r_top <= 8;  // wavefront-uniform
+  const int q16 = top_heavy ? r_top : ((T / S) & ~15);
   const int rem = T - S * q16;
-  const int sc = (rem + 15) >> 4;
+  const int sc = top_heavy ? S - 1 : ((rem + 15) >> 4);
   const int i0 = lane < q16 ? S * lane : S * q16 + sc * (lane - q16);  // first horizon step of this lane
   const int cnt = lane < q16 ? S : max(0, min(sc, T - i0));            // steps of this lane
   // number of lanes that own a step in slot j (wave-uniform)
@@ -921,6 +928,11 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
     }
   }
   R ex[STAGES ? kMaxS : 1], ey[STAGES ? kMaxS : 1];  // kept apart from the barrier gradient only for the outputs
+  // Top-heavy horizon with four slots (T = 193 .. 200): the last slot holds <= 8 steps in lanes 0 .. 7.  A regular pass
+  // would spend a full slot's instructions on them (a vector instruction costs the same whatever the lane mask,
+  // tools/ubench/exec_mask.hip); instead all 64 lanes take them together, 8 lanes per step (below the loop).
+  constexpr bool kCoopTail = sizeof(R) == 8 && (KC == 10 || KC == 5);
+  const bool coop_tail = kCoopTail && top_heavy && S == kMaxS;  // wavefront-uniform
 #pragma unroll
   for (int j = 0; j < kMaxS; ++j) {
     if (STAGES) ex[j] = ey[j] = R(0);
@@ -928,7 +940,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
     // the arrays of all four steps) in registers across the unrolled steps and spills
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (j < S) {
+    if (j < S && !(j == kMaxS - 1 && coop_tail)) {
       // Pass(es) over D, one per block of KB x-modes k1: G(k1) accumulates over the rows, the block's part of
       // H(k2) is complete at the end of row k2.  The Chebyshev pairs of the x angle run on across the blocks.
       constexpr int KB = grad_block(KC);
@@ -1057,6 +1069,109 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
         const bool act = j < cnt;
         g0[j] = act ? exj + s_g[(2 * j + 0) * kWave + lane] : R(0);
         g1[j] = act ? eyj + s_g[(2 * j + 1) * kWave + lane] : R(0);
+      }
+    }
+  }
+  if constexpr (kCoopTail) {
+    if (coop_tail) {
+      // Lane l = 8 s + t works on the step of lane s (slot 3), rows k2 = t and t + 8 of D:
+      //   edx_x = -pi/lx sin(a) sum_k2 cos(k2 b) Bx(k2),   Bx(k2) = sum_k1 D(k2,k1) k1 U_{k1-1}(cos a)
+      //   edx_y = -pi/ly        sum_k2 k2 sin(k2 b) A(k2),  A(k2)  = sum_k1 D(k2,k1) cos(k1 a)
+      // (the same sums as above in another order).  The x tables by the Chebyshev recurrences in every lane; cos / sin of
+      // the lane's own rows k2 b by binary powering of (cos b, sin b) -- the row differs from lane to lane, a recurrence
+      // would have to be run to the end and picked from.
+      constexpr int jt = kMaxS - 1;
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      const int st = lane >> 3, sub = lane & 7;
+      R* const s_tail = s_g + 2 * kMaxS * kWave;  // [3][8]
+      if (lane < 8) {
+        s_tail[lane] = c1x[jt];
+        s_tail[8 + lane] = c1y[jt];
+        s_tail[16 + lane] = kParkSine ? s_sine[lane] : s1y[jt];
+      }
+      lds_fence();
+      const R cxs = s_tail[st], cys = s_tail[8 + st], sys = s_tail[16 + st];
+      lds_fence();  // (the hand-over space is written again below)
+      R cxa[KC], kux[KC];  // cos(k1 a), k1 U_{k1-1}(cos a)
+      {
+        const R two = cxs + cxs;
+        R ta = R(1), tb = cxs, ua = R(0), ub = R(1);
+#pragma unroll
+        for (int k1 = 0; k1 < KC; ++k1) {
+          cxa[k1] = ta;
+          kux[k1] = static_cast<R>(k1) * ua;
+          const R tn = two * tb - ta, un = two * ub - ua;
+          ta = tb;
+          tb = tn;
+          ua = ub;
+          ub = un;
+        }
+      }
+      // (cos, sin)(k2 b) for k2 = sub: z^sub = z^(bit 0) z2^(bit 1) z4^(bit 2)
+      const R z2c = cys * cys - sys * sys, z2s = (cys + cys) * sys;
+      const R z4c = z2c * z2c - z2s * z2s, z4s = (z2c + z2c) * z2s;
+      R wc = (sub & 1) ? cys : R(1), ws = (sub & 1) ? sys : R(0);
+      {
+        const R mc = (sub & 2) ? z2c : R(1), ms = (sub & 2) ? z2s : R(0);
+        const R nc = wc * mc - ws * ms, ns = wc * ms + ws * mc;
+        wc = nc;
+        ws = ns;
+      }
+      {
+        const R mc = (sub & 4) ? z4c : R(1), ms = (sub & 4) ? z4s : R(0);
+        const R nc = wc * mc - ws * ms, ns = wc * ms + ws * mc;
+        wc = nc;
+        ws = ns;
+      }
+      R px = R(0), py = R(0);
+      auto tail_row = [&](int k2, R cyv, R ksv) {  // k2 < KC; cyv = cos(k2 b), ksv = k2 sin(k2 b) (both 0: row not taken)
+        const R* const row = s_D + k2 * K;
+        R a0 = R(0), a1 = R(0), b0 = R(0), b1 = R(0);
+#pragma unroll
+        for (int k1 = 0; k1 < KC; ++k1) {
+          const R d = row[k1];
+          if (k1 & 1) {
+            a1 += d * cxa[k1];
+            b1 += d * kux[k1];
+          } else {
+            a0 += d * cxa[k1];
+            if (k1 > 0) b0 += d * kux[k1];
+          }
+        }
+        px += cyv * (b0 + b1);
+        py += ksv * (a0 + a1);
+      };
+      tail_row(sub < KC ? sub : KC - 1, sub < KC ? wc : R(0), sub < KC ? static_cast<R>(sub) * ws : R(0));
+      if (KC > 8) {  // rows 8 .. KC-1: z^(sub + 8) = z^sub z8
+        const R z8c = z4c * z4c - z4s * z4s, z8s = (z4c + z4c) * z4s;
+        const R vc = wc * z8c - ws * z8s, vs = wc * z8s + ws * z8c;
+        const bool has = sub + 8 < KC;
+        tail_row(has ? sub + 8 : KC - 1, has ? vc : R(0), has ? static_cast<R>(sub + 8) * vs : R(0));
+      }
+      // the 8 lanes of a step: xor 1, xor 2 (quad permutations), then the mirror image inside the half row
+      px += dpp_or_zero<0xB1, 0xf>(px);
+      py += dpp_or_zero<0xB1, 0xf>(py);
+      px += dpp_or_zero<0x4E, 0xf>(px);
+      py += dpp_or_zero<0x4E, 0xf>(py);
+      px += dpp_or_zero<0x141, 0xf>(px);
+      py += dpp_or_zero<0x141, 0xf>(py);
+      if (sub == 0) {
+        s_tail[2 * st] = px;
+        s_tail[2 * st + 1] = py;
+      }
+      lds_fence();
+      const R accx = s_tail[2 * (lane & 7)], accy = s_tail[2 * (lane & 7) + 1];
+      const R sx = kParkSine ? s_sine[kWave + lane] : s1x[jt];
+      const R exj = (-p.pi_lx * sx * accx) * p.expl_weight;
+      const R eyj = (-p.pi_ly * accy) * p.expl_weight;  // (sin b is in the row factors)
+      if (STAGES) {
+        ex[jt] = exj;
+        ey[jt] = eyj;
+      } else {
+        const bool act = jt < cnt;  // lanes 0 .. r-1
+        g0[jt] = act ? exj + s_g[(2 * jt + 0) * kWave + lane] : R(0);
+        g1[jt] = act ? eyj + s_g[(2 * jt + 1) * kWave + lane] : R(0);
       }
     }
   }

@@ -150,6 +150,19 @@ def test_contraction_row_group_boundaries(steps):
                         tol=5e-4, tol_ck=1e-5, tol_u_rho=2e-6)
 
 
+@pytest.mark.parametrize("steps", [66, 72, 129, 130, 136, 193, 194, 197, 199, 200])
+def test_top_heavy_horizons_and_cooperative_last_slot(steps):
+    """T = 64 (S - 1) + r with r <= 8: the first r lanes of the agent's wavefront own S steps, all others S - 1 (full
+    slots + one nearly empty last slot).  With four slots (T = 193 .. 200, the metric's T = 200 among them) the fp64
+    K = 5 / 10 instances take the gradient of the last slot's r steps with all 64 lanes, 8 per step (other summation
+    order, rows' cos / sin by binary powering).  Both models, with and without replay memory, two calls (the second on
+    the first one's controls); r = 1, 2, 5, 7, 8 and the shapes with two / three slots that keep the regular pass."""
+    run_batch_vs_oracle("simple_cart", 10, steps * 0.1, 0.1, B=4, n_mem=0, calls=2, seed=71)
+    run_batch_vs_oracle("omni", 10, steps * 0.1, 0.1, B=3, n_mem=40, calls=2, seed=72)
+    run_batch_vs_oracle("omni", 5, steps * 0.1, 0.1, B=3, n_mem=0, calls=2, seed=73)
+    run_batch_vs_oracle("simple_cart", 12, steps * 0.1, 0.1, B=2, n_mem=0, calls=1, seed=74)   # generic instance: regular pass
+
+
 @pytest.mark.parametrize("dt", [0.1, 1.0, 2.0])
 def test_small_and_large_step_increments(dt):
     """The wavefront kernel takes the sin/cos of a step's mid-stage / post-step heading and of its later basis
