@@ -168,7 +168,9 @@ def main():
     print("reference-formulation work W = %d flop = %d fp64 multiply-adds = %.0f full 64-lane instructions; issued: %d "
           "fp64 FMA + %d fp64 mul/add + %d other vector + %d x 64 (MFMA: 256 multiply-adds per lane-group of 64) "
           % (W, W // 2, W / 2 / 64, tot["v_fma64"], tot["v_muladd64"], tot["v_other"], tot["mfma"]))
-    print("lanes: 50 of 64 own steps at T = 200 (48 x 4 + 8 x 1 steps): every per-step instruction runs 78 %% full")
+    print("lanes at T = 200: lanes 0..7 own 4 steps, lanes 8..63 three: the per-step instructions of slots 0..2 run on full "
+          "wavefronts, those of the last slot on 8 lanes -- except its gradient, which all 64 lanes take together "
+          "(8 lanes per step); 200 of 256 lane-steps carry a step (78 %)")
 
 
 if __name__ == "__main__":
