@@ -90,6 +90,12 @@ def with_sum_unordered(i):   # the sum launch on the exchange stream, nothing wa
     eng.ck_records_sum(B, d_arec[i % NB], d_rec[i % NB], stream=xs.cuda_stream)
 
 
+def with_tiny_sum_unordered(i):   # the same launch with one agent: what a third queue costs by itself
+    for g in range(G):
+        call(g, i % NB, (i - 2) % NB)
+    eng.ck_records_sum(1, d_arec[i % NB], d_rec[(i + 4) % NB], stream=xs.cuda_stream)
+
+
 def with_sum_after_groups(i):  # the exchange stream waits for the groups' launches; consumers do not wait
     s = i % NB
     for g in range(G):
@@ -160,6 +166,10 @@ if QUICK:
     run("+ both", rec_in_out)
     xs = torch.cuda.Stream(priority=-1)
     run("+ record sum on the exchange stream, unordered [highest stream priority]", with_sum_unordered)
+    run("+ a ONE-agent record sum on the exchange stream, unordered [highest stream priority]", with_tiny_sum_unordered)
+    for nb in (256, 1024, 2048):
+        run("+ record sum of the first %d agents only, unordered [highest]" % nb,
+            lambda i, nb=nb: (rec_in_out(i), eng.ck_records_sum(nb, d_arec[i % NB], d_rec[i % NB], stream=xs.cuda_stream)))
     run("control_groups only, kernels carry completion events", lambda i: full_c2(i, 3, exchange=False, wait=False))
     run("+ exchange (ordered after the groups), nobody waits for it", lambda i: full_c2(i, 3, wait=False))
     for lag in (2, 3, 4):
