@@ -116,8 +116,8 @@ struct eea_engine
   bool rebuild_pending = false;
   DevBuf d_lut, d_raw, d_occ;  // occupancy targets: decode table, un-normalised sums, staged cells
 
-  // workspaces of eea_ck_records_sum (group records + one ticket), one per distinct output buffer: concurrent calls
-  // on several streams must not share a ticket
+  // workspaces of eea_ck_records_sum (group records of both levels + the tickets of its tree), one per distinct output
+  // buffer: concurrent calls on several streams must not share tickets
   struct SumWs
   {
     const void* key = nullptr;
