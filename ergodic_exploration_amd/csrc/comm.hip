@@ -469,6 +469,12 @@ eea_status eea_comm_flush(eea_comm* c)
   return EEA_OK;
 }
 
+// Queries of an exchange's completion event before eea_comm_control_groups gives up pacing and enqueues a stream wait.
+// The fall-back is expensive for many passes (it drags the group streams into lockstep), so it is for an exchange that is
+// really stuck, not for one that is a few passes late: with 400 queries (~0.2 ms) bench.py's consensus leg took 28.0-29.0 us
+// per pass, with 100 000 it takes 27.3-27.5 (five interleaved runs each, one box).
+constexpr int kPaceSpins = 100000;
+
 eea_status eea_comm_control_groups(eea_engine* e, eea_comm* c, unsigned n_groups, const unsigned* B,
                                    const eea_batch_io* ios, void* const* group_streams, int wait_slot, int exchange_slot)
 {
@@ -489,12 +495,12 @@ eea_status eea_comm_control_groups(eea_engine* e, eea_comm* c, unsigned n_groups
     if (B[g] == 0) continue;
     hipStream_t s = static_cast<hipStream_t>(group_streams[g]);
     // Behind the exchange it consumes.  The host paces itself instead of the stream: it polls the exchange's completion
-    // (a few hundred microseconds at most) and launches once it is there -- with a lag of >= 2 passes the device still
+    // (kPaceSpins queries, tens of milliseconds, at most) and launches once it is there -- with a lag of >= 2 passes the device still
     // has the passes in between queued, and the group streams carry no barrier packet at all (a wait enqueued while the
     // exchange is in flight costs the stream 5-13 us per pass even when it is satisfied long before its turn:
     // tools/ck_cost.py).  Only an exchange that is really late gets a stream wait.
     if (wait_slot >= 0 && c->ev_done[wait_slot] != nullptr && !exchange_done) {
-      for (int spin = 0; spin < 400 && !exchange_done; ++spin) exchange_done = hipEventQuery(c->ev_done[wait_slot]) == hipSuccess;
+      for (int spin = 0; spin < kPaceSpins && !exchange_done; ++spin) exchange_done = hipEventQuery(c->ev_done[wait_slot]) == hipSuccess;
       if (!exchange_done) EEA_HIP(hipStreamWaitEvent(s, c->ev_done[wait_slot], 0));
     }
     if (ev != nullptr) eea::set_stop_event(*ev);  // bound to the control kernel of this call

@@ -269,8 +269,8 @@ eea_status eea_comm_records_exchange_async(eea_engine* e, eea_comm* c, unsigned 
 /* The control calls of one pass of such a batch in one call (a pass of 4096 agents takes ~25 us on the device: the host
  * must issue it in less): eea_control_batch(e, B[g], &ios[g], group_streams[g]) for every agent group g, all of them
  * behind the exchange of slot wait_slot (skipped when wait_slot < 0).  The HOST waits for that exchange -- it polls its
- * completion event for up to a few hundred microseconds and only then launches; a stream wait is the fall-back for an
- * exchange that is really late -- so that the group streams carry no wait at all: with a lag of >= 2 passes between
+ * completion event (for tens of milliseconds at most) and only then launches; a stream wait is the fall-back for an
+ * exchange that is stuck -- so that the group streams carry no wait at all: with a lag of >= 2 passes between
  * producing and consuming an exchange the device still has the passes in between queued.  exchange_slot >= 0: the slot
  * of the eea_comm_records_exchange_async call that follows for this pass; the groups' kernels then carry the completion
  * events that exchange waits for (no separate event records). */
