@@ -336,9 +336,11 @@ __device__ __forceinline__ R wrap_pi(R rad)
 }
 
 // consensus c_k of mode m (eea_batch_io::d_ck_shared): the K^2 values themselves, or -- ck_shared_parts > 0 -- the
-// sum of that many sum records divided by the sum of their agent counts (element K^2 of a record)
+// sum of that many sum records divided by the sum of their agent counts (element K^2 of a record).  A record set that
+// no agent contributed to (count 0: every agent of the producing pass was rejected, or the buffer is still zero) is no
+// consensus at all: the agent keeps its own c_k (`own`) -- the reference's behaviour -- instead of 0 / 0
 template <typename R>
-__device__ __forceinline__ R shared_ck_value(const ControlParams<R>& p, int m, int K2)
+__device__ __forceinline__ R shared_ck_value(const ControlParams<R>& p, int m, int K2, R own)
 {
   if (p.ck_shared_parts <= 0) return p.ck_shared[m];
   R s = R(0), n = R(0);
@@ -346,7 +348,7 @@ __device__ __forceinline__ R shared_ck_value(const ControlParams<R>& p, int m, i
     s += p.ck_shared[static_cast<size_t>(i) * p.rec_len + m];
     n += p.ck_shared[static_cast<size_t>(i) * p.rec_len + K2];
   }
-  return s / n;
+  return n > R(0) ? s / n : own;
 }
 
 // agent-scope (sc1: write-through / L1-bypassing) accesses for data that crosses XCDs inside one launch

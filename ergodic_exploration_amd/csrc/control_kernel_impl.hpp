@@ -655,7 +655,7 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
       if (p.ck != nullptr) p.ck[static_cast<size_t>(b) * K2 + m] = c;
       if (p.ck_rec != nullptr) p.ck_rec[static_cast<size_t>(b) * p.rec_len + m] = c;  // eea_batch_io::d_ck_rec
       // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
-      if (p.ck_shared != nullptr) c = shared_ck_value(p, m, K2);
+      if (p.ck_shared != nullptr) c = shared_ck_value(p, m, K2, c);
       // fourier_diff = lamdak % (ck - phik)  (ergodic_control.hpp:422)
       const R lam = (m == tid) ? lam_m : p.lamdak[m];
       const R phi = (m == tid) ? phi_m : p.phik[m];

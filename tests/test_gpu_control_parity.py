@@ -29,8 +29,13 @@ def dev(a, dtype=torch.float64):
 
 
 def run_batch_vs_oracle(model, K, horizon, dt, B, n_mem, calls, seed, precision=capi.PREC_F64,
-                        tol=TOL, tol_ck=TOL_CK, bounds=MAP_BOUNDS, means=MEANS, sigmas=SIGMAS, tol_u_rho=0.0):
-    """tol_u_rho (fp32 runs only): u = clamp(-Rinv B^T rho) inherits the co-state's ABSOLUTE rounding error wherever
+                        tol=TOL, tol_ck=TOL_CK, bounds=MAP_BOUNDS, means=MEANS, sigmas=SIGMAS, tol_u_rho=0.0,
+                        stages=True):
+    """stages=False: no per-stage output pointers are passed, which selects the kernel instances compiled WITHOUT the
+    stage outputs -- the ones bench.py times (the lean fp64 K <= 10 instance among them, control_wave_kernel.hip); c_k,
+    the warm-start matrix ut (every step's control: the view of the co-state that is left) and u0 are compared, on the
+    same bars as with stages.
+    tol_u_rho (fp32 runs only): u = clamp(-Rinv B^T rho) inherits the co-state's ABSOLUTE rounding error wherever
     it is not clamped, so when the co-state is far from unit size (robot outside the map: |rho| ~ 1e3) the bar on the
     controls is max(tol max(1, |u|), tol_u_rho |rho|max); fp64 runs keep the pure per-stage bar (tol_u_rho = 0)."""
     rng = np.random.default_rng(seed)
@@ -48,7 +53,7 @@ def run_batch_vs_oracle(model, K, horizon, dt, B, n_mem, calls, seed, precision=
         mem = random_poses(rng, B * n_mem, bounds).reshape(B, n_mem, 3)
     d_pose, d_ut = dev(poses, tdt), dev(ut0, tdt)
     d_u0 = torch.empty((B, 3), dtype=tdt, device="cuda")
-    outs = {k: torch.empty((B, T, 3), dtype=tdt, device="cuda") for k in ("traj", "edx", "bdx", "rhot")}
+    outs = {k: torch.empty((B, T, 3), dtype=tdt, device="cuda") for k in ("traj", "edx", "bdx", "rhot")} if stages else {}
     d_ck = torch.empty((B, K2), dtype=tdt, device="cuda")
     d_status = torch.full((B,), -1, dtype=torch.int32, device="cuda")
     d_mem = dev(mem, tdt) if n_mem else None
@@ -68,15 +73,20 @@ def run_batch_vs_oracle(model, K, horizon, dt, B, n_mem, calls, seed, precision=
         for b in range(B):
             u, st = ors[b].control(bounds, poses[b], mem[b].T if n_mem else None, stages=True)
             errs = {
-                "traj_xy": (np.abs(got["traj"][b].T[:2] - st["traj"][:2]).max(), np.abs(st["traj"][:2]).max()),
-                "traj_th": (np.abs(angle_diff(got["traj"][b].T[2], st["traj"][2])).max(), 1.0),
                 "ck": (np.abs(got["ck"][b] - st["ck"]).max(), np.abs(st["ck"]).max()),
-                "edx": (np.abs(got["edx"][b].T - st["edx"]).max(), np.abs(st["edx"]).max()),
-                "bdx": (np.abs(got["bdx"][b].T - st["bdx"]).max(), np.abs(st["bdx"]).max()),
-                "rhot": (np.abs(got["rhot"][b].T - st["rhot"]).max(), np.abs(st["rhot"]).max()),
                 "ut": (np.abs(got["ut"][b].T - st["ut"]).max(), np.abs(st["ut"]).max()),
                 "u0": (np.abs(got["u0"][b] - u).max(), np.abs(u).max()),
             }
+            if stages:
+                errs.update({
+                    "traj_xy": (np.abs(got["traj"][b].T[:2] - st["traj"][:2]).max(), np.abs(st["traj"][:2]).max()),
+                    "traj_th": (np.abs(angle_diff(got["traj"][b].T[2], st["traj"][2])).max(), 1.0),
+                    "edx": (np.abs(got["edx"][b].T - st["edx"]).max(), np.abs(st["edx"]).max()),
+                    "bdx": (np.abs(got["bdx"][b].T - st["bdx"]).max(), np.abs(st["bdx"]).max()),
+                    "rhot": (np.abs(got["rhot"][b].T - st["rhot"]).max(), np.abs(st["rhot"]).max()),
+                })
+            else:   # the co-state's magnitude still scales the bar of the controls it drives (from the oracle's stage)
+                errs["rhot"] = (0.0, np.abs(st["rhot"]).max())
             for k, (v, mag) in errs.items():
                 worst[k] = max(worst.get(k, 0.0), float(v))
                 scaled[k] = max(scaled.get(k, 0.0), float(v) / max(1.0, float(mag)))
@@ -87,9 +97,10 @@ def run_batch_vs_oracle(model, K, horizon, dt, B, n_mem, calls, seed, precision=
     eng.close()
     if os.environ.get("EEA_PRINT_WORST"):
         print("worst", model, K, T, n_mem, "dt=%g" % dt, "f32" if precision == capi.PREC_F32 else "f64",
+              "stages" if stages else "NO-STAGES(timed instance)",
               {k: "%.2e (|stage| %.1e)" % (worst[k], magn[k]) for k in worst})
     assert scaled["ck"] <= tol_ck, (worst, magn)
-    for k in ("traj_xy", "traj_th", "edx", "bdx", "rhot"):
+    for k in ("traj_xy", "traj_th", "edx", "bdx", "rhot") if stages else ():
         assert scaled[k] <= tol, (k, worst, magn)
     for k in ("ut", "u0"):
         assert scaled[k] <= tol or worst[k] <= tol_u_rho * magn["rhot"], (k, worst, magn)
