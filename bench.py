@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--no-latency", action="store_true", help="skip the B = 1 dependent-call leg")
     ap.add_argument("--no-phik", action="store_true", help="skip the phi_k legs (roofline_phik)")
     ap.add_argument("--phik-grid", type=int, default=16384, help="side of the square fp64 grid of the phi_k leg")
+    ap.add_argument("--steps-per-launch", type=int, default=1,
+                    help="receding-horizon steps (passes) per launch of the shard leg (eea_control_batch_steps: the agent's "
+                         "wavefront carries on with its own stored controls; must divide --passes-per-step)")
     ap.add_argument("--agent-groups", type=int, default=2,
                     help="split the rank's agents into this many contiguous groups, each stepped by its own "
                          "eea_control_batch call on its own HIP stream: agents are independent, and the head of one "
@@ -506,8 +509,12 @@ def main():
 
     state = {"i": 0}
     # eea_batch_io structs are built once per distinct buffer set, a pass is one ctypes call per group
+    SPL = max(1, args.steps_per_launch)
+    if R % SPL:
+        raise SystemExit("--steps-per-launch must divide --passes-per-step")
     shard_calls = [eng.prepared_batch(a["B"], a["pose"], a["ut"], a["u0"], mem_cols=a["mem_cols"], n_mem=a["n_mem"],
-                                      mem_stride=args.n_mem, stream=a["stream"]) for a in gargs]
+                                      mem_stride=args.n_mem, stream=a["stream"],
+                                      n_steps=None if SPL == 1 else SPL) for a in gargs]
     exch_calls = {}
 
     def one_pass(leg):
@@ -591,9 +598,10 @@ def main():
         # device spin-up, not part of any count: the shader clock needs a few tens of milliseconds of load to reach
         # its sustained state (with 100 passes of warm-up the timed region still starts on the ramp: 27.2 us per
         # pass against 25.8 us after 1000)
-        for _ in range(SPINUP_PASSES if leg == "shard" else 0):
+        per = SPL if leg == "shard" else 1   # passes one call of one_pass() issues
+        for _ in range(SPINUP_PASSES // per if leg == "shard" else 0):
             one_pass(leg)
-        for _ in range(warmup * Rl):
+        for _ in range(warmup * Rl // per):
             one_pass(leg)
         torch.cuda.synchronize()
         if use_dist:
@@ -602,7 +610,7 @@ def main():
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(compute)   # the device is idle here (synchronised above): the start of every group's first pass
-        for _ in range(steps * Rl):
+        for _ in range(steps * Rl // per):
             one_pass(leg)
         join_groups()         # the end event follows the last pass of EVERY agent group
         if leg == "consensus" and xcomm is not None:
@@ -684,7 +692,7 @@ def main():
                                    % (B, args.model, K, K, T, args.dt, args.horizon, args.n_mem),
                        "agents_per_gpu": B, "num_basis": K, "horizon_steps": T, "kinematics": args.model,
                        "passes_per_step": R, "optimisations_per_step": world * B * R,
-                       "agent_groups": G, "parallelism": "agent-batch x%d" % world,
+                       "agent_groups": G, "steps_per_launch": SPL, "parallelism": "agent-batch x%d" % world,
                        "dist_backend": ("gloo (host collectives: barriers, timing) + nccl (device collectives: exchange legs)"
                                         if backend == "nccl" else backend) if use_dist else None},
             "timed_region_s": elapsed, "ms_per_pass": 1e3 * elapsed / (args.steps * R),

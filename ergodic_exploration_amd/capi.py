@@ -124,6 +124,8 @@ def lib():
         L.eea_target_grid_size.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
         L.eea_get_target_grid.argtypes = [C.c_void_p, C.c_void_p]
         L.eea_control_batch.argtypes = [C.c_void_p, C.c_uint, C.POINTER(BatchIO), C.c_void_p]
+        L.eea_control_batch_steps.argtypes = [C.c_void_p, C.c_uint, C.POINTER(BatchIO), C.c_uint, C.c_uint, C.c_uint,
+                                              C.c_void_p]
         L.eea_set_option.argtypes = [C.c_int, C.c_int]
         L.eea_get_option.argtypes = [C.c_int]
         if hasattr(L, "eea_debug_phase_timing"):  # A/B library only (EEA_LIB_VARIANT=_ab, tools/ab/)
@@ -295,7 +297,9 @@ class Engine:
 
     def control_batch(self, B, pose, ut, u0, mem_cols=None, n_mem=None, mem_stride=0, traj=None,
                       ck=None, edx=None, bdx=None, rhot=None, status=None, stream=None, ck_shared=None,
-                      ck_rec=None, ck_shared_parts=0):
+                      ck_rec=None, ck_shared_parts=0, n_steps=None, pose_step_stride=0, u0_step_stride=0):
+        """n_steps (ABI 4, eea_control_batch_steps): that many consecutive control() calls per agent in one launch;
+        pose / u0 rows per step by the strides (in agents; 0 = the same row every step)."""
         io = BatchIO()
         io.d_ck_shared = _ptr(ck_shared)
         io.d_ck_rec, io.ck_shared_parts = _ptr(ck_rec), ck_shared_parts
@@ -303,10 +307,14 @@ class Engine:
         io.d_mem_cols, io.d_n_mem, io.mem_stride = _ptr(mem_cols), _ptr(n_mem), mem_stride
         io.d_traj, io.d_ck, io.d_edx, io.d_bdx = _ptr(traj), _ptr(ck), _ptr(edx), _ptr(bdx)
         io.d_rhot, io.d_status = _ptr(rhot), _ptr(status)
-        check(lib().eea_control_batch(self.h, B, C.byref(io), C.c_void_p(stream or 0)))
+        if n_steps is None:
+            check(lib().eea_control_batch(self.h, B, C.byref(io), C.c_void_p(stream or 0)))
+        else:
+            check(lib().eea_control_batch_steps(self.h, B, C.byref(io), n_steps, pose_step_stride, u0_step_stride,
+                                                C.c_void_p(stream or 0)))
 
     def prepared_batch(self, B, pose, ut, u0, mem_cols=None, n_mem=None, mem_stride=0, ck=None, ck_shared=None,
-                       stream=None, ck_rec=None, ck_shared_parts=0):
+                       stream=None, ck_rec=None, ck_shared_parts=0, n_steps=None, pose_step_stride=0, u0_step_stride=0):
         """A callable that issues eea_control_batch with these (fixed) device buffers: one ctypes call per pass, the
         eea_batch_io is built once (a pass of 4096 agents takes ~30 us on the device; building the struct from
         tensors every pass costs about as much on the host)."""
@@ -318,6 +326,14 @@ class Engine:
         io.d_ck_rec, io.ck_shared_parts = _ptr(ck_rec), ck_shared_parts
         fn, h, ref, st = lib().eea_control_batch, self.h, C.byref(io), C.c_void_p(stream or 0)
         keep = (io, pose, ut, u0, mem_cols, n_mem, ck, ck_shared, ck_rec)
+        if n_steps is not None:   # ABI 4: n_steps receding-horizon steps per launch
+            fns = lib().eea_control_batch_steps
+
+            def call_steps(_keep=keep):
+                rc = fns(h, B, ref, n_steps, pose_step_stride, u0_step_stride, st)
+                if rc != 0:
+                    check(rc)
+            return call_steps
 
         def call(_keep=keep):
             rc = fn(h, B, ref, st)

@@ -68,6 +68,10 @@ struct ControlParams
   // u0 / status of agent 0 are written; null for batches
   int* done;
   int done_seq;
+  // receding-horizon steps per launch (eea_control_batch_steps; 1 = eea_control_batch): step n reads pose row
+  // n * pose_step_stride + b and writes u0 row n * u0_step_stride + b (strides in agents: 0 = the same row every step)
+  int n_steps;
+  unsigned pose_step_stride, u0_step_stride;
 };
 
 template <typename R>
@@ -339,8 +343,8 @@ __device__ __forceinline__ R wrap_pi(R rad)
 // sum of that many sum records divided by the sum of their agent counts (element K^2 of a record).  A record set that
 // no agent contributed to (count 0: every agent of the producing pass was rejected, or the buffer is still zero) is no
 // consensus at all: the agent keeps its own c_k (`own`) -- the reference's behaviour -- instead of 0 / 0
-template <typename R>
-__device__ __forceinline__ R shared_ck_value(const ControlParams<R>& p, int m, int K2, R own)
+template <typename R, typename P>  // P: ControlParams<R>, possibly in the kernel-argument address space
+__device__ __forceinline__ R shared_ck_value(const P& p, int m, int K2, R own)
 {
   if (p.ck_shared_parts <= 0) return p.ck_shared[m];
   R s = R(0), n = R(0);

@@ -246,12 +246,31 @@ namespace wave
 // basis phase to the end of the gradient (lean_park_elems: the workgroup then uses a quarter of the CU's LDS exactly).
 template <typename R, int MODEL, int KC, bool STAGES, int WPB>
 __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE_KERNEL_ATTR void EEA_WAVE_KERNEL_NAME(
-    const ControlParams<R> p, const unsigned B, const int S, const int rollout_only)
+    const ControlParams<R> p_arg, const unsigned B, const int S, const int rollout_only)
 {
+  (void)p_arg;  // read through the kernel-argument segment below
   constexpr bool kParkSine = EEA_WAVE_KERNEL_LEAN;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  const int lane = threadIdx.x & (kWave - 1);
-  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  // Receding-horizon steps of this agent in ONE launch (eea_control_batch_steps): step n is a complete control() call
+  // from the pose of row n and the controls step n - 1 left in ut -- the wavefront reads its own stores back (from L2:
+  // the fences at the end of the loop body) instead of the host launching again.  n_steps == 1: eea_control_batch.
+  // Every step starts from the thread id alone, through a value the optimiser cannot see through: nothing lane- or
+  // agent-derived (step maps, LDS addresses, masks, pointers) is carried across the loop -- hoisted, those invariants
+  // cost the body ~460 B of scratch per lane; recomputed they cost what they cost a launch.
+  EEA_WSTAMP_RT(10);
+  EEA_WSTAMP_HWID(12);
+  typedef const __attribute__((address_space(4))) ControlParams<R> KernArgParams;
+  const int n_steps = ((KernArgParams*)__builtin_amdgcn_kernarg_segment_ptr())->n_steps;
+  for (int step = 0; step < n_steps; ++step) {
+  // ... and the launch parameters are re-read (scalar loads where they are used, as in a launch) through a pointer that
+  // is opaque per step: hoisted out of the loop they would all be live through the body (106 scalar registers + spills)
+  KernArgParams* ka = (KernArgParams*)__builtin_amdgcn_kernarg_segment_ptr();  // p_arg is argument 0
+  asm volatile("" : "+s"(ka));
+  KernArgParams& p = *ka;
+  unsigned tid_opaque = threadIdx.x;
+  asm volatile("" : "+v"(tid_opaque));
+  const int lane = tid_opaque & (kWave - 1);
+  const int wv = __builtin_amdgcn_readfirstlane(tid_opaque / kWave);
   const unsigned b = blockIdx.x * WPB + wv;
   if (b >= B) return;  // wavefront-uniform
 
@@ -294,11 +313,8 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
   auto lanes_in_slot = [&](int j) { return q16 + (j < sc ? (rem - j + sc - 1) / sc : 0); };
   // steps of another lane
   auto cnt_of = [&](int l) { return l < q16 ? S : max(0, min(sc, rem - sc * (l - q16))); };
-  const R* const pose = p.pose + 3 * static_cast<size_t>(b);
   R* const ut = p.ut + 3 * static_cast<size_t>(T) * b;
-
-  EEA_WSTAMP_RT(10);
-  EEA_WSTAMP_HWID(12);
+  const R* const pose = p.pose + 3 * (static_cast<size_t>(step) * p.pose_step_stride + b);
   EEA_WSTAMP(0);
   // ---- controls: shift left by one column, last column zero (ergodic_control.hpp:233-234) ------------
   R vx[kMaxS], vy[kMaxS], w[kMaxS];
@@ -1375,7 +1391,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
         o[2] = r2[j];
       }
       if (i == 0) {
-        R* const o = p.u0 + 3 * static_cast<size_t>(b);
+        R* const o = p.u0 + 3 * (static_cast<size_t>(step) * p.u0_step_stride + b);
         o[0] = u[0];
         o[1] = u[1];
         o[2] = u[2];
@@ -1387,6 +1403,15 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
     }
   }
   EEA_WSTAMP(9);
+  if (step + 1 < n_steps) {  // wavefront-uniform: the next step reads the controls just stored (and reuses the LDS)
+    // only THIS wavefront reads them back: work-group scope -- the stores drained (s_waitcnt vmcnt(0)), the CU's own
+    // write-through L1 is coherent for its own wavefronts.  (Agent scope writes back and invalidates the L2 on this
+    // multi-XCD part: 150 us per step, profiles/r04_multi_step.txt.)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    lds_fence();
+  }
+  }  // step
   EEA_WSTAMP_RT(11);
 }
 

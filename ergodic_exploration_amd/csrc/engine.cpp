@@ -435,6 +435,7 @@ void fill_params(const eea_engine* e, eea::ControlParams<R>& p)
   }
   p.phik = static_cast<const R*>(e->d_phik.p);
   p.lamdak = static_cast<const R*>(e->d_lamdak.p);
+  p.n_steps = 1;
 }
 
 // workspace of the sum written to `key` for up to B records (allocated on first use: one synchronisation, then none)
@@ -465,10 +466,14 @@ eea_status sum_workspace(eea_engine* e, const void* key, unsigned B, eea_engine:
 
 template <typename R>
 eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io, bool rollout_only,
-                              hipStream_t s, long long* d_stamps = nullptr)
+                              hipStream_t s, long long* d_stamps = nullptr, unsigned n_steps = 1,
+                              unsigned pose_step_stride = 0, unsigned u0_step_stride = 0)
 {
   eea::ControlParams<R> p;
   fill_params<R>(e, p);
+  p.n_steps = static_cast<int>(n_steps);
+  p.pose_step_stride = pose_step_stride;
+  p.u0_step_stride = u0_step_stride;
   p.pose = static_cast<const R*>(io->d_pose);
   p.ut = static_cast<R*>(io->d_ut);
   p.mem_cols = static_cast<const R*>(io->d_mem_cols);
@@ -502,7 +507,13 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
   if (lds > 160 * 1024) {
     return fail(EEA_ERR_UNSUPPORTED, "horizon/memory/basis too large for one workgroup's 160 KiB LDS");
   }
-  EEA_HIP(eea::launch_control<R>(p, B, e->cfg.model, n_mem_max, rollout_only, s));
+  // the workgroup-per-agent kernel takes one step per launch: a multi-step call is that many launches on the stream
+  p.n_steps = 1;
+  for (unsigned n = 0; n < n_steps; ++n) {
+    p.pose = static_cast<const R*>(io->d_pose) + 3 * static_cast<size_t>(n) * pose_step_stride;
+    p.u0 = static_cast<R*>(io->d_u0) + 3 * static_cast<size_t>(n) * u0_step_stride;
+    EEA_HIP(eea::launch_control<R>(p, B, e->cfg.model, n_mem_max, rollout_only, s));
+  }
   return EEA_OK;
 }
 
@@ -948,6 +959,27 @@ eea_status eea_control_batch(eea_engine* e, unsigned B, const eea_batch_io* io, 
                 : control_batch_impl<double>(e, B, io, false, s);
 }
 
+eea_status eea_control_batch_steps(eea_engine* e, unsigned B, const eea_batch_io* io, unsigned n_steps,
+                                   unsigned pose_step_stride, unsigned u0_step_stride, void* stream)
+{
+  if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (io == nullptr || io->d_pose == nullptr || io->d_ut == nullptr || io->d_u0 == nullptr) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "d_pose, d_ut and d_u0 are required");
+  }
+  if (n_steps == 0 || n_steps > (1u << 20)) return fail(EEA_ERR_INVALID_ARGUMENT, "n_steps must be in 1 .. 2^20");
+  if ((pose_step_stride != 0 && pose_step_stride < B) || (u0_step_stride != 0 && u0_step_stride < B)) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "a step stride is 0 (the same row every step) or >= B agents");
+  }
+  if (!e->have_phik) return fail(EEA_ERR_NO_TARGET, "no phi_k: call eea_config_domain or eea_set_target_grid first");
+  eea_status st = use_device(e);
+  if (st != EEA_OK) return st;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  st = order_after_rebuild(e, s);
+  if (st != EEA_OK) return st;
+  return e->f32 ? control_batch_impl<float>(e, B, io, false, s, nullptr, n_steps, pose_step_stride, u0_step_stride)
+                : control_batch_impl<double>(e, B, io, false, s, nullptr, n_steps, pose_step_stride, u0_step_stride);
+}
+
 eea_status eea_ck_records_sum(eea_engine* e, unsigned B, const void* d_ck_rec, void* d_sum, void* stream)
 {
   if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
@@ -1187,6 +1219,7 @@ eea_status eea_rk4_rollout(int device, int model, double dt, double horizon, con
     std::memset(&p, 0, sizeof(p));
     p.T = static_cast<int>(steps);
     p.K = 1;
+    p.n_steps = 1;
     p.chunk = 64;
     p.dt = dt;
     p.dt6 = dt / 6.0;

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EEA_ABI_VERSION 3
+#define EEA_ABI_VERSION 4
 
 /* models usable with ErgodicControl (Cart/Mecanum cannot run under it) */
 enum { EEA_MODEL_OMNI = 0,        /* models::Omni        models/omni.hpp:164-215 */
@@ -215,6 +215,21 @@ eea_status eea_ck_records_sum(eea_engine* e, unsigned B, const void* d_ck_rec, v
 /* One receding-horizon optimisation per agent (ergodic_control.hpp:224-311, without the
  * configTarget call: use eea_config_domain first).  Asynchronous on `stream`. */
 eea_status eea_control_batch(eea_engine* e, unsigned B, const eea_batch_io* io, void* stream);
+
+/* ABI 4: n_steps CONSECUTIVE receding-horizon optimisations per agent in ONE launch -- what n_steps calls of
+ * eea_control_batch do when each call's pose comes from a row of d_pose: step n runs control() (ergodic_control.hpp:224-311)
+ * from pose row n * pose_step_stride + b and the controls step n - 1 left in d_ut (the warm start of :233-234), and
+ * writes u = ut.col(0) to d_u0 row n * u0_step_stride + b.  Strides are in agents: 0 = the same row every step (a fixed
+ * pose; only the last step's u0 is kept), >= B = d_pose [n_steps][stride][3] / d_u0 [n_steps][stride][3] -- a logged
+ * pose sequence replayed through the controller (the replay harness of exploration.hpp:197-292 per agent), a
+ * closed-loop simulation driven from the host in chunks, or a throughput run.  Bitwise the same d_ut / d_u0 as the n_steps
+ * separate calls (tests/test_gpu_multi_step.py).  The other per-step outputs (d_ck, d_ck_rec, d_traj, stage outputs,
+ * d_status) hold the LAST step's values; d_ck_shared / replay-memory columns are read unchanged by every step.  The
+ * agent's wavefront carries on with its own stored controls (read back through L2) instead of the host launching again:
+ * no launch gap, no kernel tail, no cold loads between steps.  Horizons / bases outside the wavefront-per-agent kernel's
+ * range (T > 256, K > 16 and != 20) are issued as n_steps launches on the stream with the same semantics. */
+eea_status eea_control_batch_steps(eea_engine* e, unsigned B, const eea_batch_io* io, unsigned n_steps,
+                                   unsigned pose_step_stride, unsigned u0_step_stride, void* stream);
 
 /* Forward rollout only: ErgodicControl::optTraj / path (ergodic_control.hpp:313-342),
  * RungeKutta::solve (integrator.hpp:135-152).  d_ut is used as is (no shift). */
