@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--passes-per-step", type=int, default=4000,
+    ap.add_argument("--passes-per-step", type=int, default=16000,
                     help="consecutive control passes per timed step (receding horizon); the default keeps the GPU "
                          "busy for >= 2 s over the driver's --steps 20")
     ap.add_argument("--exchange-passes-per-step", type=int, default=400,
@@ -65,19 +65,19 @@ def parse():
                     help="skip the exchange legs (consensus all-reduce, c_k all-gather)")
     ap.add_argument("--force-exchange", "--force-gather", dest="force_exchange", action="store_true",
                     help="run the all-gather leg even with one rank (single-rank RCCL communicator)")
-    ap.add_argument("--consensus-lag", type=int, default=4, choices=[1, 2, 3, 4, 5],
-                    help="passes between producing c_k and consuming its consensus: the record sum of pass i gets its "
-                         "execution slots when the kernels of pass i + 1 finish, and the host launches pass i + lag only "
-                         "once that exchange has completed (tools/ck_cost.py: 34 / 30 / 30 us per pass at lag 2 / 3 / 4)")
-    ap.add_argument("--no-exchange-host-thread", action="store_true",
-                    help="one rank: keep the exchange's HIP calls on the launching thread (default: eea_comm_host_thread)")
+    ap.add_argument("--consensus-lags", default="1,2,4",
+                    help="the consensus leg is timed once per lag: pass i consumes the c_bar of pass i - lag.  Lag 1 is the "
+                         "previous step's consensus (decentralised ergodic control); the exchange is device-bound "
+                         "(eea_comm_records_exchange_bound): no host wait, no stream wait, no host thread at any lag")
     ap.add_argument("--consensus-buffers", type=int, default=8, choices=range(3, 9),
                     help="record / sum buffers (and exchange slots) the consensus leg rotates through")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per leg; 0 = skip")
     ap.add_argument("--no-latency", action="store_true", help="skip the B = 1 dependent-call leg")
     ap.add_argument("--no-phik", action="store_true", help="skip the phi_k legs (roofline_phik)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the legs of the other single-GPU BASELINE configs (configs[1], configs[2] fp32 + fp64)")
     ap.add_argument("--phik-grid", type=int, default=16384, help="side of the square fp64 grid of the phi_k leg")
-    ap.add_argument("--steps-per-launch", type=int, default=1,
+    ap.add_argument("--steps-per-launch", type=int, default=50,
                     help="receding-horizon steps (passes) per launch of the shard leg (eea_control_batch_steps: the agent's "
                          "wavefront carries on with its own stored controls; must divide --passes-per-step)")
     ap.add_argument("--agent-groups", type=int, default=2,
@@ -259,6 +259,98 @@ def phik_legs(args, torch, capi, np):
     return out
 
 
+def other_config_legs(args, torch, capi, np, spl):
+    """The other single-GPU BASELINE configurations, 4096 agents each, ~0.3 s timed, the same launch form as the headline
+    (two agent groups, `spl` receding-horizon steps per launch): configs[1] (SimpleCart, K = 10, horizon 2 s @ 0.1: T = 20,
+    fp64) and configs[2] (Omni, K = 20, horizon 5 s @ 0.02: T = 250, 256 x 256 target grid, fp32 -- and its fp64 twin).
+    Per leg: ms per pass, roofline fraction against the dtype's own vector peak, and the configTarget rebuild of that grid
+    (config/explore_omni.yaml:49-56 for the parameter names)."""
+    import time as _t
+    B = args.agents
+    cases = [
+        dict(name="configs[1]", model="simple_cart", K=10, dt=0.1, horizon=2.0, prec="f64", bounds=MAP_BOUNDS,
+             means=MEANS, sigmas=SIGMAS),
+        dict(name="configs[2]", model="omni", K=20, dt=0.02, horizon=5.0, prec="f32", bounds=(0.0, 25.5, 0.0, 25.5),
+             means=[[6.0, 6.0], [19.0, 12.0]], sigmas=[[3.0, 3.0], [3.0, 3.0]]),
+        dict(name="configs[2] fp64 twin", model="omni", K=20, dt=0.02, horizon=5.0, prec="f64", bounds=(0.0, 25.5, 0.0, 25.5),
+             means=[[6.0, 6.0], [19.0, 12.0]], sigmas=[[3.0, 3.0], [3.0, 3.0]]),
+    ]
+    res = []
+    for c in cases:
+        f32 = c["prec"] == "f32"
+        tdt = torch.float32 if f32 else torch.float64
+        if c["model"] == "simple_cart":
+            model, rdiag, lim = capi.MODEL_SIMPLE_CART, [1.0, 0.0, 2.0], np.array([1.0, 0.0, 2.0])
+        else:
+            model, rdiag, lim = capi.MODEL_OMNI, [1.0, 1.0, 2.0], np.array([1.0, 1.0, 2.0])
+        eng = capi.Engine(capi.make_config(model, c["dt"], c["horizon"], 0.1, 1.0, c["K"], np.diag(rdiag), -lim, lim,
+                                           precision=capi.PREC_F32 if f32 else capi.PREC_F64))
+        eng.set_target_gaussians(c["means"], c["sigmas"])
+        eng.config_domain(c["bounds"])
+        T, K = eng.T, c["K"]
+        b = c["bounds"]
+        rng = np.random.default_rng(777)
+        poses = np.stack([rng.uniform(0.5, b[1] - b[0] - 0.5, B) + b[0], rng.uniform(0.5, b[3] - b[2] - 0.5, B) + b[2],
+                          rng.uniform(-np.pi, np.pi, B)], 1)
+        d_pose = torch.as_tensor(poses, dtype=tdt).cuda()
+        d_ut = torch.zeros((B, T, 3), dtype=tdt, device="cuda")
+        d_u0 = torch.empty((B, 3), dtype=tdt, device="cuda")
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        half = B // 2
+        calls = [eng.prepared_batch(hi - lo, d_pose[lo:hi], d_ut[lo:hi], d_u0[lo:hi], stream=st.cuda_stream,
+                                    n_steps=None if spl == 1 else spl)
+                 for (lo, hi), st in zip(((0, half), (half, B)), streams)]
+        torch.cuda.synchronize()
+        # size the timed region from a short probe: ~0.3 s
+        def run(n_calls):
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            evj = torch.cuda.Event()
+            torch.cuda.synchronize()
+            ev0.record(streams[0])
+            streams[1].wait_event(ev0)
+            for _ in range(n_calls):
+                for call in calls:
+                    call()
+            evj.record(streams[1])
+            streams[0].wait_event(evj)
+            ev1.record(streams[0])
+            torch.cuda.synchronize()
+            return ev0.elapsed_time(ev1) / (n_calls * spl)   # ms per pass
+        probe = run(max(1, 200 // spl))
+        n_calls = max(2, int(0.3 / (probe * 1e-3) / spl))
+        run(max(1, n_calls // 4))
+        pass_ms = run(n_calls)
+        flops = 2 * K * K * T + 4 * K * K * T + (4 * K + 140) * T
+        peak = VALU_F32_PEAK_TF if f32 else VALU_F64_PEAK_TF
+        tfl = flops * B / (pass_ms * 1e-3) / 1e12
+        # configTarget rebuild of this configuration's grid: device time per rebuild (HIP events around 50 enqueue-only rebuilds)
+        st0 = streams[0]
+        alt = (b[0], b[1] + 0.1, b[2], b[3])   # (an extent change forces the rebuild; alternate between two extents)
+        for i in range(4):
+            eng.config_domain(alt if i % 2 == 0 else b)
+        evs = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        evs[0].record(st0)
+        for i in range(50):
+            eng.config_domain_async(alt if i % 2 == 0 else b, stream=st0.cuda_stream)
+        evs[1].record(st0)
+        enq = (_t.perf_counter() - t0) / 50
+        torch.cuda.synchronize()
+        nx, ny = eng.target_grid()[1:]
+        res.append({"config": c["name"], "kinematics": c["model"], "num_basis": K, "horizon_steps": T, "dt": c["dt"],
+                    "dtype": c["prec"], "agents": B, "steps_per_launch": spl, "passes_timed": n_calls * spl,
+                    "ms_per_pass": pass_ms, "value": B / (pass_ms * 1e-3), "unit": "optimisations/s",
+                    "roofline": {"bound": "valu-%s" % c["prec"], "achieved": tfl, "peak": peak, "unit": "TFLOP/s",
+                                 "frac": tfl / peak, "flops_per_optimisation": flops},
+                    "config_domain_rebuild": {"grid": "%dx%d" % (nx, ny), "device_us": 1e3 * evs[0].elapsed_time(evs[1]) / 50,
+                                              "enqueue_only_wall_us": 1e6 * enq}})
+        eng.close()
+    return {"note": "the other single-GPU BASELINE configurations in the headline's launch form (two agent groups x %d steps per "
+                    "launch), 4096 agents, ~0.3 s timed each, HIP events around the launches of both streams" % spl,
+            "cases": res}
+
+
 def dry_run(args):
     """EEA_BENCH_DRYRUN=1: the launch plumbing without a GPU (CPU test of `--gpus N`): the ranks rendezvous over
     gloo, take the max over ranks of a dummy time like the real legs do, run the grid-tile leg's partition + collective
@@ -398,10 +490,15 @@ def main():
     # launch on the exchange stream adds them (eea_ck_records_sum: sums + agent count), ONE collective adds the ranks'
     # records (nothing with one rank), and pass i + lag divides sum by count inside the kernel (ck_shared_parts = 1):
     # one launch of 2 wavefronts per 32 agents, resident beside the control kernels, instead of three dependent launches.
-    NB = min(8, max(args.consensus_lag + 2, args.consensus_buffers))  # record buffers in flight: pass i writes buffer i % NB and reads (i - lag) % NB; the
-    #                              earlier readers of buffer i % NB (pass i - 2) have finished before pass i starts (it
-    #                              waits for the exchange of pass i - lag >= their own)
+    LAGS = sorted({max(1, min(6, int(x))) for x in args.consensus_lags.split(",") if x.strip()}) or [1]
+    NB = min(8, max(max(LAGS) + 2, args.consensus_buffers))  # record buffers in flight: pass i writes buffer i % NB and
+    #                              reads (i - lag) % NB; the sum of pass i - NB has been consumed (its flag waited for) by
+    #                              passes that precede pass i on every group stream
     L = eng.ck_record_len
+    d_ready = torch.zeros((B,), dtype=torch.int32, device="cuda")   # device-bound exchange: per-agent ready marks ...
+    d_flag = torch.zeros((1,), dtype=torch.int32, device="cuda")    # ... and the flag of the finished exchange (sequence numbers)
+    d_xstatus = torch.zeros((B,), dtype=torch.int32, device="cuda")  # per-agent status of the consensus passes (timeouts)
+    cstate = {"lag": LAGS[0], "seq0": 0}
     d_arec = [torch.empty((B, L), dtype=tdt, device="cuda") for _ in range(NB)]   # per-agent records of a pass
     d_rec = [torch.zeros((L,), dtype=tdt, device="cuda") for _ in range(NB)]      # their sum (over all ranks)
     ev_grp = [[torch.cuda.Event() for _ in range(G)] for _ in range(NB)]
@@ -419,16 +516,16 @@ def main():
 
     xcalls = {}
 
-    def exchange_records(slot):
-        """sum of the pass's per-agent records and its all-reduce over the ranks, on the exchange stream, after EVERY
-        group's launch of that pass -- ONE C-ABI call (eea_comm_records_exchange_async); the consuming passes of all
-        group streams wait for its completion slot (eea_comm_wait)"""
+    def exchange_records(slot, seq):
+        """the exchange of a pass in ONE C-ABI call, device-bound (eea_comm_records_exchange_bound): the record sum polls the
+        agents' ready marks, the all-reduce over the ranks follows on the communicator's stream, the flag = seq behind it
+        is what the consuming kernels wait for -- no host wait, no stream wait"""
         if not host_staged:
             call = xcalls.get(slot)
             if call is None:
-                call = xcalls[slot] = xcomm.prepared_records_exchange(eng, B, d_arec[slot], d_rec[slot],
-                                                                      [st.cuda_stream for st in gstreams], slot)
-            call()
+                call = xcalls[slot] = xcomm.prepared_records_exchange_bound(eng, B, d_arec[slot], d_ready, d_rec[slot],
+                                                                            d_flag, slot)
+            call(seq)
             return
         # plumbing run (ranks share a GPU, gloo): the record sum on the device, the all-reduce staged through the host
         for g in range(G):
@@ -467,10 +564,6 @@ def main():
                 comm = capi.Comm(device, 1, 0, capi.comm_unique_id())
                 exchange_backend = "rccl through the C ABI (eea_comm_*), one rank"
             xcomm = comm if comm is not None else capi.Comm(device, 1, 0, None)
-            if not args.no_exchange_host_thread:
-                # the exchange's HIP calls on the communicator's own host thread: the launching thread keeps its slack
-                # (five default runs on one box: 29.1-30.8 us per pass with it, 28.1-36.1 without)
-                xcomm.host_thread(True)
             return
         if args.no_exchange:
             return
@@ -499,7 +592,7 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()):
             exchange_backend = "rccl through the C ABI (eea_comm_*)"
-            xcomm = comm   # (no host thread here: every RCCL call of this process stays on the thread that made the communicator)
+            xcomm = comm
         else:
             if comm is not None:
                 comm.close()
@@ -509,37 +602,45 @@ def main():
 
     state = {"i": 0}
     # eea_batch_io structs are built once per distinct buffer set, a pass is one ctypes call per group
-    SPL = max(1, args.steps_per_launch)
-    if R % SPL:
-        raise SystemExit("--steps-per-launch must divide --passes-per-step")
+    # receding-horizon steps per launch: the largest divisor of the passes per step that does not exceed the request
+    SPL = max(d for d in range(1, max(1, args.steps_per_launch) + 1) if R % d == 0)
     shard_calls = [eng.prepared_batch(a["B"], a["pose"], a["ut"], a["u0"], mem_cols=a["mem_cols"], n_mem=a["n_mem"],
                                       mem_stride=args.n_mem, stream=a["stream"],
                                       n_steps=None if SPL == 1 else SPL) for a in gargs]
+    shard1_calls = shard_calls if SPL == 1 else [
+        eng.prepared_batch(a["B"], a["pose"], a["ut"], a["u0"], mem_cols=a["mem_cols"], n_mem=a["n_mem"],
+                           mem_stride=args.n_mem, stream=a["stream"]) for a in gargs]
     exch_calls = {}
 
     def one_pass(leg):
         i = state["i"]
         state["i"] = i + 1
-        if leg == "shard":
+        if leg == "shard":      # SPL passes per call
             for call in shard_calls:
                 call()
             return
-        if leg == "consensus":
-            slot = i % NB
-            src = (i - args.consensus_lag) % NB if i >= args.consensus_lag else None
-            if not host_staged:
-                # two C-ABI calls per pass: the groups' control launches (each behind the exchange it consumes), then
-                # the exchange of this pass
-                call = exch_calls.get((slot, src))
-                if call is None:
-                    groups = [dict(B=a["B"], pose=a["pose"], ut=a["ut"], u0=a["u0"], mem_cols=a["mem_cols"],
-                                   n_mem=a["n_mem"], mem_stride=args.n_mem, stream=a["stream"],
-                                   ck_rec=d_arec[slot][gb[g]:gb[g + 1]],
-                                   ck_shared=None if src is None else d_rec[src],
-                                   ck_shared_parts=0 if src is None else 1) for g, a in enumerate(gargs)]
-                    call = exch_calls[(slot, src)] = xcomm.prepared_control_groups(eng, groups, -1 if src is None else src, slot)
+        if leg == "shard1":     # the same pass as ONE launch per pass and group (what rounds 1-3 timed)
+            for call in shard1_calls:
                 call()
-                exchange_records(slot)
+            return
+        if leg == "consensus":
+            lag = cstate["lag"]
+            slot = i % NB
+            src = (i - lag) % NB if i >= lag else None
+            seq = cstate["seq0"] + i + 1      # sequence numbers only grow (also from one timed() call to the next)
+            if not host_staged:
+                # device-bound: G control launches (ready marks out, flag wait in) + ONE exchange call, nothing else
+                for g, a in enumerate(gargs):
+                    call = exch_calls.get((g, slot, src))
+                    if call is None:
+                        call = exch_calls[(g, slot, src)] = eng.prepared_batch(
+                            a["B"], a["pose"], a["ut"], a["u0"], mem_cols=a["mem_cols"], n_mem=a["n_mem"],
+                            mem_stride=args.n_mem, stream=a["stream"], ck_rec=d_arec[slot][gb[g]:gb[g + 1]],
+                            rec_ready=d_ready[gb[g]:gb[g + 1]], status=d_xstatus[gb[g]:gb[g + 1]],
+                            ck_shared=None if src is None else d_rec[src], ck_shared_parts=0 if src is None else 1,
+                            ck_flag=None if src is None else d_flag)
+                    call(seq, seq - lag)
+                exchange_records(slot, seq)
                 return
             for g, a in enumerate(gargs):
                 if src is not None:   # the sum record of pass i - lag is complete (on every rank)
@@ -551,7 +652,7 @@ def main():
                         mem_stride=args.n_mem, stream=a["stream"], ck_rec=d_arec[slot][gb[g]:gb[g + 1]],
                         ck_shared=None if src is None else d_rec[src], ck_shared_parts=0 if src is None else 1)
                 call()
-            exchange_records(slot)
+            exchange_records(slot, seq)
             return
         # all-gather leg: one launch per pass that writes every agent's c_k, one ncclAllGather beside the next pass
         slot = i % 3
@@ -592,6 +693,8 @@ def main():
     def timed(leg, steps, warmup, passes=None):
         """EXACTLY `steps` steps (of `passes` passes each) between barrier + synchronize on both sides; max over ranks"""
         Rl = R if passes is None else passes
+        if leg == "consensus":
+            cstate["seq0"] += state["i"] + 8   # past every sequence number the previous consensus run used
         state["i"] = 0
         d_ut.zero_()      # on the compute stream ...
         fork_groups()     # ... and ordered before the first pass of every agent group
@@ -613,8 +716,6 @@ def main():
         for _ in range(steps * Rl // per):
             one_pass(leg)
         join_groups()         # the end event follows the last pass of EVERY agent group
-        if leg == "consensus" and xcomm is not None:
-            xcomm.flush()     # exchanges still queued on the communicator's host thread are issued
         ev1.record(compute)
         enqueue_s = time.perf_counter() - t0
         torch.cuda.synchronize()  # all streams of the device
@@ -630,6 +731,10 @@ def main():
         return elapsed, pass_ms, enqueue_s
 
     elapsed, pass_ms, enqueue_s = timed("shard", args.steps, args.warmup)
+    # the same passes as one launch per pass (short: 3 x 400 passes), device work contiguous with the headline leg
+    single_pass_ms = pass_ms
+    if SPL > 1:
+        _, single_pass_ms, single_enqueue_s = timed("shard1", 3, 1, passes=400)
 
     out = None
     if rank == 0:
@@ -646,7 +751,7 @@ def main():
         hbm_gbs = G * bytes_per_opt * Bl / launch_s / 1e9
         tflops = G * flops_per_opt * Bl / launch_s / 1e12
         traffic, traffic_source = None, None
-        for name in ("r03_control_pmc.json", "r02_control_pmc.json", "r01_control_pmc.json"):
+        for name in ("r04_control_pmc.json", "r03_control_pmc.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(pmc):
                 continue
@@ -661,22 +766,24 @@ def main():
                     break
             except Exception:
                 pass
-        # the rocprofv3 view of the same command shape (profiles/r03_bench_profile.json, written by
-        # tools/make_r03_profiles.py from a separate profiled run: NOT measured in this run)
+        # the rocprofv3 view of the same command shape (profiles/r04_bench_profile.json, written by
+        # tools/summarize_prof.py from a separate profiled run: NOT measured in this run)
         profiled = {}
         try:
-            with open(os.path.join(ROOT, "profiles", "r03_bench_profile.json")) as f:
+            with open(os.path.join(ROOT, "profiles", "r04_bench_profile.json")) as f:
                 rec = json.load(f)
             if (rec.get("agents") == B and rec.get("T") == T and rec.get("K") == K and rec.get("precision") == args.precision
-                    and rec.get("concurrent_launches") == G and args.model == "simple_cart" and not args.n_mem):
+                    and rec.get("concurrent_launches") == G and rec.get("steps_per_launch", 1) == SPL
+                    and args.model == "simple_cart" and not args.n_mem):
+                per_pass_us = rec["kernel_avg_us_profiled"] / SPL
                 profiled = {"kernel_avg_us_profiled": rec["kernel_avg_us_profiled"],
+                            "kernel_avg_us_per_pass_profiled": per_pass_us,
                             "pass_period_us_profiled": rec["pass_period_us_from_trace"],
-                            "frac_profiled": G * flops_per_opt * rec["agents_per_launch"] /
-                                             (rec["kernel_avg_us_profiled"] * 1e-6) / 1e12 / VALU_F64_PEAK_TF,
+                            "frac_profiled": G * flops_per_opt * rec["agents_per_launch"] / (per_pass_us * 1e-6) / 1e12 / VALU_F64_PEAK_TF,
                             "effective_clock_ghz_profiled": rec.get("effective_clock_ghz"),
-                            "profiled_source": "profiles/r03_bench_profile.json (rocprofv3 --kernel-trace --stats of this "
-                                               "command shape, timed-region dispatches only; clock from the A/B library's "
-                                               "phase stamps; separate runs on another box of the pool)"}
+                            "profiled_source": "profiles/r04_bench_profile.json (rocprofv3 --kernel-trace --stats of this "
+                                               "command shape, timed-region dispatches only; a separate run on another box "
+                                               "of the pool)"}
         except Exception:
             pass
         vpeak = VALU_F32_PEAK_TF if f32 else VALU_F64_PEAK_TF
@@ -697,27 +804,33 @@ def main():
                                         if backend == "nccl" else backend) if use_dist else None},
             "timed_region_s": elapsed, "ms_per_pass": 1e3 * elapsed / (args.steps * R),
             "spinup_passes": SPINUP_PASSES,
+            "single_launch_per_pass": {"ms_per_pass": single_pass_ms, "frac": tflops / vpeak * pass_ms / single_pass_ms,
+                                       "note": "the same passes as ONE launch per pass and agent group (eea_control_batch; "
+                                               "what rounds 1-3 reported), 3 x 400 passes right after the headline leg"},
             "host_enqueue_us_per_pass": 1e6 * enqueue_s / (args.steps * R),
             "parity_tol": PARITY_TOL[args.precision],
             "roofline": {"bound": "valu-%s" % args.precision,
-                         "kernel": "control_wave_kernel (%d concurrent launch%s per pass, one per agent group)"
-                                   % (G, "" if G == 1 else "es"),
+                         "kernel": "control_wave_kernel (%d concurrent launch%s, one per agent group, %d receding-horizon "
+                                   "step%s per launch)" % (G, "" if G == 1 else "es", SPL, "" if SPL == 1 else "s"),
                          "achieved": tflops, "peak": vpeak, "unit": "TFLOP/s", "frac": tflops / vpeak,
                          "traffic": traffic, "traffic_source": traffic_source,
-                         "flops_per_launch": flops_per_opt * Bl, "launch_ms": pass_ms, "agents_per_launch": Bl,
+                         "flops_per_launch": flops_per_opt * Bl * SPL, "launch_ms": pass_ms * SPL,
+                         "passes_per_launch": SPL, "agents_per_launch": Bl,
                          "concurrent_launches": G, "achieved_per_launch": tflops / G, **profiled,
                          "note": "the control kernel is vector-ALU / transcendental bound, not HBM bound (SURVEY.md "
                                  "8(d)); W = 2K^2N + 4K^2T + (4K+140)T flop per optimisation (reference formulation)"},
             "roofline_hbm": {"bound": "hbm", "kernel": "control kernel", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                             "traffic_source": traffic_source, "bytes_per_launch": bytes_per_opt * Bl,
-                             "launch_ms": pass_ms, "agents_per_launch": Bl, "concurrent_launches": G,
+                             "traffic_source": traffic_source, "bytes_per_launch": bytes_per_opt * Bl * SPL,
+                             "launch_ms": pass_ms * SPL, "passes_per_launch": SPL, "agents_per_launch": Bl,
+                             "concurrent_launches": G,
                              "achieved_per_launch": hbm_gbs / G},
         }
-        if world == 1 and args.cpu_seconds > 0:
-            one, allc = cpu_baseline(args, args.cpu_seconds)
-            out["cpu_baseline"] = one
-            out["cpu_baseline_all_cores"] = allc
+        if world == 1 and not args.no_other_configs and not args.n_mem:
+            try:
+                out["other_configs"] = other_config_legs(args, torch, capi, np, SPL)
+            except Exception as exc:  # the headline line must not die with a secondary leg
+                out["other_configs"] = {"error": repr(exc)}
         if world == 1 and not args.no_latency:
             x = poses[0].astype(np.float64)
             for _ in range(20):
@@ -835,15 +948,31 @@ def main():
             setup_exchange()
             exchange = {"backend": exchange_backend,
                         "consumer": "eea_batch_io::d_ck_shared as a sum record, ck_shared_parts = 1 (the gradient uses c_bar)"}
-            e_s, p_ms, q_s = timed("consensus", args.steps, args.warmup, passes=RX)
+            by_lag = {}
+            for lag in LAGS:
+                cstate["lag"] = lag
+                e_s, p_ms, q_s = timed("consensus", args.steps, args.warmup, passes=RX)
+                torch.cuda.synchronize()
+                by_lag[str(lag)] = {
+                    "pass_ms": p_ms, "pass_ms_vs_single_launch_pass": p_ms / single_pass_ms,
+                    "pass_ms_vs_headline": p_ms / pass_ms,
+                    "value": world * B * RX * args.steps / e_s, "unit": "optimisations/s",
+                    "host_enqueue_us_per_pass": 1e6 * q_s / (args.steps * RX),
+                    "agents_timed_out": int((d_xstatus != 0).sum().item())}
+            first = by_lag[str(LAGS[0])]
             exchange["consensus_allreduce"] = {
-                "host_enqueue_us_per_pass": 1e6 * q_s / (args.steps * RX),
-                "value": world * B * RX * args.steps / e_s, "unit": "optimisations/s", "ms_per_step": 1e3 * e_s / args.steps,
-                "pass_ms": p_ms, "pass_ms_vs_headline": p_ms / pass_ms, "lag_passes": args.consensus_lag,
-                "agent_groups": G, "bytes_per_rank_per_pass": rs * L,
-                "note": "every pass: the control kernels write per-agent sum records, one small launch on the exchange "
-                        "stream adds them (eea_ck_records_sum), one all-reduce of the record over the ranks (none with one "
-                        "rank); pass i divides the sums of pass i - lag by their count inside the kernel"}
+                "lag_passes": LAGS[0], "pass_ms": first["pass_ms"], "pass_ms_vs_headline": first["pass_ms_vs_headline"],
+                "pass_ms_vs_single_launch_pass": first["pass_ms_vs_single_launch_pass"],
+                "value": first["value"], "unit": "optimisations/s", "by_lag": by_lag,
+                "agent_groups": G, "bytes_per_rank_per_pass": rs * L, "host_threads": 0,
+                "protocol": "device-bound (eea_comm_records_exchange_bound): no host wait, no stream wait, no event",
+                "note": "every pass: the control kernels write per-agent sum records and ready marks (write-through, half way "
+                        "through the wavefront), ONE launch on the exchange stream polls the marks and adds the records "
+                        "beside the running control kernels (+ one all-reduce of the record over the ranks and a publish "
+                        "launch with an RCCL communicator), and pass i waits INSIDE its kernels, right before the first use "
+                        "of c_bar, for the flag of pass i - lag; lag 1 = the previous step's consensus.  One launch per pass "
+                        "and group (the headline runs %d steps per launch: pass_ms_vs_single_launch_pass is the like-for-"
+                        "like ratio)" % SPL}
             if use_dist or args.force_exchange:
                 d_all = [torch.empty((world * B, K2), dtype=tdt, device="cuda") for _ in range(2)]
                 e_s, p_ms, _ = timed("allgather", args.steps, args.warmup, passes=RX)
@@ -878,6 +1007,11 @@ def main():
     eng.close()
     if use_dist:
         dist.destroy_process_group()
+    # the CPU baseline LAST: every device leg above ran back to back (the driver samples GPU activity every few seconds)
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        one, allc = cpu_baseline(args, args.cpu_seconds)
+        out["cpu_baseline"] = one
+        out["cpu_baseline_all_cores"] = allc
     emit()
 
 

@@ -17,7 +17,7 @@ HEADER_PATH = os.path.join(ROOT, "include", "ergodic_amd.h")
 
 MODEL_OMNI, MODEL_SIMPLE_CART = 0, 1
 PREC_F64, PREC_F32 = 0, 1
-OK, ERR_INVALID_ARGUMENT, ERR_INVALID_TWIST, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_TARGET = range(6)
+OK, ERR_INVALID_ARGUMENT, ERR_INVALID_TWIST, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_TARGET, ERR_TIMEOUT = range(7)
 # eea_set_option (process-wide dispatch options; the library reads no environment variable)
 OPT_CONTROL_KERNEL, OPT_WORKGROUP_THREADS, OPT_COLLISION_IMPL, OPT_MAILBOX_POLL = range(4)
 
@@ -40,7 +40,8 @@ class BatchIO(C.Structure):
                 ("d_n_mem", C.c_void_p), ("mem_stride", C.c_uint), ("d_u0", C.c_void_p),
                 ("d_traj", C.c_void_p), ("d_ck", C.c_void_p), ("d_edx", C.c_void_p),
                 ("d_bdx", C.c_void_p), ("d_rhot", C.c_void_p), ("d_status", C.c_void_p),
-                ("d_ck_shared", C.c_void_p), ("d_ck_rec", C.c_void_p), ("ck_shared_parts", C.c_uint)]
+                ("d_ck_shared", C.c_void_p), ("d_ck_rec", C.c_void_p), ("ck_shared_parts", C.c_uint),
+                ("d_rec_ready", C.c_void_p), ("rec_seq", C.c_uint), ("d_ck_flag", C.c_void_p), ("ck_flag_seq", C.c_uint)]
 
 
 class CollisionCfg(C.Structure):
@@ -101,6 +102,9 @@ def lib():
         L.eea_ck_record_len.restype = C.c_uint
         L.eea_ck_record_len.argtypes = [C.c_void_p]
         L.eea_ck_records_sum.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.eea_ck_records_sum_bound.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p,
+                                               C.c_void_p]
+        L.eea_publish_record.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
         for name in ("eea_steps", "eea_num_modes", "eea_real_size", "eea_time_step", "eea_destroy"):
             getattr(L, name).argtypes = [C.c_void_p]
         L.eea_destroy.restype = None
@@ -143,10 +147,8 @@ def lib():
         L.eea_comm_records_exchange_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p,
                                                       C.c_void_p, C.c_uint, C.c_int]
         L.eea_comm_wait.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
-        L.eea_comm_control_groups.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
-                                              C.c_int]
-        L.eea_comm_host_thread.argtypes = [C.c_void_p, C.c_int]
-        L.eea_comm_flush.argtypes = [C.c_void_p]
+        L.eea_comm_records_exchange_bound.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint,
+                                                      C.c_void_p, C.c_void_p, C.c_int]
         L.eea_comm_allreduce_sum.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
         L.eea_comm_consensus_ck_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.eea_comm_allgather_ck_async.argtypes = [C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -297,7 +299,8 @@ class Engine:
 
     def control_batch(self, B, pose, ut, u0, mem_cols=None, n_mem=None, mem_stride=0, traj=None,
                       ck=None, edx=None, bdx=None, rhot=None, status=None, stream=None, ck_shared=None,
-                      ck_rec=None, ck_shared_parts=0, n_steps=None, pose_step_stride=0, u0_step_stride=0):
+                      ck_rec=None, ck_shared_parts=0, n_steps=None, pose_step_stride=0, u0_step_stride=0,
+                      rec_ready=None, rec_seq=0, ck_flag=None, ck_flag_seq=0):
         """n_steps (ABI 4, eea_control_batch_steps): that many consecutive control() calls per agent in one launch;
         pose / u0 rows per step by the strides (in agents; 0 = the same row every step)."""
         io = BatchIO()
@@ -307,6 +310,7 @@ class Engine:
         io.d_mem_cols, io.d_n_mem, io.mem_stride = _ptr(mem_cols), _ptr(n_mem), mem_stride
         io.d_traj, io.d_ck, io.d_edx, io.d_bdx = _ptr(traj), _ptr(ck), _ptr(edx), _ptr(bdx)
         io.d_rhot, io.d_status = _ptr(rhot), _ptr(status)
+        io.d_rec_ready, io.rec_seq, io.d_ck_flag, io.ck_flag_seq = _ptr(rec_ready), rec_seq, _ptr(ck_flag), ck_flag_seq
         if n_steps is None:
             check(lib().eea_control_batch(self.h, B, C.byref(io), C.c_void_p(stream or 0)))
         else:
@@ -314,7 +318,8 @@ class Engine:
                                                 C.c_void_p(stream or 0)))
 
     def prepared_batch(self, B, pose, ut, u0, mem_cols=None, n_mem=None, mem_stride=0, ck=None, ck_shared=None,
-                       stream=None, ck_rec=None, ck_shared_parts=0, n_steps=None, pose_step_stride=0, u0_step_stride=0):
+                       stream=None, ck_rec=None, ck_shared_parts=0, n_steps=None, pose_step_stride=0, u0_step_stride=0,
+                       rec_ready=None, ck_flag=None, status=None):
         """A callable that issues eea_control_batch with these (fixed) device buffers: one ctypes call per pass, the
         eea_batch_io is built once (a pass of 4096 agents takes ~30 us on the device; building the struct from
         tensors every pass costs about as much on the host)."""
@@ -324,8 +329,17 @@ class Engine:
         io.d_mem_cols, io.d_n_mem, io.mem_stride = _ptr(mem_cols), _ptr(n_mem), mem_stride
         io.d_ck = _ptr(ck)
         io.d_ck_rec, io.ck_shared_parts = _ptr(ck_rec), ck_shared_parts
+        io.d_rec_ready, io.d_ck_flag, io.d_status = _ptr(rec_ready), _ptr(ck_flag), _ptr(status)
         fn, h, ref, st = lib().eea_control_batch, self.h, C.byref(io), C.c_void_p(stream or 0)
-        keep = (io, pose, ut, u0, mem_cols, n_mem, ck, ck_shared, ck_rec)
+        keep = (io, pose, ut, u0, mem_cols, n_mem, ck, ck_shared, ck_rec, rec_ready, ck_flag, status)
+        if rec_ready is not None or ck_flag is not None:
+            # device-bound exchange: the sequence numbers change from pass to pass -- call(rec_seq, ck_flag_seq)
+            def call_bound(rec_seq=0, ck_flag_seq=0, _keep=keep):
+                io.rec_seq, io.ck_flag_seq = rec_seq, ck_flag_seq
+                rc = fn(h, B, ref, st)
+                if rc != 0:
+                    check(rc)
+            return call_bound
         if n_steps is not None:   # ABI 4: n_steps receding-horizon steps per launch
             fns = lib().eea_control_batch_steps
 
@@ -349,6 +363,14 @@ class Engine:
     def ck_records_sum(self, B, recs, out, stream=None):
         """out[record_len] = sum of the B per-agent records (one launch, fixed order)"""
         check(lib().eea_ck_records_sum(self.h, B, _ptr(recs), _ptr(out), C.c_void_p(stream or 0)))
+
+    def ck_records_sum_bound(self, B, recs, rec_ready, seq, out, flag=None, stream=None):
+        """eea_ck_records_sum_bound: the sum polls the agents' ready marks (== seq) itself; flag (optional) = seq when done"""
+        check(lib().eea_ck_records_sum_bound(self.h, B, _ptr(recs), _ptr(rec_ready), seq, _ptr(out), _ptr(flag),
+                                             C.c_void_p(stream or 0)))
+
+    def publish_record(self, src, pub, flag, seq, stream=None):
+        check(lib().eea_publish_record(self.h, _ptr(src), _ptr(pub), _ptr(flag), seq, C.c_void_p(stream or 0)))
 
     def ck_sum(self, B, ck, sums, stream=None):
         """sums[:K2] = sum over the B agents of ck, sums[K2] = B (device tensors)"""
@@ -548,32 +570,19 @@ class Comm:
                 check(rc)
         return call
 
-    def host_thread(self, on=True):
-        """eea_comm_host_thread: the exchange's HIP calls issued by a thread the communicator owns"""
-        check(lib().eea_comm_host_thread(self.h, 1 if on else 0))
+    def records_exchange_bound(self, eng, B_local, ck_rec, rec_ready, seq, out_sum, flag, slot):
+        """eea_comm_records_exchange_bound: the device-bound exchange of one pass (no host or stream waits anywhere)"""
+        check(lib().eea_comm_records_exchange_bound(eng.h, self.h, B_local, _ptr(ck_rec), _ptr(rec_ready), seq,
+                                                    _ptr(out_sum), _ptr(flag), slot))
 
-    def flush(self):
-        """eea_comm_flush: every queued exchange has been issued to the device (call before a host synchronisation)"""
-        check(lib().eea_comm_flush(self.h))
+    def prepared_records_exchange_bound(self, eng, B_local, ck_rec, rec_ready, out_sum, flag, slot):
+        """the same as a callable call(seq) with the argument marshalling done once"""
+        fn, h, eh = lib().eea_comm_records_exchange_bound, self.h, eng.h
+        a = (_ptr(ck_rec), _ptr(rec_ready), _ptr(out_sum), _ptr(flag))
+        keep = (ck_rec, rec_ready, out_sum, flag)
 
-    def prepared_control_groups(self, eng, groups, wait_slot, exchange_slot=-1):
-        """eea_comm_control_groups as a callable: groups = [dict(B, pose, ut, u0, stream, mem_cols, n_mem, mem_stride, ck,
-        ck_rec, ck_shared, ck_shared_parts)]; the eea_batch_io array is built once"""
-        n = len(groups)
-        ios = (BatchIO * n)()
-        Bs = (C.c_uint * n)(*[g["B"] for g in groups])
-        streams = (C.c_void_p * n)(*[C.c_void_p(g.get("stream") or 0) for g in groups])
-        keep = [ios, Bs, streams]
-        for io, g in zip(ios, groups):
-            io.d_pose, io.d_ut, io.d_u0 = _ptr(g["pose"]), _ptr(g["ut"]), _ptr(g["u0"])
-            io.d_mem_cols, io.d_n_mem, io.mem_stride = _ptr(g.get("mem_cols")), _ptr(g.get("n_mem")), g.get("mem_stride", 0)
-            io.d_ck, io.d_ck_rec = _ptr(g.get("ck")), _ptr(g.get("ck_rec"))
-            io.d_ck_shared, io.ck_shared_parts = _ptr(g.get("ck_shared")), g.get("ck_shared_parts", 0)
-            keep.append(dict(g))
-        fn, args = lib().eea_comm_control_groups, (eng.h, self.h, n, Bs, ios, streams, wait_slot, exchange_slot)
-
-        def call(_keep=keep):
-            rc = fn(*args)
+        def call(seq, _keep=keep):
+            rc = fn(eh, h, B_local, a[0], a[1], seq, a[2], a[3], slot)
             if rc != 0:
                 check(rc)
         return call

@@ -13,10 +13,8 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
-#include <atomic>
 #include <cstring>
 #include <string>
-#include <thread>
 
 #include "abi_util.hpp"
 #include "common.hpp"
@@ -130,35 +128,13 @@ struct eea_comm
   hipStream_t xstream = nullptr;
   hipEvent_t ev_in = nullptr;
   hipEvent_t ev_done[EEA_COMM_SLOTS] = {};
-  // completion of the agent groups' control launches of the current pass (eea_comm_control_groups): what the exchange
-  // of that pass waits for; bound to the kernels themselves, not recorded separately
+  // completion of the agent groups' control launches of a pass (eea_comm_records_exchange_async records them)
   static constexpr unsigned kMaxGroups = 8;
-  hipEvent_t ev_group[EEA_COMM_SLOTS][kMaxGroups] = {};  // per exchange slot: the pass that feeds it
-  unsigned groups_launched = 0;  // groups of the pass being issued (eea_comm_control_groups sets, the exchange takes)
-  int groups_slot = 0;           // ... and the exchange slot their events belong to
-
-  // Optional host thread that issues the exchange's HIP calls (eea_comm_host_thread): a pass of 4096 agents gives the
-  // host ~25 us, and the four event waits + three launches of a consensus pass take a thread of these hosts 25-40 us.
-  // The caller's thread then only queues a request; the worker orders it behind the groups' kernels (their events are
-  // already bound) and binds the completion event.  A consumer that wants to wait on a slot's completion event first
-  // makes sure the worker has bound it (issued >= slot_seq[slot]).
-  struct Req
-  {
-    eea_engine* e;
-    unsigned B;
-    const void* rec;
-    void* sum;
-    int slot;
-    unsigned mask;
-  };
-  static constexpr unsigned kRing = 16;
-  Req ring[kRing] = {};
-  std::atomic<unsigned long> submitted{ 0 }, issued{ 0 };
-  unsigned long slot_seq[EEA_COMM_SLOTS] = {};
-  std::atomic<bool> stop{ false };
-  std::atomic<int> worker_status{ EEA_OK };
-  std::thread worker;
-  bool host_thread = false;
+  hipEvent_t ev_group[EEA_COMM_SLOTS][kMaxGroups] = {};
+  // device-bound exchange with more than one rank: per slot, the sum record the ranks all-reduce (the control kernels
+  // read the PUBLISHED copy, eea_comm_records_exchange_bound)
+  void* d_xrec[EEA_COMM_SLOTS] = {};
+  size_t xrec_cap[EEA_COMM_SLOTS] = {};
 };
 
 namespace
@@ -227,12 +203,6 @@ void eea_comm_destroy(eea_comm* c)
 {
   if (c == nullptr) return;
   (void)hipSetDevice(c->device);
-  if (c->host_thread) {  // the worker first: it uses the stream and the events destroyed below
-    (void)eea_comm_flush(c);
-    c->stop.store(true, std::memory_order_release);
-    if (c->worker.joinable()) c->worker.join();
-    c->host_thread = false;
-  }
   if (c->xstream) {
     (void)hipStreamSynchronize(c->xstream);
     (void)hipStreamDestroy(c->xstream);
@@ -248,6 +218,9 @@ void eea_comm_destroy(eea_comm* c)
   }
   if (c->comm != nullptr && rccl().ok) (void)rccl().CommDestroy(c->comm);
   if (c->d_sums) (void)hipFree(c->d_sums);
+  for (void* q : c->d_xrec) {
+    if (q) (void)hipFree(q);
+  }
   delete c;
 }
 
@@ -370,148 +343,12 @@ eea_status eea_comm_allreduce_sum_async(eea_engine* e, eea_comm* c, void* d_buf,
 
 }  // extern "C"
 
-namespace
-{
-// the worker (if any) has bound the completion event of `slot`
-void ensure_issued(eea_comm* c, int slot)
-{
-  if (!c->host_thread) return;
-  const unsigned long want = c->slot_seq[slot];
-  while (c->issued.load(std::memory_order_acquire) < want) __builtin_ia32_pause();
-}
-
-// the HIP calls of one exchange: the exchange stream behind the groups' kernels, record sum, all-reduce, completion event.
-// paced (the communicator's host thread): the thread polls the completion of the groups' kernels itself -- it has nothing
-// else to do -- and the exchange stream carries no barrier packet either; a group that is very late gets a stream wait
-eea_status issue_exchange(eea_comm* c, const eea_comm::Req& r, bool paced)
-{
-  for (unsigned g = 0; g < eea_comm::kMaxGroups; ++g) {
-    if (!(r.mask & (1u << g))) continue;
-    bool done = false;
-    for (int spin = 0; paced && spin < 4000 && !done; ++spin) {
-      done = hipEventQuery(c->ev_group[r.slot][g]) == hipSuccess;
-      if (!done) {
-        for (int k = 0; k < 16; ++k) __builtin_ia32_pause();  // leave the runtime's locks to the launching thread
-      }
-    }
-    if (!done) EEA_HIP(hipStreamWaitEvent(c->xstream, c->ev_group[r.slot][g], 0));
-  }
-  const bool collective = c->comm != nullptr;
-  if (!collective) eea::set_stop_event(c->ev_done[r.slot]);  // the record sum is the last step: its kernel carries the event
-  eea_status st = eea_ck_records_sum(r.e, r.B, r.rec, r.sum, c->xstream);
-  (void)eea::take_stop_event();
-  if (st != EEA_OK) return st;
-  if (collective) {
-    st = eea_comm_allreduce_sum(r.e, c, r.sum, eea_ck_record_len(r.e), c->xstream);
-    if (st != EEA_OK) return st;
-    EEA_HIP(hipEventRecord(c->ev_done[r.slot], c->xstream));
-  }
-  return EEA_OK;
-}
-
-void worker_main(eea_comm* c)
-{
-  (void)hipSetDevice(c->device);
-  unsigned idle = 0;
-  while (!c->stop.load(std::memory_order_acquire)) {
-    const unsigned long n = c->issued.load(std::memory_order_relaxed);
-    if (c->submitted.load(std::memory_order_acquire) > n) {
-      const eea_status st = issue_exchange(c, c->ring[n % eea_comm::kRing], true);
-      if (st != EEA_OK) c->worker_status.store(st, std::memory_order_relaxed);
-      c->issued.store(n + 1, std::memory_order_release);
-      idle = 0;
-    } else if (++idle < 20000) {
-      __builtin_ia32_pause();
-    } else {
-      std::this_thread::yield();  // nothing for a while: stop burning the core
-    }
-  }
-}
-}  // namespace
-
 extern "C" {
 
-eea_status eea_comm_host_thread(eea_comm* c, int on)
-{
-  if (c == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null communicator");
-  if ((on != 0) == c->host_thread) return EEA_OK;
-  if (on == 0) {
-    (void)eea_comm_flush(c);
-    c->stop.store(true, std::memory_order_release);
-    if (c->worker.joinable()) c->worker.join();
-    c->host_thread = false;
-    return EEA_OK;
-  }
-  // everything the worker touches exists before it starts
-  eea_status st = async_begin(c, nullptr, 0, false);
-  if (st != EEA_OK) return st;
-  for (int slot = 0; slot < EEA_COMM_SLOTS; ++slot) {
-    if (c->ev_done[slot] == nullptr) EEA_HIP(hipEventCreateWithFlags(&c->ev_done[slot], kDeviceEvent));
-    for (unsigned g = 0; g < eea_comm::kMaxGroups; ++g) {
-      if (c->ev_group[slot][g] == nullptr) EEA_HIP(hipEventCreateWithFlags(&c->ev_group[slot][g], kDeviceEvent));
-    }
-  }
-  c->stop.store(false, std::memory_order_release);
-  c->worker = std::thread(worker_main, c);
-  c->host_thread = true;
-  return EEA_OK;
-}
-
-eea_status eea_comm_flush(eea_comm* c)
-{
-  if (c == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null communicator");
-  if (c->host_thread) {
-    const unsigned long want = c->submitted.load(std::memory_order_relaxed);
-    while (c->issued.load(std::memory_order_acquire) < want) __builtin_ia32_pause();
-  }
-  const int ws = c->worker_status.load(std::memory_order_relaxed);
-  if (ws != EEA_OK) return fail(static_cast<eea_status>(ws), "an exchange issued by the communicator's host thread failed");
-  return EEA_OK;
-}
-
-// Queries of an exchange's completion event before eea_comm_control_groups gives up pacing and enqueues a stream wait.
-// The fall-back is expensive for many passes (it drags the group streams into lockstep), so it is for an exchange that is
-// really stuck, not for one that is a few passes late: with 400 queries (~0.2 ms) bench.py's consensus leg took 28.0-29.0 us
-// per pass, with 100 000 it takes 27.3-27.5 (five interleaved runs each, one box).
-constexpr int kPaceSpins = 100000;
-
-eea_status eea_comm_control_groups(eea_engine* e, eea_comm* c, unsigned n_groups, const unsigned* B,
-                                   const eea_batch_io* ios, void* const* group_streams, int wait_slot, int exchange_slot)
-{
-  if (e == nullptr || c == nullptr || B == nullptr || ios == nullptr || group_streams == nullptr) {
-    return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
-  }
-  if (wait_slot >= EEA_COMM_SLOTS || exchange_slot >= EEA_COMM_SLOTS || n_groups > eea_comm::kMaxGroups) {
-    return fail(EEA_ERR_INVALID_ARGUMENT, "bad slot / group count");
-  }
-  EEA_HIP(hipSetDevice(c->device));
-  if (wait_slot >= 0) ensure_issued(c, wait_slot);
-  c->groups_launched = 0;
-  c->groups_slot = exchange_slot;
-  bool exchange_done = false;  // of wait_slot: polled once for all groups
-  for (unsigned g = 0; g < n_groups; ++g) {
-    hipEvent_t* const ev = exchange_slot >= 0 ? &c->ev_group[exchange_slot][g] : nullptr;
-    if (ev != nullptr && *ev == nullptr) EEA_HIP(hipEventCreateWithFlags(ev, kDeviceEvent));
-    if (B[g] == 0) continue;
-    hipStream_t s = static_cast<hipStream_t>(group_streams[g]);
-    // Behind the exchange it consumes.  The host paces itself instead of the stream: it polls the exchange's completion
-    // (kPaceSpins queries, tens of milliseconds, at most) and launches once it is there -- with a lag of >= 2 passes the device still
-    // has the passes in between queued, and the group streams carry no barrier packet at all (a wait enqueued while the
-    // exchange is in flight costs the stream 5-13 us per pass even when it is satisfied long before its turn:
-    // tools/ck_cost.py).  Only an exchange that is really late gets a stream wait.
-    if (wait_slot >= 0 && c->ev_done[wait_slot] != nullptr && !exchange_done) {
-      for (int spin = 0; spin < kPaceSpins && !exchange_done; ++spin) exchange_done = hipEventQuery(c->ev_done[wait_slot]) == hipSuccess;
-      if (!exchange_done) EEA_HIP(hipStreamWaitEvent(s, c->ev_done[wait_slot], 0));
-    }
-    if (ev != nullptr) eea::set_stop_event(*ev);  // bound to the control kernel of this call
-    const eea_status st = eea_control_batch(e, B[g], &ios[g], group_streams[g]);
-    (void)eea::take_stop_event();                 // (not consumed if the call failed before its launch)
-    if (st != EEA_OK) return st;
-    if (ev != nullptr) c->groups_launched |= 1u << g;
-  }
-  return EEA_OK;
-}
-
+// The exchange of one pass, stream-ordered: the exchange stream waits for everything enqueued so far on each group
+// stream (one event per group), then record sum, then the all-reduce of the sum record over the ranks; the consuming
+// streams eea_comm_wait for the slot.  Correct by construction and the form AgentBatch-style hosts use at their control
+// rate; a consensus EVERY pass at the device's own rate is eea_comm_records_exchange_bound.
 eea_status eea_comm_records_exchange_async(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_rec,
                                            void* d_sum, void* const* group_streams, unsigned n_streams, int slot)
 {
@@ -522,36 +359,61 @@ eea_status eea_comm_records_exchange_async(eea_engine* e, eea_comm* c, unsigned 
   if (n_streams > eea_comm::kMaxGroups) return fail(EEA_ERR_INVALID_ARGUMENT, "too many group streams");
   eea_status st = async_begin(c, nullptr, slot, false);
   if (st != EEA_OK) return st;
-  eea_comm::Req r{ e, B_local, d_ck_rec, d_sum, slot, 0u };
-  if (c->groups_launched != 0 && c->groups_slot == slot) {
-    // the groups' control kernels of this pass came through eea_comm_control_groups: their completion events are bound
-    r.mask = c->groups_launched;
-    c->groups_launched = 0;
-  } else {
-    // ... otherwise: after everything enqueued so far on each of the group streams
-    for (unsigned g = 0; g < n_streams; ++g) {
-      if (c->ev_group[slot][g] == nullptr) EEA_HIP(hipEventCreateWithFlags(&c->ev_group[slot][g], kDeviceEvent));
-      EEA_HIP(hipEventRecord(c->ev_group[slot][g], static_cast<hipStream_t>(group_streams[g])));
-      r.mask |= 1u << g;
-    }
+  for (unsigned g = 0; g < n_streams; ++g) {
+    if (c->ev_group[slot][g] == nullptr) EEA_HIP(hipEventCreateWithFlags(&c->ev_group[slot][g], kDeviceEvent));
+    EEA_HIP(hipEventRecord(c->ev_group[slot][g], static_cast<hipStream_t>(group_streams[g])));
+    EEA_HIP(hipStreamWaitEvent(c->xstream, c->ev_group[slot][g], 0));
   }
-  if (!c->host_thread) return issue_exchange(c, r, false);
-  // hand the HIP calls to the worker thread
-  const unsigned long n = c->submitted.load(std::memory_order_relaxed);
-  while (n - c->issued.load(std::memory_order_acquire) >= eea_comm::kRing) __builtin_ia32_pause();
-  c->ring[n % eea_comm::kRing] = r;
-  c->slot_seq[slot] = n + 1;
-  c->submitted.store(n + 1, std::memory_order_release);
-  const int ws = c->worker_status.load(std::memory_order_relaxed);
-  if (ws != EEA_OK) return fail(static_cast<eea_status>(ws), "an exchange issued by the communicator's host thread failed");
+  st = eea_ck_records_sum(e, B_local, d_ck_rec, d_sum, c->xstream);
+  if (st != EEA_OK) return st;
+  st = eea_comm_allreduce_sum(e, c, d_sum, eea_ck_record_len(e), c->xstream);  // (nothing without an RCCL communicator)
+  if (st != EEA_OK) return st;
+  EEA_HIP(hipEventRecord(c->ev_done[slot], c->xstream));
   return EEA_OK;
+}
+
+// The exchange of one pass, DEVICE-BOUND (ABI 4): nothing is ordered by the host or by stream waits.  On the
+// communicator's own highest-priority stream: the record sum that polls the agents' ready marks (eea_ck_records_sum_bound:
+// it starts while the producing control kernels are still in their backward halves), with more than one rank (or a
+// one-rank RCCL communicator) the all-reduce of the sum record over the ranks and one small launch that publishes the
+// result write-through, and *d_flag = seq behind it.  The control kernels that consume d_sum are launched WITHOUT
+// waiting -- eea_batch_io::d_ck_flag / ck_flag_seq make them wait inside the kernel, right before the first use of the
+// shared c_k (~45 % into the wavefront's lifetime).  Caller's duties: rotate d_ck_rec / d_sum over >= 3 buffers (slot =
+// the buffer index; d_rec_ready and d_flag may be shared by all buffers: sequence numbers only grow), and keep every
+// batch that consumes a flag small enough that the producers it waits for can be resident beside it (two agent groups
+// per GPU are: each holds half of the execution slots) -- a consumer that cannot be served gives up after tens of
+// milliseconds with EEA_ERR_TIMEOUT in d_status and its own c_k.
+eea_status eea_comm_records_exchange_bound(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_rec,
+                                           const unsigned* d_rec_ready, unsigned seq, void* d_sum, unsigned* d_flag, int slot)
+{
+  if (e == nullptr || d_ck_rec == nullptr || d_rec_ready == nullptr || d_sum == nullptr || d_flag == nullptr) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  }
+  if (c == nullptr || slot < 0 || slot >= EEA_COMM_SLOTS) return fail(EEA_ERR_INVALID_ARGUMENT, "bad communicator / slot");
+  eea_status st = async_begin(c, nullptr, slot, false);
+  if (st != EEA_OK) return st;
+  if (c->comm == nullptr) {  // one rank, no collective: the sum's last wavefront publishes the flag itself
+    return eea_ck_records_sum_bound(e, B_local, d_ck_rec, d_rec_ready, seq, d_sum, d_flag, c->xstream);
+  }
+  const size_t bytes = eea_real_size(e) * eea_ck_record_len(e);
+  if (c->xrec_cap[slot] < bytes) {
+    if (c->d_xrec[slot]) (void)hipFree(c->d_xrec[slot]);
+    c->d_xrec[slot] = nullptr;
+    c->xrec_cap[slot] = 0;
+    EEA_HIP(hipMalloc(&c->d_xrec[slot], bytes));
+    c->xrec_cap[slot] = bytes;
+  }
+  st = eea_ck_records_sum_bound(e, B_local, d_ck_rec, d_rec_ready, seq, c->d_xrec[slot], nullptr, c->xstream);
+  if (st != EEA_OK) return st;
+  st = eea_comm_allreduce_sum(e, c, c->d_xrec[slot], eea_ck_record_len(e), c->xstream);
+  if (st != EEA_OK) return st;
+  return eea_publish_record(e, c->d_xrec[slot], d_sum, d_flag, seq, c->xstream);
 }
 
 eea_status eea_comm_wait(eea_comm* c, int slot, void* stream)
 {
   if (c == nullptr || slot < 0 || slot >= EEA_COMM_SLOTS) return fail(EEA_ERR_INVALID_ARGUMENT, "bad communicator / slot");
   if (c->ev_done[slot] == nullptr) return EEA_OK;  // nothing was ever started in this slot
-  ensure_issued(c, slot);
   if (hipEventQuery(c->ev_done[slot]) == hipSuccess) return EEA_OK;  // already finished: nothing to wait for
   EEA_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), c->ev_done[slot], 0));
   return EEA_OK;

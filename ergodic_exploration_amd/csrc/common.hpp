@@ -22,13 +22,6 @@ enum : int { kModelOmni = 0, kModelSimpleCart = 1 };
 
 // process-wide dispatch option (eea_set_option, EEA_OPT_* of include/ergodic_amd.h); defined in engine.cpp
 int option(int id);
-// Completion event for the NEXT control / record-sum launch of the calling thread (internal: the exchange entry points
-// of comm.hip set it right before they call eea_control_batch / eea_ck_records_sum).  The launch site takes it and binds
-// it to the kernel itself (hipExtLaunchKernelGGL's stop event: the kernel's own completion signal instead of a separate
-// event-record packet -- an event operation costs the host ~3 us, as much as a launch).  Defined in engine.cpp.
-void set_stop_event(hipEvent_t ev);
-hipEvent_t take_stop_event();
-
 // Everything one control launch needs; passed by value (kernarg).
 template <typename R>
 struct ControlParams
@@ -59,6 +52,14 @@ struct ControlParams
   int rec_len;         // K^2 + 1 rounded up to even: [sums over agents of c_k, number of agents, pad]
   // per-agent sum records (eea_batch_io::d_ck_rec): [B][rec_len] = [c_k, 1 (0 for a rejected agent), pad]; optional
   R* ck_rec;
+  // device-bound exchange (eea_batch_io::d_rec_ready / d_ck_flag): rec_ready[b] = rec_seq once agent b's record is
+  // visible device-wide (the record sum waits for the marks, not for the kernel); the consumer waits until
+  // *ck_flag - ck_flag_seq >= 0 (mod 2^32) right before it reads ck_shared ("late binding": ~45 % into the wavefront's
+  // lifetime) and reads it past its L1
+  unsigned* rec_ready;
+  unsigned rec_seq;
+  const unsigned* ck_flag;
+  unsigned ck_flag_seq;
   R* edx;
   R* bdx;
   R* rhot;
@@ -104,10 +105,16 @@ inline size_t ck_sum_ws_elems(unsigned B, int K2)
 inline size_t ck_sum_tickets(unsigned B, int K2)
 {
   const size_t g1 = (ck_sum_groups(B) + kSumFan - 1) / kSumFan;
-  return ck_sum_slices(K2) * (g1 + 1);
+  return ck_sum_slices(K2) * (g1 + 1) + 1;  // per slice: level-1 tickets + the level-2 ticket; then the slices' ticket
 }
+// d_ready / seq / d_flag: the device-bound form (eea_ck_records_sum_bound): wait for rec_ready[b] == seq per agent inside
+// the launch, publish *d_flag = seq behind the finished record; all null / 0: the plain form
 template <typename R>
-hipError_t launch_ck_records_sum(const R* d_rec, unsigned B, int K2, R* d_ws, unsigned* d_ctr, R* d_out, hipStream_t stream);
+hipError_t launch_ck_records_sum(const R* d_rec, unsigned B, int K2, R* d_ws, unsigned* d_ctr, R* d_out, hipStream_t stream,
+                                 const unsigned* d_ready = nullptr, unsigned seq = 0, unsigned* d_flag = nullptr);
+// d_pub [n] = d_src [n] written through, then *d_flag = seq (one small launch behind an all-reduce)
+template <typename R>
+hipError_t launch_publish_record(const R* d_src, int n, R* d_pub, unsigned* d_flag, unsigned seq, hipStream_t stream);
 
 // ---- phi_k path ----------------------------------------------------------------------
 // Gaussians of a target passed to the fill kernel by value: [mean x, mean y (Fourier frame), cov_inv xx, yy]
@@ -343,18 +350,6 @@ __device__ __forceinline__ R wrap_pi(R rad)
 // sum of that many sum records divided by the sum of their agent counts (element K^2 of a record).  A record set that
 // no agent contributed to (count 0: every agent of the producing pass was rejected, or the buffer is still zero) is no
 // consensus at all: the agent keeps its own c_k (`own`) -- the reference's behaviour -- instead of 0 / 0
-template <typename R, typename P>  // P: ControlParams<R>, possibly in the kernel-argument address space
-__device__ __forceinline__ R shared_ck_value(const P& p, int m, int K2, R own)
-{
-  if (p.ck_shared_parts <= 0) return p.ck_shared[m];
-  R s = R(0), n = R(0);
-  for (int i = 0; i < p.ck_shared_parts; ++i) {
-    s += p.ck_shared[static_cast<size_t>(i) * p.rec_len + m];
-    n += p.ck_shared[static_cast<size_t>(i) * p.rec_len + K2];
-  }
-  return n > R(0) ? s / n : own;
-}
-
 // agent-scope (sc1: write-through / L1-bypassing) accesses for data that crosses XCDs inside one launch
 template <typename R>
 __device__ __forceinline__ void store_agent(R* q, R v)
@@ -365,6 +360,35 @@ template <typename R>
 __device__ __forceinline__ R load_agent(const R* q)
 {
   return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <typename R, typename P>  // P: ControlParams<R>, possibly in the kernel-argument address space
+__device__ __forceinline__ R shared_ck_value(const P& p, int m, int K2, R own)
+{
+  // a buffer another kernel fills WHILE this one runs (device-bound exchange) is read past the L1
+  const bool bound = p.ck_flag != nullptr;
+  if (p.ck_shared_parts <= 0) return bound ? load_agent(p.ck_shared + m) : p.ck_shared[m];
+  R s = R(0), n = R(0);
+  for (int i = 0; i < p.ck_shared_parts; ++i) {
+    const R* const rec = p.ck_shared + static_cast<size_t>(i) * p.rec_len;
+    s += bound ? load_agent(rec + m) : rec[m];
+    n += bound ? load_agent(rec + K2) : rec[K2];
+  }
+  return n > R(0) ? s / n : own;
+}
+
+// Device-bound exchange, consumer side: wait (bounded) until *flag has reached seq.  One lane polls past the L1 with a
+// sleep between polls (MI355X_MICROARCH.md "polling-cost"); ~1 us per poll, 30 000 polls: tens of milliseconds, then the
+// caller reports EEA_ERR_TIMEOUT and goes on with the agent's own c_k.  Wavefront-uniform result.
+constexpr int kFlagPolls = 30000;
+__device__ __forceinline__ bool wait_flag(const unsigned* flag, unsigned seq)
+{
+  for (int i = 0; i < kFlagPolls; ++i) {
+    const unsigned v = __builtin_amdgcn_readfirstlane(load_agent(flag));
+    if (static_cast<int>(v - seq) >= 0) return true;
+    __builtin_amdgcn_s_sleep(32);
+  }
+  return false;
 }
 
 // std::clamp semantics (NaN passes through), ergodic_control.hpp:447-449

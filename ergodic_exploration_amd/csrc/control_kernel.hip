@@ -120,9 +120,17 @@ __device__ __forceinline__ bool last_arrival(unsigned* ticket, unsigned members)
   return true;
 }
 
+// Device-bound form (ready != nullptr; eea_ck_records_sum_bound): the launch does not wait for the control kernels that
+// write the records -- every unit polls the ready marks of ITS 32 agents (rec_ready[b] == seq, written behind the agent's
+// drained write-through record) and starts as soon as they are there, while the control kernels are still in their
+// backward halves; the wavefront that completes the last slice of the sum publishes flag = seq behind the drained sum
+// record, which is what the consuming control kernels wait for (ControlParams::ck_flag).  A unit whose agents never
+// report (tens of milliseconds) makes the record's agent count negative: consumers then keep their own c_k and report
+// EEA_ERR_TIMEOUT.
 template <typename R>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_num_vgpr(16))) void ck_records_sum_kernel(
-    const R* __restrict__ rec, unsigned B, int rec_len, R* ws, unsigned* ctr, R* __restrict__ out)
+    const R* __restrict__ rec, unsigned B, int rec_len, int K2, R* ws, unsigned* ctr, R* __restrict__ out,
+    const unsigned* ready, unsigned seq, unsigned* flag)
 {
   const unsigned ng0 = gridDim.x, ng1 = (ng0 + kSumFan - 1) / kSumFan;
   const unsigned g0 = blockIdx.x, e = blockIdx.y;
@@ -132,11 +140,36 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_num_vgpr(16))) void ck
   R* const ws0 = ws;                                        // [ng0][rec_len]
   R* const ws1 = ws + static_cast<size_t>(ng0) * rec_len;   // [ng1][rec_len]
   unsigned* const tickets = ctr + static_cast<size_t>(e) * (ng1 + 1);  // [ng1] level-1 tickets, then the level-2 ticket
+  unsigned* const slice_ticket = ctr + static_cast<size_t>(gridDim.y) * (ng1 + 1);  // the slices of the finished sum
 
   const unsigned first = g0 * kSumGroup, n0 = (B - first) < kSumGroup ? (B - first) : kSumGroup;
-  R acc = sum_rows<R, false>(rec + static_cast<size_t>(first) * rec_len, n0, rec_len, mm);
+  const bool bound = ready != nullptr;
+  bool timed_out = false;
+  if (bound) {
+    for (int i = 0;; ++i) {
+      const bool ok = threadIdx.x >= n0 || static_cast<int>(load_agent(ready + first + threadIdx.x) - seq) >= 0;
+      if (__all(ok)) break;
+      if (i >= kFlagPolls) {
+        timed_out = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(32);
+    }
+  }
+  R acc = bound ? sum_rows<R, true>(rec + static_cast<size_t>(first) * rec_len, n0, rec_len, mm)
+                : sum_rows<R, false>(rec + static_cast<size_t>(first) * rec_len, n0, rec_len, mm);
+  if (timed_out && m == K2) acc = R(-1.0e9);  // the agent count of the finished record goes negative
+  // the finished slice: out, and -- device-bound form -- the flag behind the last slice
+  auto finish = [&](R v) {
+    if (flag == nullptr) {
+      if (active) out[m] = v;
+      return;
+    }
+    if (active) store_agent(out + m, v);
+    if (last_arrival(slice_ticket, gridDim.y) && threadIdx.x == 0) store_agent(flag, seq);
+  };
   if (ng0 == 1) {
-    if (active) out[m] = acc;
+    finish(acc);
     return;
   }
   if (active) store_agent(ws0 + static_cast<size_t>(g0) * rec_len + m, acc);
@@ -145,34 +178,53 @@ __global__ __launch_bounds__(kWave) __attribute__((amdgpu_num_vgpr(16))) void ck
 
   acc = sum_rows<R, true>(ws0 + static_cast<size_t>(g1) * kSumFan * rec_len, n1, rec_len, mm);
   if (ng1 == 1) {
-    if (active) out[m] = acc;
+    finish(acc);
     return;
   }
   if (active) store_agent(ws1 + static_cast<size_t>(g1) * rec_len + m, acc);
   if (!last_arrival(tickets + ng1, ng1)) return;
 
   acc = sum_rows<R, true>(ws1, ng1, rec_len, mm);
-  if (active) out[m] = acc;
+  finish(acc);
+}
+
+// d_pub [n] = d_src [n] written through (sc1), then *flag = seq: makes a record another kernel produced with plain stores
+// (the all-reduce of the ranks' sum records) visible to control kernels that are already running and wait for the flag
+template <typename R>
+__global__ __launch_bounds__(kBlock) void publish_record_kernel(const R* __restrict__ src, int n, R* pub, unsigned* flag,
+                                                               unsigned seq)
+{
+  for (int i = threadIdx.x; i < n; i += kBlock) store_agent(pub + i, src[i]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) store_agent(flag, seq);
 }
 }  // namespace
 
 template <typename R>
-hipError_t launch_ck_records_sum(const R* d_rec, unsigned B, int K2, R* d_ws, unsigned* d_ctr, R* d_out, hipStream_t stream)
+hipError_t launch_ck_records_sum(const R* d_rec, unsigned B, int K2, R* d_ws, unsigned* d_ctr, R* d_out, hipStream_t stream,
+                                 const unsigned* d_ready, unsigned seq, unsigned* d_flag)
 {
   if (B == 0) return hipSuccess;
   const dim3 grid(ck_sum_groups(B), ck_sum_slices(K2));
-  if (const hipEvent_t stop = take_stop_event()) {
-    hipExtLaunchKernelGGL(ck_records_sum_kernel<R>, grid, dim3(kWave), 0, stream, nullptr, stop, 0, d_rec, B,
-                          ck_record_len(K2), d_ws, d_ctr, d_out);
-  } else {
-    hipLaunchKernelGGL(ck_records_sum_kernel<R>, grid, dim3(kWave), 0, stream, d_rec, B, ck_record_len(K2), d_ws, d_ctr,
-                       d_out);
-  }
+  hipLaunchKernelGGL(ck_records_sum_kernel<R>, grid, dim3(kWave), 0, stream, d_rec, B, ck_record_len(K2), K2, d_ws, d_ctr,
+                     d_out, d_ready, seq, d_flag);
   return hipGetLastError();
 }
 
-template hipError_t launch_ck_records_sum<double>(const double*, unsigned, int, double*, unsigned*, double*, hipStream_t);
-template hipError_t launch_ck_records_sum<float>(const float*, unsigned, int, float*, unsigned*, float*, hipStream_t);
+template <typename R>
+hipError_t launch_publish_record(const R* d_src, int n, R* d_pub, unsigned* d_flag, unsigned seq, hipStream_t stream)
+{
+  hipLaunchKernelGGL(publish_record_kernel<R>, dim3(1), dim3(kBlock), 0, stream, d_src, n, d_pub, d_flag, seq);
+  return hipGetLastError();
+}
+
+template hipError_t launch_publish_record<double>(const double*, int, double*, unsigned*, unsigned, hipStream_t);
+template hipError_t launch_publish_record<float>(const float*, int, float*, unsigned*, unsigned, hipStream_t);
+template hipError_t launch_ck_records_sum<double>(const double*, unsigned, int, double*, unsigned*, double*, hipStream_t,
+                                                  const unsigned*, unsigned, unsigned*);
+template hipError_t launch_ck_records_sum<float>(const float*, unsigned, int, float*, unsigned*, float*, hipStream_t,
+                                                 const unsigned*, unsigned, unsigned*);
 template size_t control_lds_bytes<double>(int, int, int, int);
 template size_t control_lds_bytes<float>(int, int, int, int);
 template hipError_t launch_control<double>(const ControlParams<double>&, unsigned, int, int, bool,

@@ -28,7 +28,6 @@
 //   * sin(pi t) / cos(pi t) evaluation (exact argument reduction) for headings and basis angles;
 //   * LDS regions with disjoint lifetimes are aliased: 32 KB per agent at K=10, T=200 (fp64),
 //     4 workgroups per CU.
-#include <hip/hip_ext.h>
 
 #include "common.hpp"
 
@@ -336,7 +335,12 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
           // the reference throws out of rk4_.solve; nothing else of this agent is touched
           if (tid == 0 && p.status != nullptr) p.status[b] = 2;  // EEA_ERR_INVALID_TWIST
           if (p.ck_rec != nullptr && !rollout_only) {  // an all-zero sum record: the agent does not count
-            for (int m = tid; m < p.rec_len; m += BLK) p.ck_rec[static_cast<size_t>(b) * p.rec_len + m] = R(0);
+            for (int m = tid; m < p.rec_len; m += BLK) store_agent(p.ck_rec + static_cast<size_t>(b) * p.rec_len + m, R(0));
+            if (p.rec_ready != nullptr) {  // device-bound exchange: the ready mark behind the drained record
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+              __syncthreads();
+              if (tid == 0) store_agent(p.rec_ready + b, p.rec_seq);
+            }
           }
           if (tid == 0 && p.done != nullptr && b == 0) {
             __hip_atomic_store(p.done, p.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -653,16 +657,34 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
       }
       R c = invN * s;
       if (p.ck != nullptr) p.ck[static_cast<size_t>(b) * K2 + m] = c;
-      if (p.ck_rec != nullptr) p.ck_rec[static_cast<size_t>(b) * p.rec_len + m] = c;  // eea_batch_io::d_ck_rec
+      if (p.ck_rec != nullptr) store_agent(p.ck_rec + static_cast<size_t>(b) * p.rec_len + m, c);  // eea_batch_io::d_ck_rec
+      s_D[m] = c;  // (same thread reads it back below)
+    }
+    if (p.ck_rec != nullptr) {  // [c_k, 1 (this agent counts), pad]
+      for (int m = K2 + tid; m < p.rec_len; m += BLK) {
+        store_agent(p.ck_rec + static_cast<size_t>(b) * p.rec_len + m, (m == K2) ? R(1) : R(0));
+      }
+      if (p.rec_ready != nullptr) {  // device-bound exchange: every thread's part has left, then the agent's ready mark
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) store_agent(p.rec_ready + b, p.rec_seq);
+      }
+    }
+    bool use_shared = p.ck_shared != nullptr;
+    if (use_shared && p.ck_flag != nullptr) {  // ... consumer side: wait for the shared c_k's flag (every wavefront)
+      bool ok = wait_flag(p.ck_flag, p.ck_flag_seq);
+      if (ok && p.ck_shared_parts > 0) ok = !(load_agent(p.ck_shared + K2) < R(0));
+      if (!ok && tid == 0 && p.status != nullptr) p.status[b] = 6;  // EEA_ERR_TIMEOUT
+      use_shared = ok;  // (the same outcome in every wavefront of the agent: the flag only grows; a give-up is final)
+    }
+    for (int m = tid; m < K2; m += BLK) {
+      R c = s_D[m];
       // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
-      if (p.ck_shared != nullptr) c = shared_ck_value(p, m, K2, c);
+      if (use_shared) c = shared_ck_value(p, m, K2, c);
       // fourier_diff = lamdak % (ck - phik)  (ergodic_control.hpp:422)
       const R lam = (m == tid) ? lam_m : p.lamdak[m];
       const R phi = (m == tid) ? phi_m : p.phik[m];
       s_D[m] = lam * (c - phi);
-    }
-    if (p.ck_rec != nullptr) {  // [c_k, 1 (this agent counts), pad]
-      for (int m = K2 + tid; m < p.rec_len; m += BLK) p.ck_rec[static_cast<size_t>(b) * p.rec_len + m] = (m == K2) ? R(1) : R(0);
     }
     __syncthreads();
     EEA_STAMP(7);
@@ -877,11 +899,7 @@ hipError_t launch_one(const ControlParams<R>& p, unsigned B, int Nmax, bool roll
                                              static_cast<int>(lds));
     if (e != hipSuccess) return e;
   }
-  if (const hipEvent_t stop = take_stop_event()) {
-    hipExtLaunchKernelGGL(kern, dim3(B), dim3(BLK), lds, stream, nullptr, stop, 0, p, Nmax, rollout_only ? 1 : 0);
-  } else {
-    hipLaunchKernelGGL(kern, dim3(B), dim3(BLK), lds, stream, p, Nmax, rollout_only ? 1 : 0);
-  }
+  hipLaunchKernelGGL(kern, dim3(B), dim3(BLK), lds, stream, p, Nmax, rollout_only ? 1 : 0);
   return hipGetLastError();
 }
 

@@ -342,7 +342,11 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
 #pragma unroll
       for (int r = 0; r < kRecRounds; ++r) {
         const int e = kWave * r + lane;
-        if (e < p.rec_len) p.ck_rec[static_cast<size_t>(b) * p.rec_len + e] = R(0);
+        if (e < p.rec_len) store_agent(p.ck_rec + static_cast<size_t>(b) * p.rec_len + e, R(0));
+      }
+      if (p.rec_ready != nullptr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) store_agent(p.rec_ready + b, p.rec_seq);
       }
     }
     if (lane == 0 && p.status != nullptr) p.status[b] = 2;  // EEA_ERR_INVALID_TWIST
@@ -900,12 +904,35 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
     }
     lds_fence();
     R* const rec = p.ck_rec + static_cast<size_t>(b) * p.rec_len;
+    if (p.rec_ready != nullptr) {
+      // device-bound exchange: the record leaves write-through, and once it has left the agent's ready mark follows
+      // (MI355X_MICROARCH.md: sc1 payload -> s_waitcnt vmcnt(0) -> sc1 flag); the record sum polls the marks
 #pragma unroll
-    for (int r = 0; r < kRecRounds; ++r) {
-      const int e = kWave * r + lane;
-      if (e < p.rec_len) rec[e] = s_D[e];
+      for (int r = 0; r < kRecRounds; ++r) {
+        const int e = kWave * r + lane;
+        if (e < p.rec_len) store_agent(rec + e, s_D[e]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) store_agent(p.rec_ready + b, p.rec_seq);
+    } else {
+#pragma unroll
+      for (int r = 0; r < kRecRounds; ++r) {
+        const int e = kWave * r + lane;
+        if (e < p.rec_len) rec[e] = s_D[e];
+      }
     }
     lds_fence();
+  };
+  // device-bound exchange, consumer side: the shared c_k this step consumes may still be on its way -- wait for its flag
+  // here, as late as possible (the first use of c_bar is D).  On a timeout the agent goes on with its own c_k and says so
+  auto bind_shared_ck = [&]() -> bool {  // true: the shared c_k replaces the own one
+    if (p.ck_shared == nullptr) return false;
+    if (p.ck_flag == nullptr) return true;  // wavefront-uniform
+    bool ok = wait_flag(p.ck_flag, p.ck_flag_seq);
+    // a producer that gave up marks its record with a negative agent count
+    if (ok && p.ck_shared_parts > 0) ok = !(load_agent(p.ck_shared + K2) < R(0));
+    if (!ok && lane == 0 && p.status != nullptr) p.status[b] = 6;  // EEA_ERR_TIMEOUT
+    return ok;
   };
   // D = lambda (c - phi), fourier_diff of ergodic_control.hpp:422, in both orientations
   if constexpr (kBlock4) {
@@ -950,10 +977,11 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
       }
       publish_record();
     }
+    const bool use_shared = bind_shared_ck();
 #pragma unroll
     for (int t = 0; t < TS; ++t) {
       // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
-      if (p.ck_shared != nullptr) cv[t] = shared_ck_value(p, idx[t], K2, cv[t]);
+      if (use_shared) cv[t] = shared_ck_value(p, idx[t], K2, cv[t]);
       if (okv[t]) s_D[idx[t]] = lamv[t] * (cv[t] - phiv[t]);
     }
     lds_fence();
@@ -975,6 +1003,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
       }
     }
     if (p.ck_rec != nullptr) publish_record();  // wavefront-uniform
+    const bool use_shared = bind_shared_ck();
 #pragma unroll
     for (int t = 0; t < NT * NT; ++t) {
 #pragma unroll
@@ -984,7 +1013,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
         if (k1 < K && k2 < K) {
           R c = invN * (*accs[t])[r];
           // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
-          if (p.ck_shared != nullptr) c = shared_ck_value(p, k2 * K + k1, K2, c);
+          if (use_shared) c = shared_ck_value(p, k2 * K + k1, K2, c);
           s_D[k2 * K + k1] = lam[t][r] * (c - phi[t][r]);
         }
       }

@@ -1,6 +1,4 @@
 // Instantiations and dispatch of the wavefront-per-agent control kernel (control_wave_impl.hpp).
-#include <hip/hip_ext.h>
-
 #include "control_wave_impl.hpp"
 // the same kernel text once more: the lean instance (<= 120 registers: the request is in register pairs on gfx90a+)
 #undef EEA_WAVE_KERNEL_NAME
@@ -41,13 +39,7 @@ hipError_t launch_wave_one(const ControlParams<R>& p, unsigned B, bool rollout_o
                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
     if (e != hipSuccess) return e;
   }
-  if (const hipEvent_t stop = take_stop_event()) {
-    hipExtLaunchKernelGGL(kern, dim3((B + WPB - 1) / WPB), dim3(WPB * kWave), lds, stream, nullptr, stop, 0, p, B, S,
-                          rollout_only ? 1 : 0);
-  } else {
-    hipLaunchKernelGGL(kern, dim3((B + WPB - 1) / WPB), dim3(WPB * kWave), lds, stream, p, B, S,
-                       rollout_only ? 1 : 0);
-  }
+  hipLaunchKernelGGL(kern, dim3((B + WPB - 1) / WPB), dim3(WPB * kWave), lds, stream, p, B, S, rollout_only ? 1 : 0);
   return hipGetLastError();
 }
 

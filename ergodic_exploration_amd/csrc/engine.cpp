@@ -10,6 +10,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -27,17 +29,6 @@ std::atomic<int> g_options[EEA_OPT_COUNT] = { { 0 }, { 0 }, { 0 }, { 1 } };
 namespace eea
 {
 int option(int id) { return (id >= 0 && id < EEA_OPT_COUNT) ? g_options[id].load(std::memory_order_relaxed) : 0; }
-namespace
-{
-thread_local hipEvent_t tl_stop_event = nullptr;
-}
-void set_stop_event(hipEvent_t ev) { tl_stop_event = ev; }
-hipEvent_t take_stop_event()
-{
-  const hipEvent_t ev = tl_stop_event;
-  tl_stop_event = nullptr;
-  return ev;
-}
 }  // namespace eea
 
 namespace
@@ -121,9 +112,12 @@ struct eea_engine
   struct SumWs
   {
     const void* key = nullptr;
+    unsigned long last_use = 0;
     DevBuf ws, ctr;
   };
-  std::vector<SumWs> sum_ws;
+  std::vector<std::unique_ptr<SumWs>> sum_ws;  // (pointers: a workspace in use must not move when the list grows)
+  std::mutex sum_mutex;
+  unsigned long sum_clock = 0;
 
   // single-agent path
   hipStream_t stream1 = nullptr;
@@ -438,26 +432,44 @@ void fill_params(const eea_engine* e, eea::ControlParams<R>& p)
   p.n_steps = 1;
 }
 
-// workspace of the sum written to `key` for up to B records (allocated on first use: one synchronisation, then none)
+// workspace of the sum written to `key` for up to B records.  One per distinct output buffer (concurrent sums on
+// several streams must not share tickets), found under the engine's lock (the header allows concurrent calls with
+// distinct d_sum buffers); at most kMaxSumWs of them -- a caller that passes a fresh output buffer every call recycles
+// the least recently used workspace instead of growing the list.  (Re)allocation synchronises the device once; the
+// tickets are zeroed on the launch stream.
+constexpr size_t kMaxSumWs = 32;
 template <typename R>
-eea_status sum_workspace(eea_engine* e, const void* key, unsigned B, eea_engine::SumWs** out)
+eea_status sum_workspace(eea_engine* e, const void* key, unsigned B, hipStream_t s, eea_engine::SumWs** out)
 {
+  std::lock_guard<std::mutex> lock(e->sum_mutex);
   eea_engine::SumWs* w = nullptr;
   for (auto& cand : e->sum_ws) {
-    if (cand.key == key) w = &cand;
+    if (cand->key == key) w = cand.get();
   }
+  bool recycled = false;
   if (w == nullptr) {
-    e->sum_ws.emplace_back();
-    w = &e->sum_ws.back();
+    if (e->sum_ws.size() < kMaxSumWs) {
+      e->sum_ws.emplace_back(new eea_engine::SumWs());
+      w = e->sum_ws.back().get();
+    } else {  // least recently used
+      w = e->sum_ws.front().get();
+      for (auto& cand : e->sum_ws) {
+        if (cand->last_use < w->last_use) w = cand.get();
+      }
+      recycled = true;
+    }
     w->key = key;
   }
+  w->last_use = ++e->sum_clock;
   const size_t need_ws = sizeof(R) * eea::ck_sum_ws_elems(B, e->K2);
   const size_t need_ctr = sizeof(unsigned) * eea::ck_sum_tickets(B, e->K2);
   if (need_ws > w->ws.cap || need_ctr > w->ctr.cap) {
     EEA_HIP(hipDeviceSynchronize());  // an earlier launch may still use the buffers about to be replaced
     EEA_HIP(w->ws.reserve(need_ws));
     EEA_HIP(w->ctr.reserve(need_ctr));
-    EEA_HIP(hipMemset(w->ctr.p, 0, w->ctr.cap));  // the tickets reset themselves from here on
+    EEA_HIP(hipMemsetAsync(w->ctr.p, 0, w->ctr.cap, s));  // the tickets reset themselves from here on
+  } else if (recycled) {
+    // (the tickets of a finished sum are back at zero; a recycled workspace may belong to a sum still in flight)
     EEA_HIP(hipDeviceSynchronize());
   }
   *out = w;
@@ -485,6 +497,10 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
   p.ck_shared = static_cast<const R*>(io->d_ck_shared);
   p.ck_shared_parts = io->d_ck_shared != nullptr ? static_cast<int>(io->ck_shared_parts) : 0;
   p.rec_len = eea::ck_record_len(e->K2);
+  p.rec_ready = rollout_only ? nullptr : io->d_rec_ready;
+  p.rec_seq = io->rec_seq;
+  p.ck_flag = io->d_ck_shared != nullptr ? io->d_ck_flag : nullptr;
+  p.ck_flag_seq = io->ck_flag_seq;
   p.edx = static_cast<R*>(io->d_edx);
   p.bdx = static_cast<R*>(io->d_bdx);
   p.rhot = static_cast<R*>(io->d_rhot);
@@ -666,8 +682,8 @@ void eea_destroy(eea_engine* e)
                      &e->d_lut, &e->d_raw, &e->d_occ };
   for (DevBuf* b : bufs) b->release();
   for (auto& w : e->sum_ws) {
-    w.ws.release();
-    w.ctr.release();
+    w->ws.release();
+    w->ctr.release();
   }
   if (e->ev_done) (void)hipEventDestroy(e->ev_done);
   if (e->ev_rebuild) (void)hipEventDestroy(e->ev_rebuild);
@@ -980,23 +996,51 @@ eea_status eea_control_batch_steps(eea_engine* e, unsigned B, const eea_batch_io
                 : control_batch_impl<double>(e, B, io, false, s, nullptr, n_steps, pose_step_stride, u0_step_stride);
 }
 
-eea_status eea_ck_records_sum(eea_engine* e, unsigned B, const void* d_ck_rec, void* d_sum, void* stream)
+static eea_status records_sum_impl(eea_engine* e, unsigned B, const void* d_ck_rec, void* d_sum, void* stream,
+                                   const unsigned* d_ready, unsigned seq, unsigned* d_flag)
 {
   if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
   if (d_ck_rec == nullptr || d_sum == nullptr || B == 0) return fail(EEA_ERR_INVALID_ARGUMENT, "d_ck_rec, d_sum and B > 0 are required");
   eea_status st = use_device(e);
   if (st != EEA_OK) return st;
-  eea_engine::SumWs* w = nullptr;
-  st = e->f32 ? sum_workspace<float>(e, d_sum, B, &w) : sum_workspace<double>(e, d_sum, B, &w);
-  if (st != EEA_OK) return st;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  eea_engine::SumWs* w = nullptr;
+  st = e->f32 ? sum_workspace<float>(e, d_sum, B, s, &w) : sum_workspace<double>(e, d_sum, B, s, &w);
+  if (st != EEA_OK) return st;
   if (e->f32) {
     EEA_HIP(eea::launch_ck_records_sum<float>(static_cast<const float*>(d_ck_rec), B, e->K2, static_cast<float*>(w->ws.p),
-                                              static_cast<unsigned*>(w->ctr.p), static_cast<float*>(d_sum), s));
+                                              static_cast<unsigned*>(w->ctr.p), static_cast<float*>(d_sum), s, d_ready, seq,
+                                              d_flag));
   } else {
     EEA_HIP(eea::launch_ck_records_sum<double>(static_cast<const double*>(d_ck_rec), B, e->K2, static_cast<double*>(w->ws.p),
-                                               static_cast<unsigned*>(w->ctr.p), static_cast<double*>(d_sum), s));
+                                               static_cast<unsigned*>(w->ctr.p), static_cast<double*>(d_sum), s, d_ready, seq,
+                                               d_flag));
   }
+  return EEA_OK;
+}
+
+eea_status eea_ck_records_sum(eea_engine* e, unsigned B, const void* d_ck_rec, void* d_sum, void* stream)
+{
+  return records_sum_impl(e, B, d_ck_rec, d_sum, stream, nullptr, 0u, nullptr);
+}
+
+eea_status eea_ck_records_sum_bound(eea_engine* e, unsigned B, const void* d_ck_rec, const unsigned* d_rec_ready, unsigned seq,
+                                    void* d_sum, unsigned* d_flag, void* stream)
+{
+  if (d_rec_ready == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "d_rec_ready is required (eea_batch_io::d_rec_ready of the producing calls)");
+  return records_sum_impl(e, B, d_ck_rec, d_sum, stream, d_rec_ready, seq, d_flag);
+}
+
+eea_status eea_publish_record(eea_engine* e, const void* d_src, void* d_pub, unsigned* d_flag, unsigned seq, void* stream)
+{
+  if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (d_src == nullptr || d_pub == nullptr || d_flag == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  eea_status st = use_device(e);
+  if (st != EEA_OK) return st;
+  const int n = eea::ck_record_len(e->K2);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (e->f32) EEA_HIP(eea::launch_publish_record<float>(static_cast<const float*>(d_src), n, static_cast<float*>(d_pub), d_flag, seq, s));
+  else EEA_HIP(eea::launch_publish_record<double>(static_cast<const double*>(d_src), n, static_cast<double*>(d_pub), d_flag, seq, s));
   return EEA_OK;
 }
 

@@ -45,7 +45,9 @@ typedef enum {
   EEA_ERR_INVALID_TWIST = 2,    /* reference: SimpleCart::operator() throws, cart.hpp:167-170 */
   EEA_ERR_UNSUPPORTED = 3,      /* size outside what the kernels are built for */
   EEA_ERR_HIP = 4,              /* HIP runtime failure (no device, OOM, launch error) */
-  EEA_ERR_NO_TARGET = 5         /* control requested before any target was set */
+  EEA_ERR_NO_TARGET = 5,        /* control requested before any target was set */
+  EEA_ERR_TIMEOUT = 6           /* per-agent status of the device-bound exchange: the shared c_k an agent waited for
+                                   inside the kernel did not arrive (eea_batch_io::d_ck_flag); it used its own c_k */
 } eea_status;
 
 typedef struct eea_engine eea_engine;
@@ -200,6 +202,21 @@ typedef struct {
                                         group -- all-reduced over the ranks or not): the kernel uses
                                         c_bar[m] = sum_i rec_i[m] / sum_i rec_i[K^2]: no divide
                                         launch, and the exchange is one all-reduce of n records */
+  /* ABI 4 -- device-bound exchange: producers and consumers of the shared c_k meet on the DEVICE, no host wait and no
+   * stream wait anywhere (eea_comm_records_exchange_bound).  All optional (NULL / 0 = the forms above). */
+  unsigned* d_rec_ready;  /* [B] out (with d_ck_rec): rec_ready[b] = rec_seq once agent b's record is visible
+                                        device-wide -- written behind the drained, write-through record, about half
+                                        way through the agent's wavefront; eea_ck_records_sum_bound polls these marks
+                                        instead of waiting for the kernel to finish                              */
+  unsigned rec_seq;       /* sequence number of this pass (any value that grows from pass to pass, mod 2^32)     */
+  const unsigned* d_ck_flag;/* in (with d_ck_shared): the kernel waits until *d_ck_flag has reached ck_flag_seq
+                                        ((int)(*d_ck_flag - ck_flag_seq) >= 0) right before the first use of the shared
+                                        c_k, and reads d_ck_shared past its L1: "late binding" -- the call can be
+                                        launched before the exchange that fills d_ck_shared has run.  Bounded (tens
+                                        of milliseconds): then d_status[b] = EEA_ERR_TIMEOUT and the agent uses its own
+                                        c_k.  The waiting wavefronts hold their execution slots: see
+                                        eea_comm_records_exchange_bound for what must fit beside them             */
+  unsigned ck_flag_seq;
 } eea_batch_io;
 
 /* length in reals of one sum record (eea_batch_io::d_ck_rec): K^2 + 1 rounded up to an even number */
@@ -211,6 +228,18 @@ unsigned eea_ck_record_len(const eea_engine* e);
  * compute streams: the wavefronts use no LDS and <= 32 registers and are resident BESIDE a full fp64 K <= 10 control
  * kernel).  Concurrent calls on one engine must use distinct d_sum buffers. */
 eea_status eea_ck_records_sum(eea_engine* e, unsigned B, const void* d_ck_rec, void* d_sum, void* stream);
+/* ABI 4, device-bound form: the same sum, but the launch does not have to be ordered behind the control kernels that
+ * write the records -- every unit of the sum polls the ready marks of its 32 agents (d_rec_ready[b] == seq,
+ * eea_batch_io::d_rec_ready / rec_seq of the producing calls) and starts when they are there.  d_flag != NULL: *d_flag = seq
+ * is published (write-through, behind the drained sum record) by the wavefront that completes the sum -- what
+ * eea_batch_io::d_ck_flag of the consuming calls waits for.  Agents that never report within tens of milliseconds make the
+ * record's agent count negative (consumers then keep their own c_k and report EEA_ERR_TIMEOUT).  Same summation tree, same
+ * bits as eea_ck_records_sum. */
+eea_status eea_ck_records_sum_bound(eea_engine* e, unsigned B, const void* d_ck_rec, const unsigned* d_rec_ready, unsigned seq,
+                                    void* d_sum, unsigned* d_flag, void* stream);
+/* d_pub [eea_ck_record_len] = d_src written through, then *d_flag = seq: publishes a record that another kernel produced with
+ * ordinary stores (e.g. an all-reduce over the ranks) to control kernels that are already running and wait for the flag. */
+eea_status eea_publish_record(eea_engine* e, const void* d_src, void* d_pub, unsigned* d_flag, unsigned seq, void* stream);
 
 /* One receding-horizon optimisation per agent (ergodic_control.hpp:224-311, without the
  * configTarget call: use eea_config_domain first).  Asynchronous on `stream`. */
@@ -274,33 +303,31 @@ eea_status eea_comm_consensus_ck_async(eea_engine* e, eea_comm* c, unsigned B_lo
 eea_status eea_comm_allgather_ck_async(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_local,
                                        void* d_ck_all, void* compute_stream, int slot);
 eea_status eea_comm_wait(eea_comm* c, int slot, void* stream);
-/* The whole exchange of one pass of an agent batch stepped as n_streams agent groups, in one call: on the
- * communicator's own (highest-priority) stream, ordered after everything enqueued so far on EACH of the group streams:
- * eea_ck_records_sum over the B_local per-agent records d_ck_rec (eea_batch_io::d_ck_rec of the groups' control calls),
- * then the all-reduce of the sum record over the ranks (none with one rank).  d_sum [eea_ck_record_len] then feeds
- * eea_batch_io::d_ck_shared with ck_shared_parts = 1 on every rank; the consuming streams call eea_comm_wait(c, slot, ..). */
+/* The whole exchange of one pass of an agent batch stepped as n_streams agent groups, in one call, STREAM-ORDERED: the
+ * communicator's own (highest-priority) stream waits for everything enqueued so far on EACH of the group streams (one event
+ * per group), then eea_ck_records_sum over the B_local per-agent records d_ck_rec (eea_batch_io::d_ck_rec of the groups'
+ * control calls), then the all-reduce of the sum record over the ranks (none with one rank).  d_sum [eea_ck_record_len] then
+ * feeds eea_batch_io::d_ck_shared with ck_shared_parts = 1 on every rank; the consuming streams call eea_comm_wait(c, slot, ..).
+ * The form for hosts that exchange at their control rate (the reference's nodes: 10 Hz). */
 eea_status eea_comm_records_exchange_async(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_rec,
                                            void* d_sum, void* const* group_streams, unsigned n_streams, int slot);
-/* The control calls of one pass of such a batch in one call (a pass of 4096 agents takes ~25 us on the device: the host
- * must issue it in less): eea_control_batch(e, B[g], &ios[g], group_streams[g]) for every agent group g, all of them
- * behind the exchange of slot wait_slot (skipped when wait_slot < 0).  The HOST waits for that exchange -- it polls its
- * completion event (for tens of milliseconds at most) and only then launches; a stream wait is the fall-back for an
- * exchange that is stuck -- so that the group streams carry no wait at all: with a lag of >= 2 passes between
- * producing and consuming an exchange the device still has the passes in between queued.  exchange_slot >= 0: the slot
- * of the eea_comm_records_exchange_async call that follows for this pass; the groups' kernels then carry the completion
- * events that exchange waits for (no separate event records). */
-eea_status eea_comm_control_groups(eea_engine* e, eea_comm* c, unsigned n_groups, const unsigned* B,
-                                   const eea_batch_io* ios, void* const* group_streams, int wait_slot, int exchange_slot);
-/* on != 0: the HIP calls of eea_comm_records_exchange_async are issued by a host thread the communicator owns (the call
- * itself only queues a request), so that the caller's thread spends its time on the control launches; eea_comm_wait and
- * eea_comm_control_groups make sure the thread has issued the exchange they refer to.  The thread also paces the exchange
- * itself: it polls the completion of the groups' kernels (their events came through eea_comm_control_groups) and launches
- * the record sum once they are there, so the exchange stream carries no wait either (a stream wait is the fall-back for a
- * group that is milliseconds late).  It spins while exchanges keep coming and yields when idle; on == 0 (default) stops it. */
-eea_status eea_comm_host_thread(eea_comm* c, int on);
-/* returns once every exchange queued so far has been ISSUED to the device (a no-op without the host thread): call it
- * before a host-side synchronisation (hipStreamSynchronize / hipDeviceSynchronize) that is meant to cover them */
-eea_status eea_comm_flush(eea_comm* c);
+/* ABI 4 -- the same exchange DEVICE-BOUND, for a consensus on EVERY pass at the device's own rate (a pass of 4096 agents
+ * takes ~23 us: no host wait and no stream wait fits into it).  Nothing is ordered by the host: on the communicator's
+ * stream, eea_ck_records_sum_bound (polls the agents' ready marks d_rec_ready == seq: it runs while the producing control
+ * kernels are still in their backward halves), with an RCCL communicator the all-reduce of the sum record over the ranks +
+ * eea_publish_record, and *d_flag = seq behind the finished d_sum.  The consuming control calls are launched WITHOUT
+ * waiting, with eea_batch_io::d_ck_shared = d_sum, ck_shared_parts = 1, d_ck_flag = d_flag, ck_flag_seq = seq: they wait
+ * inside the kernel, right before the first use of the shared c_k.  A consensus of lag n passes = pass i consumes seq i - n;
+ * lag 1 is the previous step's c_bar (decentralised ergodic control, reference README ref. [2]).
+ * The caller rotates d_ck_rec / d_sum over >= lag + 2 buffers (slot = buffer index, < EEA_COMM_SLOTS); d_rec_ready [B_local]
+ * and d_flag [1] may be shared by all of them (sequence numbers only grow; zero them once).  Every launch that waits for a
+ * flag must leave room for what it waits for: the producers of that flag (control kernels of other agent groups, the
+ * record sum's single-wavefront workgroups, the all-reduce) have to become resident BESIDE the waiting wavefronts -- two
+ * agent groups per GPU of at most half its execution slots each do (the fp64 K <= 10 instance leaves registers for the
+ * sum beside a full set of control wavefronts); a waiter that cannot be served gives up after tens of milliseconds
+ * (EEA_ERR_TIMEOUT in d_status, own c_k), it never hangs.  Host threads: none; the calling thread issues 1-3 launches. */
+eea_status eea_comm_records_exchange_bound(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_rec,
+                                           const unsigned* d_rec_ready, unsigned seq, void* d_sum, unsigned* d_flag, int slot);
 /* in-place ncclAllReduce(sum) of n reals: the K^2 partial sums of a grid-tiled phi_k
  * (eea_spatial_coeff_rows / eea_spatial_coeff_occupancy_rows) */
 eea_status eea_comm_allreduce_sum(eea_engine* e, eea_comm* c, void* d_buf, unsigned n, void* stream);

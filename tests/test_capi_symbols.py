@@ -32,8 +32,30 @@ def test_library_exports_only_the_documented_abi():
 def test_struct_layouts_match_header():
     # sizes the C compiler gives the ABI structs (kept in sync with ergodic_amd.h by hand)
     assert C.sizeof(capi.Config) == 3 * 4 + 4 + 4 * 8 + 8 + 15 * 8  # ints, pad, doubles, K+pad, arrays
-    assert C.sizeof(capi.BatchIO) == 15 * 8  # 13 pointers / padded uint, d_ck_rec, ck_shared_parts (+ pad)
+    assert C.sizeof(capi.BatchIO) == 15 * 8 + 4 * 8  # ABI 3 (15 slots) + d_rec_ready, rec_seq, d_ck_flag, ck_flag_seq (ABI 4)
     assert C.sizeof(capi.CollisionCfg) == 3 * 8 + 2 * 4 + 4 * 8
+
+
+def test_struct_layouts_against_the_c_compiler(tmp_path):
+    """sizeof / offsetof of every ABI struct as gcc lays them out from include/ergodic_amd.h, against the ctypes mirrors"""
+    import subprocess
+    structs = {"eea_config": capi.Config, "eea_batch_io": capi.BatchIO, "eea_collision_cfg": capi.CollisionCfg,
+               "eea_dwa_cfg": capi.DwaCfg}
+    lines = []
+    for cname, cls in structs.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for fname, _ in cls._fields_:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, fname, cname, fname))
+    src = tmp_path / "layout.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "ergodic_amd.h"\nint main(void) {\n%s\nreturn 0; }\n'
+                   % "\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.dirname(capi.HEADER_PATH), str(src), "-o", str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == C.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got["%s.%s" % (cname, fname)]) == getattr(cls, fname).offset, (cname, fname)
 
 
 def test_no_cpu_fallback_without_device():

@@ -282,39 +282,40 @@ def test_shared_ck_as_sum_records(K, horizon):
     eng.close()
 
 
-@pytest.mark.parametrize("lag,host_thread", [(1, False), (3, False), (1, True), (3, True)])
-def test_consensus_pass_through_the_exchange_calls(lag, host_thread):
-    """The consensus loop as bench.py and a C++ host issue it -- eea_comm_control_groups (two agent groups on two streams,
-    each launch behind the exchange it consumes) + eea_comm_records_exchange_async (record sum + all-reduce on the
-    communicator's own stream, completion slots) -- against the same passes issued one call at a time on one stream
-    with explicit synchronisation: bitwise the same controls and sum records after 7 passes."""
+def _consensus_reference(eng, B, gb, d_pose, ut0, lag, passes, L):
+    """the consensus passes issued one call at a time on one stream with explicit synchronisation: pass i consumes the
+    sum record of pass i - lag (ck_shared_parts = 1), two agent groups"""
+    ut, u0 = dev(ut0), torch.empty((B, 3), dtype=torch.float64, device="cuda")
+    arec = torch.zeros((B, L), dtype=torch.float64, device="cuda")
+    sums = [torch.zeros((L,), dtype=torch.float64, device="cuda") for _ in range(passes)]
+    for i in range(passes):
+        src = i - lag
+        for g in range(len(gb) - 1):
+            sl = slice(gb[g], gb[g + 1])
+            eng.control_batch(gb[g + 1] - gb[g], d_pose[sl], ut[sl], u0[sl], ck_rec=arec[sl],
+                              ck_shared=sums[src] if src >= 0 else None, ck_shared_parts=1 if src >= 0 else 0)
+        torch.cuda.synchronize()
+        eng.ck_records_sum(B, arec, sums[i])
+        torch.cuda.synchronize()
+    return ut, u0, sums
+
+
+@pytest.mark.parametrize("lag", [1, 3])
+@pytest.mark.parametrize("rccl", [False, True])
+def test_consensus_pass_stream_ordered_exchange(lag, rccl):
+    """eea_comm_records_exchange_async (events on the group streams, record sum + all-reduce on the communicator's
+    stream) + eea_comm_wait on the consuming streams, no host synchronisation in between -- bitwise the synchronised
+    sequence after 7 passes; over the local communicator and over a REAL one-rank RCCL communicator (the collective
+    branch of the exchange: ncclAllReduce of the 816-byte record)."""
     rng = np.random.default_rng(17)
     B, K, G, NB, passes = 300, 10, 2, 6, 7
     eng, _ = make_pair("omni", K, 20.0, n_oracles=0)
     T, K2, L = eng.T, eng.K2, eng.ck_record_len
-    poses = random_poses(rng, B)
+    d_pose = dev(random_poses(rng, B))
     ut0 = rng.uniform(-0.3, 0.3, (B, T, 3))
-    d_pose = dev(poses)
     gb = [0, 130, B]
-
-    # (a) reference sequence: one stream, synchronised after every call
-    ut_a, u0_a = dev(ut0), torch.empty((B, 3), dtype=torch.float64, device="cuda")
-    arec = torch.zeros((B, L), dtype=torch.float64, device="cuda")
-    sums_a = [torch.zeros((L,), dtype=torch.float64, device="cuda") for _ in range(passes)]
-    for i in range(passes):
-        src = i - lag
-        for g in range(G):
-            sl = slice(gb[g], gb[g + 1])
-            eng.control_batch(gb[g + 1] - gb[g], d_pose[sl], ut_a[sl], u0_a[sl], ck_rec=arec[sl],
-                              ck_shared=sums_a[src] if src >= 0 else None, ck_shared_parts=1 if src >= 0 else 0)
-        torch.cuda.synchronize()
-        eng.ck_records_sum(B, arec, sums_a[i])
-        torch.cuda.synchronize()
-
-    # (b) the exchange calls: nothing but the two C-ABI calls per pass, no host synchronisation in between
-    comm = capi.Comm(0, 1, 0, None)
-    if host_thread:
-        comm.host_thread(True)   # the exchange's HIP calls issued by the communicator's own thread
+    ut_a, u0_a, sums_a = _consensus_reference(eng, B, gb, d_pose, ut0, lag, passes, L)
+    comm = capi.Comm(0, 1, 0, capi.comm_unique_id() if rccl else None)
     streams = [torch.cuda.Stream() for _ in range(G)]
     ut_b, u0_b = dev(ut0), torch.empty((B, 3), dtype=torch.float64, device="cuda")
     arecs = [torch.zeros((B, L), dtype=torch.float64, device="cuda") for _ in range(NB)]
@@ -322,20 +323,106 @@ def test_consensus_pass_through_the_exchange_calls(lag, host_thread):
     torch.cuda.synchronize()
     for i in range(passes):
         slot, src = i % NB, (i - lag) % NB if i >= lag else None
-        groups = [dict(B=gb[g + 1] - gb[g], pose=d_pose[gb[g]:gb[g + 1]], ut=ut_b[gb[g]:gb[g + 1]], u0=u0_b[gb[g]:gb[g + 1]],
-                       stream=streams[g].cuda_stream, ck_rec=arecs[slot][gb[g]:gb[g + 1]],
-                       ck_shared=None if src is None else sums_b[src], ck_shared_parts=0 if src is None else 1)
-                  for g in range(G)]
-        comm.prepared_control_groups(eng, groups, -1 if src is None else src, slot)()
+        for g in range(G):
+            sl = slice(gb[g], gb[g + 1])
+            if src is not None:
+                comm.wait(src, streams[g].cuda_stream)
+            eng.control_batch(gb[g + 1] - gb[g], d_pose[sl], ut_b[sl], u0_b[sl], ck_rec=arecs[slot][sl],
+                              ck_shared=None if src is None else sums_b[src], ck_shared_parts=0 if src is None else 1,
+                              stream=streams[g].cuda_stream)
         comm.records_exchange_async(eng, B, arecs[slot], sums_b[slot], [st.cuda_stream for st in streams], slot)
-    comm.flush()               # (host thread: the last exchanges may still be queued on the host side)
     torch.cuda.synchronize()
     assert torch.equal(ut_a, ut_b) and torch.equal(u0_a, u0_b)
-    last = passes - 1
-    assert torch.equal(sums_a[last], sums_b[last % NB])
-    assert float(sums_a[last][K2]) == B
+    assert torch.equal(sums_a[passes - 1], sums_b[(passes - 1) % NB])
+    assert float(sums_a[passes - 1][K2]) == B
     comm.close()
     eng.close()
+
+
+@pytest.mark.parametrize("lag", [1, 2, 4])
+@pytest.mark.parametrize("rccl", [False, True])
+@pytest.mark.parametrize("K,horizon", [(10, 20.0), (30, 6.0)])
+def test_consensus_pass_device_bound_exchange(lag, rccl, K, horizon):
+    """The DEVICE-BOUND exchange (ABI 4), as bench.py's consensus leg issues it: per pass the two groups' control calls
+    (eea_batch_io::d_rec_ready / rec_seq out, d_ck_flag / ck_flag_seq in) and ONE eea_comm_records_exchange_bound -- no
+    host wait, no stream wait, no event anywhere: the record sum polls the agents' ready marks, the consuming kernels poll
+    the exchange's flag right before the first use of c_bar.  Bitwise the synchronised sequence after 9 passes, lag 1
+    (the previous pass's c_bar), 2 and 4; local communicator and a real one-rank RCCL communicator (sum -> ncclAllReduce
+    -> publish); the wavefront kernel (lean instance) and the workgroup kernel (K = 30).  No agent may report a timeout."""
+    rng = np.random.default_rng(23)
+    B, G, NB, passes = 300, 2, 6, 9
+    eng, _ = make_pair("omni", K, horizon, n_oracles=0)
+    T, K2, L = eng.T, eng.K2, eng.ck_record_len
+    d_pose = dev(random_poses(rng, B))
+    ut0 = rng.uniform(-0.3, 0.3, (B, T, 3))
+    gb = [0, 130, B]
+    ut_a, u0_a, sums_a = _consensus_reference(eng, B, gb, d_pose, ut0, lag, passes, L)
+    comm = capi.Comm(0, 1, 0, capi.comm_unique_id() if rccl else None)
+    streams = [torch.cuda.Stream() for _ in range(G)]
+    ut_b, u0_b = dev(ut0), torch.empty((B, 3), dtype=torch.float64, device="cuda")
+    arecs = [torch.zeros((B, L), dtype=torch.float64, device="cuda") for _ in range(NB)]
+    sums_b = [torch.zeros((L,), dtype=torch.float64, device="cuda") for _ in range(NB)]
+    ready = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    flag = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    status = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for i in range(passes):
+        seq = i + 1
+        slot, src = i % NB, (i - lag) % NB if i >= lag else None
+        for g in range(G):
+            sl = slice(gb[g], gb[g + 1])
+            eng.control_batch(gb[g + 1] - gb[g], d_pose[sl], ut_b[sl], u0_b[sl], ck_rec=arecs[slot][sl],
+                              rec_ready=ready[sl], rec_seq=seq, status=status[sl],
+                              ck_shared=None if src is None else sums_b[src], ck_shared_parts=0 if src is None else 1,
+                              ck_flag=None if src is None else flag, ck_flag_seq=seq - lag,
+                              stream=streams[g].cuda_stream)
+        comm.records_exchange_bound(eng, B, arecs[slot], ready, seq, sums_b[slot], flag, slot)
+    torch.cuda.synchronize()
+    assert (status.cpu().numpy() == 0).all()
+    assert int(flag.item()) == passes and (ready.cpu().numpy() == passes).all()
+    assert torch.equal(ut_a, ut_b) and torch.equal(u0_a, u0_b)
+    assert torch.equal(sums_a[passes - 1], sums_b[(passes - 1) % NB])
+    assert float(sums_a[passes - 1][K2]) == B
+    comm.close()
+    eng.close()
+
+
+def test_device_bound_exchange_times_out_instead_of_hanging():
+    """A consumer whose flag never arrives, and a record sum whose producers never report, give up after tens of
+    milliseconds: per-agent EEA_ERR_TIMEOUT, the agent's OWN c_k in the gradient (bitwise the call without a shared c_k);
+    a sum that gave up marks its record with a negative agent count, which its consumers report the same way."""
+    rng = np.random.default_rng(29)
+    for K, horizon in ((10, 20.0), (30, 6.0)):
+        B = 6
+        eng, _ = make_pair("omni", K, horizon, n_oracles=0)
+        T, K2, L = eng.T, eng.K2, eng.ck_record_len
+        d_pose = dev(random_poses(rng, B))
+        ut0 = rng.uniform(-0.3, 0.3, (B, T, 3))
+        ut_ref, u0_ref = dev(ut0), torch.empty((B, 3), dtype=torch.float64, device="cuda")
+        eng.control_batch(B, d_pose, ut_ref, u0_ref)
+        # (1) flag never set
+        flag = torch.zeros((1,), dtype=torch.int32, device="cuda")
+        rec = torch.ones((L,), dtype=torch.float64, device="cuda")
+        status = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+        ut_a, u0_a = dev(ut0), torch.empty((B, 3), dtype=torch.float64, device="cuda")
+        eng.control_batch(B, d_pose, ut_a, u0_a, ck_shared=rec, ck_shared_parts=1, ck_flag=flag, ck_flag_seq=5, status=status)
+        torch.cuda.synchronize()
+        assert (status.cpu().numpy() == capi.ERR_TIMEOUT).all()
+        assert torch.equal(ut_a, ut_ref) and torch.equal(u0_a, u0_ref)
+        # (2) producers never report: the sum gives up, publishes its flag with a negative count
+        arec = torch.zeros((B, L), dtype=torch.float64, device="cuda")
+        ready = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        out = torch.zeros((L,), dtype=torch.float64, device="cuda")
+        eng.ck_records_sum_bound(B, arec, ready, 3, out, flag=flag)
+        torch.cuda.synchronize()
+        assert int(flag.item()) == 3 and float(out[K2]) < 0
+        status.fill_(-1)
+        ut_b, u0_b = dev(ut0), torch.empty((B, 3), dtype=torch.float64, device="cuda")
+        eng.control_batch(B, d_pose, ut_b, u0_b, ck_shared=out, ck_shared_parts=1, ck_flag=flag, ck_flag_seq=3, status=status)
+        torch.cuda.synchronize()
+        assert (status.cpu().numpy() == capi.ERR_TIMEOUT).all()
+        assert torch.equal(ut_b, ut_ref) and torch.equal(u0_b, u0_ref)
+        eng.close()
 
 
 @pytest.mark.parametrize("model", ["simple_cart", "omni"])
