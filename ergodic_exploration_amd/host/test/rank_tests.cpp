@@ -1,0 +1,370 @@
+// Multi-rank exchange paths of the engine with TWO ranks on ONE GPU: the ranks are two threads of this
+// process, each with its own engine, streams and eea_comm (eea_comm_create(nranks = 2)); the collective library behind
+// the communicators is the test double tests/fake_rccl/librccl.so.1 (host rendezvous + device copies), which csrc/comm.hip
+// binds at run time because the harness puts its directory in front of LD_LIBRARY_PATH -- no PyTorch, no real RCCL in
+// the process (RCCL itself refuses two ranks of one communicator on one device).
+//
+// What runs here for the first time with more than one rank:
+//   (1) eea_comm_create / rank / nranks;
+//   (2) the all-gather of every agent's c_k (north_star's exchange): rank order, bitwise against one rank that holds
+//       all agents (AgentBatch::gatherTrajCoeff);
+//   (3) the stream-ordered consensus of AgentBatch::control(true) (record sum + all-reduce of the 816-byte record),
+//       equal and ragged shards, several steps back to back, against one rank holding all agents: <= 1e-12;
+//   (4) the DEVICE-BOUND exchange (eea_comm_records_exchange_bound: polling record sum -> all-reduce -> publish -> flag;
+//       consumers wait inside their kernels) with two ranks, lag 1, five dependent passes: controls against one rank holding all
+//       agents <= 1e-9 (the parity bar on controls),
+//       no agent timed out;
+//   (5) the grid-tiled occupancy target: rows split over the ranks, one all-reduce of K^2 sums, eea_set_phik_from_sums,
+//       against the un-tiled eea_set_target_occupancy: <= 1e-12.
+// Semantics source: decentralised ergodic control shares c_k between agents (reference README.md:225-227); every agent
+// is one reference ErgodicControl (ergodic_control.hpp:224-311).
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include <ergodic_exploration/agent_batch.hpp>
+
+using namespace ergodic_exploration;
+
+static int g_fail = 0, g_checks = 0;
+#define CHECK(cond)                                                          \
+  do {                                                                       \
+    ++g_checks;                                                              \
+    if (!(cond)) {                                                           \
+      ++g_fail;                                                              \
+      std::printf("FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond);            \
+    }                                                                        \
+  } while (0)
+
+namespace
+{
+constexpr unsigned K = 10, K2 = 100;
+mat make_rinv()
+{
+  mat Rinv(3, 3);
+  Rinv(0, 0) = 1.0;
+  Rinv(1, 1) = 1.0;
+  Rinv(2, 2) = 2.0;
+  return Rinv;
+}
+const vec kUmin{ -1.0, -1.0, -2.0 }, kUmax{ 1.0, 1.0, 2.0 };
+mat make_poses(unsigned n)
+{
+  mat p(3, n);
+  for (unsigned a = 0; a < n; ++a) {
+    p(0, a) = -0.7 + std::fmod(0.13 * a, 11.0);   // inside the 12 x 6 m map (clamped controls would compare trivially)
+    p(1, a) = -0.5 + 0.1 * (a % 47);
+    p(2, a) = -3.0 + std::fmod(0.083 * a, 6.0);
+  }
+  return p;
+}
+mat cols(const mat& m, unsigned first, unsigned n)
+{
+  mat out(m.n_rows(), n);
+  for (unsigned c = 0; c < n; ++c) {
+    for (unsigned r = 0; r < m.n_rows(); ++r) out(r, c) = m(r, first + c);
+  }
+  return out;
+}
+double max_abs_diff(const mat& a, const mat& b)
+{
+  double w = 0.0;
+  for (unsigned c = 0; c < a.n_cols(); ++c) {
+    for (unsigned r = 0; r < a.n_rows(); ++r) w = std::max(w, std::fabs(a(r, c) - b(r, c)));
+  }
+  return w;
+}
+struct World
+{
+  GridMap grid{ -1.0, 11.0, -1.0, 5.0, 0.05, GridData(240 * 120, 0) };
+  Target target{ { Gaussian({ 2.5, 2.5 }, { 1.5, 1.5 }), Gaussian({ 8.5, 2.5 }, { 1.5, 1.5 }) } };
+};
+
+// runs fn(rank, comm) on two threads, each with its communicator of the same id
+void on_two_ranks(const std::function<void(int, eea_comm*)>& fn)
+{
+  char id[EEA_COMM_ID_BYTES];
+  throw_on_error(eea_comm_get_unique_id(id));
+  std::string errors[2];
+  auto body = [&](int rank) {
+    try {
+      hip_check(hipSetDevice(0));
+      eea_comm* c = nullptr;
+      throw_on_error(eea_comm_create(0, 2, rank, id, &c));
+      fn(rank, c);
+      eea_comm_destroy(c);
+    } catch (const std::exception& e) {
+      errors[rank] = e.what();
+    }
+  };
+  std::thread t1(body, 1);
+  body(0);
+  t1.join();
+  for (const std::string& e : errors) {
+    if (!e.empty()) {
+      ++g_fail;
+      std::printf("FAIL rank thread: %s\n", e.c_str());
+    }
+  }
+}
+
+// (2) + (3): AgentBatch over two ranks against one rank holding all agents
+void test_agent_batch_two_ranks(unsigned n0, unsigned n1, bool gather)
+{
+  const World w;
+  const unsigned N = n0 + n1;
+  const mat poses = make_poses(N), Rinv = make_rinv();
+  // reference: one rank, all agents
+  AgentBatch<models::Omni> ref(N, 0.1, 5.0, 0.1, 1.0, K, Rinv, kUmin, kUmax);
+  ref.setTarget(w.target);
+  ref.configTarget(w.grid);
+  ref.setPoses(poses);
+  ref.control();
+  const mat ck_ref = ref.gatherTrajCoeff();
+  for (int i = 0; i < 4; ++i) ref.control(true);
+  const mat u_ref = ref.controls();
+  const vec cbar_ref = ref.consensusTrajCoeff();
+
+  mat u[2], ck[2];
+  vec cbar[2];
+  int ranks_seen[2] = { -1, -1 }, nranks_seen[2] = { 0, 0 };
+  on_two_ranks([&](int rank, eea_comm* c) {
+    ranks_seen[rank] = eea_comm_rank(c);
+    nranks_seen[rank] = eea_comm_nranks(c);
+    const unsigned first = rank == 0 ? 0 : n0, n = rank == 0 ? n0 : n1;
+    AgentBatch<models::Omni> b(n, 0.1, 5.0, 0.1, 1.0, K, Rinv, kUmin, kUmax, c);
+    b.setTarget(w.target);
+    b.configTarget(w.grid);
+    b.setPoses(cols(poses, first, n));
+    b.control();
+    if (gather) ck[rank] = b.gatherTrajCoeff();   // equal shards only (one ncclAllGather)
+    for (int i = 0; i < 4; ++i) b.control(true);  // back to back: no host synchronisation in between
+    u[rank] = b.controls();
+    cbar[rank] = b.consensusTrajCoeff();
+  });
+  CHECK(ranks_seen[0] == 0 && ranks_seen[1] == 1 && nranks_seen[0] == 2 && nranks_seen[1] == 2);
+  if (gather) {
+    for (int r = 0; r < 2; ++r) {
+      CHECK(ck[r].n_rows() == K2 && ck[r].n_cols() == N);
+      CHECK(ck[r].n_cols() == N && max_abs_diff(ck[r], ck_ref) == 0.0);  // rank order, bitwise
+    }
+  }
+  // consensus: the ranks' sum records are added per rank and then in rank order -- another order than one rank's tree
+  double wc = 0.0;
+  for (unsigned m = 0; m < K2; ++m) {
+    wc = std::max(wc, std::fabs(cbar[0](m) - cbar_ref(m)));
+    CHECK(cbar[0](m) == cbar[1](m));  // both ranks hold the same all-reduced record
+  }
+  CHECK(wc <= 1e-13);
+  CHECK(max_abs_diff(u[0], cols(u_ref, 0, n0)) <= 1e-12);
+  CHECK(max_abs_diff(u[1], cols(u_ref, n0, n1)) <= 1e-12);
+  std::printf("  agent batch %u + %u agents%s: |c_bar diff| %.2e, |u diff| %.2e / %.2e\n", n0, n1, gather ? " (+ gather)" : "", wc,
+              max_abs_diff(u[0], cols(u_ref, 0, n0)), max_abs_diff(u[1], cols(u_ref, n0, n1)));
+}
+
+struct DevBufs
+{
+  std::vector<void*> ptrs;
+  void* alloc(size_t bytes, bool zero = true)
+  {
+    void* p = nullptr;
+    hip_check(hipMalloc(&p, bytes ? bytes : 1));
+    if (zero) hip_check(hipMemset(p, 0, bytes));
+    ptrs.push_back(p);
+    return p;
+  }
+  ~DevBufs()
+  {
+    for (void* p : ptrs) (void)hipFree(p);
+  }
+};
+
+eea_engine* make_engine(const World& w, unsigned k, double horizon)
+{
+  eea_config cfg{};
+  cfg.model = EEA_MODEL_OMNI;
+  cfg.precision = EEA_PREC_F64;
+  cfg.device = 0;
+  cfg.dt = 0.1;
+  cfg.horizon = horizon;
+  cfg.resolution = 0.1;
+  cfg.expl_weight = 1.0;
+  cfg.num_basis = k;
+  const mat Rinv = make_rinv();
+  for (int i = 0; i < 9; ++i) cfg.Rinv[i] = Rinv.memptr()[i];
+  for (int i = 0; i < 3; ++i) {
+    cfg.umin[i] = kUmin(i);
+    cfg.umax[i] = kUmax(i);
+  }
+  eea_engine* e = nullptr;
+  throw_on_error(eea_create(&cfg, &e));
+  std::vector<double> mu, sg;
+  w.target.flatten(mu, sg);
+  throw_on_error(eea_set_target_gaussians(e, static_cast<unsigned>(mu.size() / 2), mu.data(), sg.data()));
+  throw_on_error(eea_config_domain(e, w.grid.xmin(), w.grid.xmax(), w.grid.ymin(), w.grid.ymax(), nullptr, nullptr));
+  return e;
+}
+
+// `passes` consensus passes of n agents (two agent groups on two streams) through the device-bound exchange, lag 1;
+// returns the final u0 (3 x n) and the number of agents that ever reported a status != 0
+mat bound_consensus_passes(const World& w, eea_comm* c, const mat& poses, int passes, int* bad_status)
+{
+  const unsigned n = poses.n_cols();
+  eea_engine* e = make_engine(w, K, 20.0);
+  const unsigned T = eea_steps(e), L = eea_ck_record_len(e);
+  constexpr int NB = 4;
+  DevBufs d;
+  double* const d_pose = static_cast<double*>(d.alloc(sizeof(double) * 3 * n));
+  double* const d_ut = static_cast<double*>(d.alloc(sizeof(double) * 3 * T * n));
+  double* const d_u0 = static_cast<double*>(d.alloc(sizeof(double) * 3 * n));
+  int* const d_status = static_cast<int*>(d.alloc(sizeof(int) * n));
+  unsigned* const d_ready = static_cast<unsigned*>(d.alloc(sizeof(unsigned) * n));
+  unsigned* const d_flag = static_cast<unsigned*>(d.alloc(sizeof(unsigned)));
+  double* d_arec[NB];
+  double* d_sum[NB];
+  for (int s = 0; s < NB; ++s) {
+    d_arec[s] = static_cast<double*>(d.alloc(sizeof(double) * L * n));
+    d_sum[s] = static_cast<double*>(d.alloc(sizeof(double) * L));
+  }
+  hip_check(hipMemcpy(d_pose, poses.memptr(), sizeof(double) * 3 * n, hipMemcpyHostToDevice));
+  hipStream_t streams[2];
+  for (hipStream_t& s : streams) hip_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  std::vector<int> h_status(n);
+  *bad_status = 0;
+  const unsigned gb[3] = { 0, n / 2, n };
+  for (int i = 0; i < passes; ++i) {
+    const unsigned seq = static_cast<unsigned>(i) + 1;
+    const int slot = i % NB, src = (i - 1) % NB;
+    for (int g = 0; g < 2; ++g) {
+      const unsigned first = gb[g], cnt = gb[g + 1] - gb[g];
+      eea_batch_io io{};
+      io.d_pose = d_pose + 3 * first;
+      io.d_ut = d_ut + static_cast<size_t>(3) * T * first;
+      io.d_u0 = d_u0 + 3 * first;
+      io.d_status = d_status + first;
+      io.d_ck_rec = d_arec[slot] + static_cast<size_t>(L) * first;
+      io.d_rec_ready = d_ready + first;
+      io.rec_seq = seq;
+      if (i >= 1) {
+        io.d_ck_shared = d_sum[src];
+        io.ck_shared_parts = 1;
+        io.d_ck_flag = d_flag;
+        io.ck_flag_seq = seq - 1;
+      }
+      throw_on_error(eea_control_batch(e, cnt, &io, streams[g]));
+    }
+    throw_on_error(eea_comm_records_exchange_bound(e, c, n, d_arec[slot], d_ready, seq, d_sum[slot], d_flag, slot));
+    // (the status words are overwritten every pass: look at them while the next pass is not yet launched)
+    for (hipStream_t s : streams) hip_check(hipStreamSynchronize(s));
+    hip_check(hipMemcpy(h_status.data(), d_status, sizeof(int) * n, hipMemcpyDeviceToHost));
+    for (int st : h_status) *bad_status += st != 0;
+  }
+  hip_check(hipDeviceSynchronize());
+  mat u(3, n);
+  hip_check(hipMemcpy(u.memptr(), d_u0, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
+  for (hipStream_t s : streams) (void)hipStreamDestroy(s);
+  eea_destroy(e);
+  return u;
+}
+
+// (4): the device-bound exchange with two ranks
+void test_bound_exchange_two_ranks(unsigned n0, unsigned n1)
+{
+  const World w;
+  const unsigned N = n0 + n1;
+  const mat poses = make_poses(N);
+  const int passes = 5;
+  eea_comm* local = nullptr;
+  throw_on_error(eea_comm_create(0, 1, 0, nullptr, &local));
+  int bad_ref = 0;
+  const mat u_ref = bound_consensus_passes(w, local, poses, passes, &bad_ref);
+  eea_comm_destroy(local);
+  CHECK(bad_ref == 0);
+  mat u[2];
+  int bad[2] = { -1, -1 };
+  on_two_ranks([&](int rank, eea_comm* c) {
+    const unsigned first = rank == 0 ? 0 : n0, n = rank == 0 ? n0 : n1;
+    u[rank] = bound_consensus_passes(w, c, cols(poses, first, n), passes, &bad[rank]);
+  });
+  CHECK(bad[0] == 0 && bad[1] == 0);
+  CHECK(u[0].n_cols() == n0 && u[1].n_cols() == n1);
+  const double w0 = max_abs_diff(u[0], cols(u_ref, 0, n0)), w1 = max_abs_diff(u[1], cols(u_ref, n0, n1));
+  // five dependent passes at T = 200 with the consensus in the loop: a 1e-16 difference of c_bar (another summation order
+  // over the ranks) feeds back through the warm start and the co-state (measured 4e-13 ... 2e-11): the parity bar on
+  // controls, 1e-9
+  CHECK(w0 <= 1e-9 && w1 <= 1e-9);
+  std::printf("  device-bound exchange %u + %u agents, lag 1, %d passes: |u diff| %.2e / %.2e, timeouts %d / %d\n", n0, n1, passes, w0,
+              w1, bad[0], bad[1]);
+}
+
+// (5): grid-tiled occupancy target
+void test_grid_tile_two_ranks()
+{
+  const unsigned n = 96, K5 = 12;
+  const double res = 0.1, l = (n - 1) * res;
+  std::vector<int8_t> occ(static_cast<size_t>(n) * n);
+  for (unsigned iy = 0; iy < n; ++iy) {
+    for (unsigned ix = 0; ix < n; ++ix) {
+      const unsigned v = (ix / 8 + 3 * (iy / 8)) % 10;
+      occ[static_cast<size_t>(iy) * n + ix] = v < 6 ? 0 : (v < 8 ? 100 : -1);
+    }
+  }
+  const World w;
+  auto phik_of = [&](eea_engine* e) {
+    std::vector<double> p(K5 * K5);
+    throw_on_error(eea_get_phik(e, p.data()));
+    return p;
+  };
+  eea_engine* ref = make_engine(w, K5, 2.0);
+  throw_on_error(eea_set_target_occupancy(ref, n, n, occ.data(), 0, l, l, nullptr));
+  const std::vector<double> p_ref = phik_of(ref);
+  eea_destroy(ref);
+  std::vector<double> p[2];
+  const unsigned split = 41;  // ragged: 41 + 55 rows
+  on_two_ranks([&](int rank, eea_comm* c) {
+    eea_engine* e = make_engine(w, K5, 2.0);
+    const unsigned row0 = rank == 0 ? 0 : split, nrows = rank == 0 ? split : n - split;
+    DevBufs d;
+    int8_t* const d_rows = static_cast<int8_t*>(d.alloc(static_cast<size_t>(nrows) * n, false));
+    double* const d_sums = static_cast<double*>(d.alloc(sizeof(double) * K5 * K5));
+    hip_check(hipMemcpy(d_rows, occ.data() + static_cast<size_t>(row0) * n, static_cast<size_t>(nrows) * n, hipMemcpyHostToDevice));
+    hipStream_t s = nullptr;
+    hip_check(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    throw_on_error(eea_spatial_coeff_occupancy_rows(e, n, n, row0, nrows, d_rows, l, l, d_sums, s));
+    throw_on_error(eea_comm_allreduce_sum(e, c, d_sums, K5 * K5, s));
+    throw_on_error(eea_set_phik_from_sums(e, d_sums, l, l, s));
+    hip_check(hipStreamSynchronize(s));
+    p[rank] = phik_of(e);
+    (void)hipStreamDestroy(s);
+    eea_destroy(e);
+  });
+  double worst = 0.0;
+  for (unsigned m = 0; m < K5 * K5; ++m) {
+    CHECK(p[0].size() == K5 * K5 && p[1].size() == K5 * K5 && p[0][m] == p[1][m]);
+    if (p[0].size() == K5 * K5) worst = std::max(worst, std::fabs(p[0][m] - p_ref[m]));
+  }
+  CHECK(worst <= 1e-12);
+  std::printf("  grid tile 41 + 55 rows of a %ux%u occupancy grid, K = %u: |phi_k diff| %.2e\n", n, n, K5, worst);
+}
+}  // namespace
+
+int main()
+{
+  try {
+    hip_check(hipSetDevice(0));
+    test_agent_batch_two_ranks(35, 35, true);
+    test_agent_batch_two_ranks(41, 29, false);  // ragged shards
+    test_bound_exchange_two_ranks(300, 300);
+    test_bound_exchange_two_ranks(77, 130);
+    test_grid_tile_two_ranks();
+  } catch (const std::exception& e) {
+    std::printf("FAIL exception: %s\n", e.what());
+    ++g_fail;
+  }
+  std::printf("ranks2: %d checks, %d failures\n", g_checks, g_fail);
+  return g_fail ? 1 : 0;
+}

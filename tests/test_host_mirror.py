@@ -51,6 +51,26 @@ def test_device_backed_classes_and_anchors():
     assert "0 failures" in out.stdout
 
 
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_through_the_rccl_test_double():
+    """host/test/rank_tests.cpp: eea_comm_create(nranks = 2), the all-gather's rank order, AgentBatch's stream-ordered
+    consensus (equal + ragged shards), the device-bound exchange with a collective in it, and the grid-tiled occupancy
+    target -- two ranks as two threads of one process WITHOUT PyTorch, the collectives served by tests/fake_rccl
+    (RCCL itself refuses two ranks of one communicator on one device).  The harness checks that the process really
+    bound the test double."""
+    _build()
+    fake = os.path.join(ROOT, "tests", "fake_rccl")
+    subprocess.run(["make", "-s", "-C", fake], check=True)
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = fake + os.pathsep + env.get("LD_LIBRARY_PATH", "")
+    out = subprocess.run([os.path.join(BUILD, "rank_tests")], capture_output=True, text=True, env=env, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "0 failures" in out.stdout and "ranks2:" in out.stdout
+    # the binary has no link dependency on any RCCL; with the fake in front, that is what dlopen("librccl.so.1") finds
+    ldd = subprocess.run(["ldd", os.path.join(BUILD, "rank_tests")], capture_output=True, text=True, env=env).stdout
+    assert "rccl" not in ldd
+
+
 # parameter values of ergodic_exploration_amd/host/config/explore_{omni,cart}.yaml
 COLL = (0.7, 1.0, 0.2, 0.8)
 DWA = {"omni": (0.1, 2.0, 0.2, 2.5, 2.5, 1.0, 1.0, -1.0, 1.0, -1.0, 2.0, -2.0, 3, 8, 5),
