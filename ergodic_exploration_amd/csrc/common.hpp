@@ -136,6 +136,12 @@ int target_fill_blocks(size_t P);
 template <typename R>
 hipError_t launch_target_fill_args(const R* d_coord, int nx, int ny, const GaussArgs<R>& ga, R* d_phi,
                                    R* d_partials, int K, R pi_lx, R pi_ly, R* d_cx, R* d_cy, hipStream_t s);
+// configTarget for a sum of axis-aligned Gaussians in ONE launch of one workgroup: phi_k and the target's mass from the
+// per-axis factors (phik_kernel.hip gaussian_phik_kernel); needs gaussian_phik_lds_bytes <= 160 KiB of LDS
+size_t gaussian_phik_lds_bytes(int nx, int ny, int n_gauss, int K, size_t real_size);
+template <typename R>
+hipError_t launch_gaussian_phik(const R* d_coord, int nx, int ny, const GaussArgs<R>& ga, int K, R inv_lx, R inv_ly,
+                                R* d_phik, R* d_mass, hipStream_t s, hipEvent_t stop = nullptr);
 // spatialCoeff of an UN-normalised grid divided by its mass (the sum of d_mass_partials); d_mass[0] receives
 // the mass.  stop (optional): an event bound to the completion of the last launch
 template <typename R>

@@ -23,7 +23,7 @@ namespace
 using eea::fail;
 
 // process-wide dispatch options (eea_set_option); index = EEA_OPT_*
-std::atomic<int> g_options[EEA_OPT_COUNT] = { { 0 }, { 0 }, { 0 }, { 1 } };
+std::atomic<int> g_options[EEA_OPT_COUNT] = { { 0 }, { 0 }, { 0 }, { 1 }, { 0 } };
 }  // namespace
 
 namespace eea
@@ -92,6 +92,10 @@ struct eea_engine
   unsigned nx = 0, ny = 0;
   bool have_fill_grid = false;  // d_phi holds the Target::fill output of the last rebuild ...
   bool phi_is_raw = false;      // ... un-normalised: d_sum[0] is its mass (eea_get_target_grid divides)
+  // ... or WILL hold it: a Gaussian rebuild computes phi_k from the per-axis factors without the grid; the grid is
+  // filled when eea_get_target_grid asks for it, from the Gaussians as they were at the rebuild (Fourier frame)
+  bool fill_deferred = false;
+  std::vector<double> fill_gauss;  // [n][4] of the last rebuild: mean - map_pos, diag(cov_inv)
   DevBuf d_phi, d_axis, d_cx, d_cy, d_work, d_gauss, d_sum;
   // accumulated grid coordinates 0, res, res + res, ... (ergodic_control.hpp:387-408): one device array serves
   // both axes of every grid of this engine (the resolution is fixed); grown on demand
@@ -300,21 +304,59 @@ eea_status rebuild_phik(eea_engine* e, hipStream_t s, bool wait)
   e->nx = nx;
   e->ny = ny;
   const int ng = static_cast<int>(e->mu.size() / 2);
-  bool tables_stale = false;
-  eea_status st = upload_axes_and_tables<R>(e, nx, ny, s, ng <= eea::kMaxGaussArgs ? &tables_stale : nullptr);
-  if (st != EEA_OK) return st;
-
   // Gaussian parameters as the reference prepares them: mean translated into the Fourier
   // frame (target.hpp:99), cov_inv = inv(diagmat(sigma^2)) (target.hpp:69; 2x2 inverse)
   std::vector<R> g(static_cast<size_t>(4) * (ng ? ng : 1));
+  e->fill_gauss.assign(static_cast<size_t>(4) * ng, 0.0);
   for (int i = 0; i < ng; ++i) {
     const double a = e->sigma[2 * i] * e->sigma[2 * i], d = e->sigma[2 * i + 1] * e->sigma[2 * i + 1];
     const double det = a * d - 0.0 * 0.0;
-    g[4 * i + 0] = static_cast<R>(e->mu[2 * i] - e->map_x);
-    g[4 * i + 1] = static_cast<R>(e->mu[2 * i + 1] - e->map_y);
-    g[4 * i + 2] = static_cast<R>(d / det);
-    g[4 * i + 3] = static_cast<R>(a / det);
+    e->fill_gauss[4 * i + 0] = e->mu[2 * i] - e->map_x;
+    e->fill_gauss[4 * i + 1] = e->mu[2 * i + 1] - e->map_y;
+    e->fill_gauss[4 * i + 2] = d / det;
+    e->fill_gauss[4 * i + 3] = a / det;
+    for (int c = 0; c < 4; ++c) g[4 * i + c] = static_cast<R>(e->fill_gauss[4 * i + c]);
   }
+  // A sum of axis-aligned Gaussians on the rectangular grid factors per axis, and so do phi_k and the mass: ONE launch
+  // of one workgroup, (nx + ny)(G + K) transcendentals, no grid (gaussian_phik_kernel).  The grid itself is filled only
+  // when eea_get_target_grid asks for it.  EEA_OPT_REBUILD_IMPL = 1 forces the streaming form below (A/B, tests).
+  if (ng >= 1 && ng <= eea::kMaxGaussArgs && eea::option(EEA_OPT_REBUILD_IMPL) != 1 &&
+      eea::gaussian_phik_lds_bytes(nx, ny, ng, e->K, sizeof(R)) <= 160 * 1024) {
+    eea_status st = ensure_axis<R>(e, nx > ny ? nx : ny);
+    if (st != EEA_OK) return st;
+    if (e->d_sum.cap < sizeof(R)) {
+      EEA_HIP(hipDeviceSynchronize());
+      EEA_HIP(e->d_sum.reserve(sizeof(R) * 64));
+    }
+    eea::GaussArgs<R> ga;
+    std::memset(&ga, 0, sizeof(ga));
+    ga.n = ng;
+    for (int i = 0; i < ng; ++i) {
+      for (int c = 0; c < 4; ++c) ga.g[i][c] = g[4 * i + c];
+    }
+    if (!wait && e->ev_rebuild == nullptr) EEA_HIP(hipEventCreateWithFlags(&e->ev_rebuild, hipEventDisableTiming | hipEventDisableSystemFence));
+    EEA_HIP(eea::launch_gaussian_phik<R>(static_cast<const R*>(e->d_axis.p), nx, ny, ga, e->K,
+                                         static_cast<R>(1.0 / e->lx), static_cast<R>(1.0 / e->ly),
+                                         static_cast<R*>(e->d_phik.p), static_cast<R*>(e->d_sum.p), s,
+                                         wait ? nullptr : e->ev_rebuild));
+    if (wait) {
+      st = wait_stream_spin(e, s);
+      if (st != EEA_OK) return st;
+      e->rebuild_pending = false;
+    } else {
+      e->rebuild_stream = s;
+      e->rebuild_pending = true;
+    }
+    e->have_phik = true;
+    e->have_fill_grid = true;
+    e->phi_is_raw = true;
+    e->fill_deferred = true;
+    return EEA_OK;
+  }
+  e->fill_deferred = false;
+  bool tables_stale = false;
+  eea_status st = upload_axes_and_tables<R>(e, nx, ny, s, ng <= eea::kMaxGaussArgs ? &tables_stale : nullptr);
+  if (st != EEA_OK) return st;
   const size_t need_phi = sizeof(R) * P;
   const int fill_blocks_args = eea::target_fill_blocks(P);
   const int fill_blocks_buf = static_cast<int>((P + eea::kBlock - 1) / eea::kBlock);
@@ -375,6 +417,35 @@ eea_status rebuild_phik(eea_engine* e, hipStream_t s, bool wait)
   e->have_phik = true;
   e->have_fill_grid = true;
   e->phi_is_raw = true;
+  return EEA_OK;
+}
+
+// Target::fill of the last Gaussian rebuild on demand (eea_get_target_grid): the un-normalised grid into d_phi; d_sum[0]
+// keeps the mass the rebuild computed from the per-axis factors
+template <typename R>
+eea_status fill_deferred_grid(eea_engine* e)
+{
+  const unsigned nx = e->nx, ny = e->ny;
+  const size_t P = static_cast<size_t>(nx) * ny;
+  const int ng = static_cast<int>(e->fill_gauss.size() / 4);
+  const int blocks = eea::target_fill_blocks(P);
+  EEA_HIP(hipDeviceSynchronize());
+  EEA_HIP(e->d_phi.reserve(sizeof(R) * P));
+  DevBuf partials;  // (the fill's per-workgroup sums are not needed: the mass is already known)
+  EEA_HIP(partials.reserve(sizeof(R) * (static_cast<size_t>(blocks) + 1)));
+  eea::GaussArgs<R> ga;
+  std::memset(&ga, 0, sizeof(ga));
+  ga.n = ng;
+  for (int i = 0; i < ng; ++i) {
+    for (int c = 0; c < 4; ++c) ga.g[i][c] = static_cast<R>(e->fill_gauss[4 * i + c]);
+  }
+  const hipError_t err = eea::launch_target_fill_args<R>(static_cast<const R*>(e->d_axis.p), nx, ny, ga, static_cast<R*>(e->d_phi.p),
+                                                         static_cast<R*>(partials.p), e->K, R(0), R(0), nullptr, nullptr, nullptr);
+  const hipError_t err2 = hipDeviceSynchronize();
+  partials.release();
+  EEA_HIP(err);
+  EEA_HIP(err2);
+  e->fill_deferred = false;
   return EEA_OK;
 }
 
@@ -597,6 +668,7 @@ eea_status eea_set_option(int option, int value)
     case EEA_OPT_WORKGROUP_THREADS: ok = value == 0 || value == 64 || value == 128 || value == 256; break;
     case EEA_OPT_COLLISION_IMPL: ok = value >= 0 && value <= 2; break;
     case EEA_OPT_MAILBOX_POLL: ok = value == 0 || value == 1; break;
+    case EEA_OPT_REBUILD_IMPL: ok = value == 0 || value == 1; break;
     default: return fail(EEA_ERR_INVALID_ARGUMENT, "unknown option");
   }
   if (!ok) return fail(EEA_ERR_INVALID_ARGUMENT, "option value out of range");
@@ -939,11 +1011,15 @@ eea_status eea_target_grid_size(const eea_engine* e, unsigned* nx, unsigned* ny)
 eea_status eea_get_target_grid(eea_engine* e, double* h_phi_vals)
 {
   if (check_engine(e) != EEA_OK || h_phi_vals == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
-  if (e->d_phi.p == nullptr || e->nx == 0 || !e->have_fill_grid) {
+  if (e->nx == 0 || !e->have_fill_grid || (e->d_phi.p == nullptr && !e->fill_deferred)) {
     return fail(EEA_ERR_NO_TARGET, "no Target::fill grid on the device (explicit / occupancy targets are not kept)");
   }
   if (finish_rebuild(e) != EEA_OK) return EEA_ERR_HIP;
   const size_t P = static_cast<size_t>(e->nx) * e->ny;
+  if (e->fill_deferred) {  // the Gaussian rebuild never needed the grid: fill it now (un-normalised; the mass is in d_sum[0])
+    const eea_status stf = e->f32 ? fill_deferred_grid<float>(e) : fill_deferred_grid<double>(e);
+    if (stf != EEA_OK) return stf;
+  }
   eea_status st = download_reals(e, e->d_phi.p, P, h_phi_vals);
   if (st != EEA_OK || !e->phi_is_raw) return st;
   // the device keeps the un-normalised grid and its mass; phi_vals / sum(phi_vals) as target.cpp:87 forms it

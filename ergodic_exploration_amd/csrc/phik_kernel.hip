@@ -151,6 +151,97 @@ __global__ __launch_bounds__(kBlock) void target_fill_args_kernel(const R* __res
   if (threadIdx.x == 0) partials[blockIdx.x] = t;
 }
 
+// ---- configTarget for Gaussian targets, in ONE launch of ONE workgroup (round 4) ---------------------------------------
+// The reference's target is a sum of AXIS-ALIGNED Gaussians (target.hpp:68-70: Sigma = diagmat(sigma^2)), evaluated on a
+// rectangular grid whose coordinates are products of two 1-D sequences (ergodic_control.hpp:387-408).  Both the target
+// and the basis therefore factor per axis and so does every sum over the grid:
+//   sum_{ix,iy} exp(-1/2 cxx dx^2 - 1/2 cyy dy^2) cos(a_k1 x) cos(b_k2 y)
+//     = [sum_ix exp(-1/2 cxx dx^2) cos(a_k1 x_ix)] [sum_iy exp(-1/2 cyy dy^2) cos(b_k2 y_iy)]  =: Ax_g(k1) Ay_g(k2)
+// phi_k = sum_g Ax_g(k1) Ay_g(k2) / sum_g Ax_g(0) Ay_g(0)   (Target::fill's normalisation, target.cpp:87, is mode (0,0))
+// -- (nx + ny)(G + 1) transcendental evaluations and (nx + ny) G K multiply-adds instead of nx ny (G + K^2), the
+// reference's value up to rounding (its one exp of the summed exponent against a product of two: ~2 ulp per point; the
+// cosines of a point by the Chebyshev recurrence from cos(pi x / l), error <~ k^2 2^-54 as in the control kernels).  The
+// grid itself (eea_get_target_grid) is filled only when somebody asks for it.
+//   1. wavefronts 0..3 take the x axis, 4..7 the y axis; a lane owns the points lane + 64 (w + 4 p) of its axis.  Per
+//      Gaussian g: per point one exponential and T_k(cos(pi x / l)) by recurrence, accumulated over the lane's points in
+//      K registers; then ONE 4-step row sum per (g, k) -- the four rows of the wavefront keep separate partials;
+//   2. A[axis][g][k] = the (wavefront, row) partials in fixed order;   3. the K^2 modes.
+// One workgroup on one CU: what counts is the number of wavefront instructions (4 cycles each on one of 4 SIMDs), so
+// the cross-lane sums are taken once per (g, k) and wavefront, not once per point round (first form: 30 us at 1024^2).
+constexpr int kGaussBlock = 512;
+constexpr int kGaussAxisWaves = 4;   // wavefronts per axis
+constexpr int kGaussKMax = kMaxBasis;
+template <typename R>
+__global__ __launch_bounds__(kGaussBlock) void gaussian_phik_kernel(const R* __restrict__ coord, int nx, int ny,
+                                                                    const GaussArgs<R> ga, int K, R inv_lx, R inv_ly,
+                                                                    R* __restrict__ phik, R* __restrict__ mass_out)
+{
+  extern __shared__ __attribute__((aligned(16))) char gsm_raw[];
+  constexpr int kParts = 2 * kGaussAxisWaves * 4;  // (axis, wavefront of the axis, row of 16 lanes)
+  const int G = ga.n, GK = G * K;
+  R* const sW = reinterpret_cast<R*>(gsm_raw);             // [axis][wave of the axis][row][g][K] partial sums
+  R* const sA = sW + static_cast<size_t>(kParts) * GK;      // [axis][g][K]
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  const int axis = wave / kGaussAxisWaves, aw = wave - axis * kGaussAxisWaves;
+  const int cnt = axis ? ny : nx;
+  const R inv_l = axis ? inv_ly : inv_lx;
+  R* const dst = sW + (static_cast<size_t>(wave) * 4 + (lane >> 4)) * GK;
+  const int first = aw * kWave + lane, stride = kGaussAxisWaves * kWave;
+  for (int g = 0; g < G; ++g) {
+    R acc[kGaussKMax];
+#pragma unroll
+    for (int k = 0; k < kGaussKMax; ++k) acc[k] = R(0);
+    const R mean = ga.g[g][axis], cinv = ga.g[g][2 + axis];
+    for (int i = first; i < cnt; i += stride) {
+      const R x = coord[i];
+      const R d = x - mean;
+      const R e = exp_r(R(-0.5) * ((d * cinv) * d));  // (dx cinv_xx) dx as target.hpp:101 groups it
+      R sn, c1;
+      sincospi_r(x * inv_l, &sn, &c1);                // cos(pi x / l): basis.cpp:85 at k = 1
+      const R two = c1 + c1;
+      R ta = e, tb = e * c1;                          // e T_k, e T_{k+1}: the recurrence is linear
+#pragma unroll
+      for (int k = 0; k < kGaussKMax; ++k) {
+        if (k < K) {  // wavefront-uniform
+          acc[k] += ta;
+          const R tn = two * tb - ta;
+          ta = tb;
+          tb = tn;
+        }
+      }
+    }
+    // row sums (lanes 15, 31, 47, 63 of the wavefront): four independent chains per step
+#pragma unroll
+    for (int k = 0; k < kGaussKMax; ++k) {
+      if (k < K) {
+        R v = acc[k];
+        v += dpp_or_zero<0x111, 0xf>(v);
+        v += dpp_or_zero<0x112, 0xf>(v);
+        v += dpp_or_zero<0x114, 0xf>(v);
+        v += dpp_or_zero<0x118, 0xf>(v);
+        if ((lane & 15) == 15) dst[g * K + k] = v;
+      }
+    }
+  }
+  __syncthreads();
+  for (int q = tid; q < 2 * GK; q += kGaussBlock) {  // q = axis * GK + (g * K + k)
+    const int ax = q / GK, r = q - ax * GK;
+    R a = R(0);
+    for (int part = 0; part < kGaussAxisWaves * 4; ++part) a += sW[(static_cast<size_t>(ax) * kGaussAxisWaves * 4 + part) * GK + r];
+    sA[q] = a;
+  }
+  __syncthreads();
+  R mass = R(0);
+  for (int g = 0; g < G; ++g) mass += sA[g * K] * sA[(G + g) * K];
+  for (int m = tid; m < K * K; m += kGaussBlock) {
+    const int k2 = m / K, k1 = m - k2 * K;  // mode order of basis.cpp:58-66
+    R v = R(0);
+    for (int g = 0; g < G; ++g) v += sA[g * K + k1] * sA[(G + g) * K + k2];
+    phik[m] = v / mass;
+  }
+  if (tid == 0) mass_out[0] = mass;
+}
+
 // un-normalised sum of axis-aligned Gaussians on the grid; gauss: [n][4] = mean (Fourier
 // frame) and diagonal of the inverse covariance
 template <typename R>
@@ -655,6 +746,32 @@ hipError_t launch_target_fill_args(const R* d_coord, int nx, int ny, const Gauss
   return hipGetLastError();
 }
 
+size_t gaussian_phik_lds_bytes(int nx, int ny, int n_gauss, int K, size_t real_size)
+{
+  (void)nx;
+  (void)ny;
+  return real_size * (static_cast<size_t>(2 * kGaussAxisWaves * 4) + 2) * n_gauss * K;
+}
+template <typename R>
+hipError_t launch_gaussian_phik(const R* d_coord, int nx, int ny, const GaussArgs<R>& ga, int K, R inv_lx, R inv_ly,
+                                R* d_phik, R* d_mass, hipStream_t s, hipEvent_t stop)
+{
+  const size_t lds = gaussian_phik_lds_bytes(nx, ny, ga.n, K, sizeof(R));
+  if (lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gaussian_phik_kernel<R>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+  }
+  if (stop != nullptr) {
+    hipExtLaunchKernelGGL(gaussian_phik_kernel<R>, dim3(1), dim3(kGaussBlock), lds, s, nullptr, stop, 0, d_coord, nx, ny, ga,
+                          K, inv_lx, inv_ly, d_phik, d_mass);
+  } else {
+    hipLaunchKernelGGL(gaussian_phik_kernel<R>, dim3(1), dim3(kGaussBlock), lds, s, d_coord, nx, ny, ga, K, inv_lx, inv_ly,
+                       d_phik, d_mass);
+  }
+  return hipGetLastError();
+}
+
 template <typename R>
 hipError_t launch_target_fill(const R* d_xs, const R* d_ys, int nx, int ny, const R* d_gauss,
                               int n_gauss, R* d_phi, R* d_partials, int* n_partials, hipStream_t s)
@@ -857,6 +974,8 @@ hipError_t launch_point_coeff(const R* d_x, const R* d_y, const R* d_w, unsigned
   template hipError_t launch_axis_tables<R>(const R*, int, int, int, R, R, R*, R*, hipStream_t);    \
   template hipError_t launch_target_fill_args<R>(const R*, int, int, const GaussArgs<R>&, R*, R*,   \
                                                  int, R, R, R*, R*, hipStream_t);                   \
+  template hipError_t launch_gaussian_phik<R>(const R*, int, int, const GaussArgs<R>&, int, R, R, R*, R*, hipStream_t, \
+                                              hipEvent_t);                                          \
   template hipError_t launch_spatial_coeff_normalised<R>(const R*, int, int, int, const R*, const R*, R*, R*, \
                                                          const R*, int, R*, hipStream_t, hipEvent_t); \
   template hipError_t launch_cos_tables<R>(const R*, int, int, R, R*, hipStream_t);                 \

@@ -86,7 +86,10 @@ enum { EEA_OPT_CONTROL_KERNEL = 0,    /* 0 = automatic (wavefront-per-agent kern
        EEA_OPT_COLLISION_IMPL = 2,    /* Collision::collisionCheck implementation: 0 = cost model, 1 = ring
                                          search, 2 = inflated map (both bit-exact) */
        EEA_OPT_MAILBOX_POLL = 3,      /* eea_control: 1 = poll the completion word (default), 0 = wait for the stream */
-       EEA_OPT_COUNT = 4 };
+       EEA_OPT_REBUILD_IMPL = 4,      /* configTarget rebuild of a Gaussian target: 0 = automatic (per-axis factors, one
+                                         launch of one workgroup), 1 = fill the grid and stream it (Target::fill +
+                                         Basis::spatialCoeff as two / three launches: what explicit grids take) */
+       EEA_OPT_COUNT = 5 };
 eea_status eea_set_option(int option, int value);
 int eea_get_option(int option);
 

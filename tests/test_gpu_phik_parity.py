@@ -13,6 +13,15 @@ from tests.gpu_util import MAP_BOUNDS, MEANS, SIGMAS
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["axis_factors", "fill_and_stream"])
+def rebuild_impl(request):
+    """configTarget of a Gaussian target has two implementations (EEA_OPT_REBUILD_IMPL): the per-axis factors in one launch
+    (default) and Target::fill + the streaming Basis::spatialCoeff that explicit grids take -- both against the oracle"""
+    capi.set_option(capi.OPT_REBUILD_IMPL, 1 if request.param == "fill_and_stream" else 0)
+    yield request.param
+    capi.set_option(capi.OPT_REBUILD_IMPL, 0)
+
+
 def _engine(K, resolution=0.1, precision=capi.PREC_F64):
     return capi.Engine(capi.make_config(capi.MODEL_OMNI, 0.1, 2.0, resolution, 1.0, K, np.eye(3),
                                         [-1] * 3, [1] * 3, precision=precision))
@@ -32,7 +41,7 @@ def _oracle_phik(K, bounds, means, sigmas, resolution=0.1):
     (7, (-3.0, 30.3, 2.0, 9.7), [[1.0, 4.0], [20.0, 8.0], [12.0, 3.0]],
      [[2.0, 1.0], [4.0, 2.5], [0.7, 0.9]]),                              # ragged 334 x 78, 3 Gaussians
 ])
-def test_phik_matches_oracle(K, bounds, means, sigmas):
+def test_phik_matches_oracle(K, bounds, means, sigmas, rebuild_impl):
     eng = _engine(K)
     eng.set_target_gaussians(means, sigmas)
     assert eng.config_domain(bounds) is True
@@ -55,7 +64,7 @@ def test_phik_matches_oracle(K, bounds, means, sigmas):
     (0.02, (0.0, 11.98, 0.0, 9.98), 6),     # 600 x 500 = 3.0e5 >= 2^18 points: 4 per thread
     (0.01, (-1.0, 20.0, 2.0, 23.0), 5),     # 2101 x 2101 = 4.4e6 >= 2^22 points: 16 per thread
 ])
-def test_fill_kernel_regimes(res, bounds, K):
+def test_fill_kernel_regimes(res, bounds, K, rebuild_impl):
     """Target::fill takes 1 / 4 / 16 grid points per thread by grid size (and a grid of one tile is normalised by the
     streaming kernel itself): phi_k and the normalised grid against the oracle in each regime."""
     means, sigmas = [[2.5, 3.5], [8.5, 6.5]], [[1.5, 1.0], [0.8, 2.0]]
@@ -74,7 +83,7 @@ def test_fill_kernel_regimes(res, bounds, K):
     eng.close()
 
 
-def test_phik_anchor_from_reference(anchors):
+def test_phik_anchor_from_reference(anchors, rebuild_impl):
     a = anchors["phik_K10_121x61_trans0"]
     eng = _engine(a["num_basis"], a["resolution"])
     eng.set_target_gaussians(a["means"], a["sigmas"])
@@ -107,7 +116,7 @@ def test_rebuild_rule():
 
 
 @pytest.mark.parametrize("K,bounds", [(10, (-1.0, 11.0, -1.0, 5.0)), (20, (0.0, 25.5, 0.0, 25.5))])
-def test_rebuild_enqueued_only(K, bounds):
+def test_rebuild_enqueued_only(K, bounds, rebuild_impl):
     """eea_config_domain_async: the rebuild is only enqueued.  Control calls on the SAME stream are ordered by the
     stream, control calls on ANOTHER stream are made to wait by the engine, the getters wait: phi_k and the controls
     are bitwise those of the synchronous form."""

@@ -50,12 +50,15 @@ def main():
         if bench is not None and disp:
             disp.sort()
             G = int(bench["config"]["agent_groups"])
-            n_timed = int(bench["steps"]) * int(bench["config"]["passes_per_step"]) * G
-            timed = disp[-n_timed:]
+            SPL = int(bench["config"].get("steps_per_launch", 1))   # receding-horizon steps (passes) per launch
+            # the shard leg is followed by the short one-launch-per-pass leg (3 + 1 steps of 400 passes) when SPL > 1
+            tail = (3 + 1) * 400 * G if SPL > 1 else 0
+            n_timed = int(bench["steps"]) * int(bench["config"]["passes_per_step"]) // SPL * G
+            timed = disp[-(n_timed + tail):len(disp) - tail] if tail else disp[-n_timed:]
             dur = [e - s for s, e in timed]
             avg_ns = sum(dur) / len(dur)
             span_ns = max(e for _, e in timed) - min(s for s, _ in timed)
-            passes = n_timed // G
+            passes = n_timed // G * SPL
             tr = {"dispatches_timed_region": len(timed), "dispatches_total": len(disp), "concurrent_launches": G,
                   "agents_per_launch": bench["roofline"]["agents_per_launch"],
                   "kernel_avg_us_timed_region": avg_ns * 1e-3,
@@ -65,7 +68,12 @@ def main():
                   "bench_launch_ms_same_run": bench["roofline"]["launch_ms"],
                   "flops_per_launch": bench["roofline"]["flops_per_launch"]}
             # launches_per_pass x avg / concurrent launches = pass period the kernel durations alone would give
-            tr["pass_us_from_kernel_avg"] = tr["kernel_avg_us_timed_region"] * G / G
+            tr["steps_per_launch"] = SPL
+            tr["pass_us_from_kernel_avg"] = tr["kernel_avg_us_timed_region"] / SPL
+            if tail:
+                single = disp[-(3 * 400 * G):]   # the timed part of the one-launch-per-pass leg
+                tr["single_launch_kernel_avg_us"] = sum(e - s for s, e in single) / len(single) * 1e-3
+                tr["single_launch_pass_period_us_from_trace"] = (max(e for _, e in single) - min(s for s, _ in single)) * 1e-3 / (3 * 400)
             tr["tflops_from_kernel_avg"] = G * tr["flops_per_launch"] / (avg_ns * 1e-9) / 1e12
             tr["frac_of_78.6_from_kernel_avg"] = tr["tflops_from_kernel_avg"] / 78.6
             tr["frac_same_run_bench_line"] = bench["roofline"]["frac"]
