@@ -257,8 +257,6 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
   // Every step starts from the thread id alone, through a value the optimiser cannot see through: nothing lane- or
   // agent-derived (step maps, LDS addresses, masks, pointers) is carried across the loop -- hoisted, those invariants
   // cost the body ~460 B of scratch per lane; recomputed they cost what they cost a launch.
-  EEA_WSTAMP_RT(10);
-  EEA_WSTAMP_HWID(12);
   typedef const __attribute__((address_space(4))) ControlParams<R> KernArgParams;
   const int n_steps = ((KernArgParams*)__builtin_amdgcn_kernarg_segment_ptr())->n_steps;
   for (int step = 0; step < n_steps; ++step) {
@@ -273,6 +271,8 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
   const int wv = __builtin_amdgcn_readfirstlane(tid_opaque / kWave);
   const unsigned b = blockIdx.x * WPB + wv;
   if (b >= B) return;  // wavefront-uniform
+  EEA_WSTAMP_RT(10);
+  EEA_WSTAMP_HWID(12);
 
   const int T = p.T;
   // kGenericK: any K <= 16 at run time (modes beyond K are masked to zero).  kRowGuard: the rows of the gradient
@@ -1440,8 +1440,8 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     lds_fence();
   }
-  }  // step
   EEA_WSTAMP_RT(11);
+  }  // step
 }
 
 }  // namespace wave

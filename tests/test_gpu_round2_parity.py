@@ -387,6 +387,61 @@ def test_consensus_pass_device_bound_exchange(lag, rccl, K, horizon):
     eng.close()
 
 
+def test_consensus_loop_needs_no_host_cores():
+    """the per-pass consensus loop must not depend on spinning host threads.  The device-bound
+    exchange has none (the calling thread issues three launches per pass and waits for nothing), so the whole loop --
+    4096 agents, two groups, lag 1, 300 passes -- is run in a child process pinned to ONE CPU (sched_setaffinity before
+    anything else starts, inherited by every runtime thread): it must finish, with no agent timed out, at a pass time of
+    the same order as unpinned."""
+    code = r"""
+import os, sys, time
+os.sched_setaffinity(0, {sorted(os.sched_getaffinity(0))[0]})
+sys.path.insert(0, %r)
+import numpy as np, torch
+from ergodic_exploration_amd import capi
+from tests.gpu_util import make_pair, random_poses
+rng = np.random.default_rng(5)
+B, G, NB, passes, lag = 4096, 2, 4, 300, 1
+eng, _ = make_pair("simple_cart", 10, 20.0, n_oracles=0)
+T, L = eng.T, eng.ck_record_len
+d_pose = torch.as_tensor(random_poses(rng, B)).cuda()
+ut = torch.zeros((B, T, 3), dtype=torch.float64, device="cuda")
+u0 = torch.empty((B, 3), dtype=torch.float64, device="cuda")
+arecs = [torch.zeros((B, L), dtype=torch.float64, device="cuda") for _ in range(NB)]
+sums = [torch.zeros((L,), dtype=torch.float64, device="cuda") for _ in range(NB)]
+ready = torch.zeros((B,), dtype=torch.int32, device="cuda")
+flag = torch.zeros((1,), dtype=torch.int32, device="cuda")
+status = torch.zeros((B,), dtype=torch.int32, device="cuda")
+comm = capi.Comm(0, 1, 0, None)
+streams = [torch.cuda.Stream() for _ in range(G)]
+gb = [0, B // 2, B]
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(passes):
+    seq, slot = i + 1, i %% NB
+    src = (i - lag) %% NB if i >= lag else None
+    for g in range(G):
+        sl = slice(gb[g], gb[g + 1])
+        eng.control_batch(gb[g + 1] - gb[g], d_pose[sl], ut[sl], u0[sl], ck_rec=arecs[slot][sl], rec_ready=ready[sl],
+                          rec_seq=seq, status=status[sl], ck_shared=None if src is None else sums[src],
+                          ck_shared_parts=0 if src is None else 1, ck_flag=None if src is None else flag,
+                          ck_flag_seq=seq - lag, stream=streams[g].cuda_stream)
+    comm.records_exchange_bound(eng, B, arecs[slot], ready, seq, sums[slot], flag, slot)
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print("PINNED_OK cpus=%%d us_per_pass=%%.1f timeouts=%%d flag=%%d" %% (len(os.sched_getaffinity(0)), 1e6 * dt / passes,
+      int((status != 0).sum().item()), int(flag.item())))
+""" % ROOT
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    line = [l for l in r.stdout.splitlines() if l.startswith("PINNED_OK")][-1]
+    fields = dict(kv.split("=") for kv in line.split()[1:])
+    assert int(fields["cpus"]) == 1 and int(fields["timeouts"]) == 0 and int(fields["flag"]) == 300
+    assert float(fields["us_per_pass"]) < 500.0   # (host-bound through per-pass Python struct building; the point is: it finishes)
+    if os.environ.get("EEA_PRINT_WORST"):
+        print("consensus loop pinned to one CPU:", line)
+
+
 def test_device_bound_exchange_times_out_instead_of_hanging():
     """A consumer whose flag never arrives, and a record sum whose producers never report, give up after tens of
     milliseconds: per-agent EEA_ERR_TIMEOUT, the agent's OWN c_k in the gradient (bitwise the call without a shared c_k);

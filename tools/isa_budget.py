@@ -12,7 +12,7 @@ walks the executed path:
     workload runs (both fast paths on, no rejected agent).
 Phases are delimited by the stamps' s_memtime instructions.  The totals are checked against the hardware counters of
 the real kernel (SQ_INSTS_VALU etc., profiles/r03_*_summary.txt) by the caller.
-Usage: python tools/isa_budget.py [--keep /tmp/budget.s]
+Usage: python tools/isa_budget.py [--case metric|k20f32|k20f64] [--keep /tmp/budget.s]
 """
 import collections
 import os
@@ -27,13 +27,28 @@ PHASES = ["load + shift controls", "heading increments + scan", "heading sin/cos
           "co-state scans", "update + store"]
 
 
+CASES = {
+    # name: (real type, model id, K, T, kernel symbol prefix, lean, WPB, label)
+    "metric": ("double", 1, 10, 200, "_ZN3eea4wave24control_wave_kernel_leanIdLi1ELi10ELb0ELi4E", True, 4,
+               "fp64, SimpleCart, K = 10, T = 200"),
+    "k20f32": ("float", 0, 20, 250, "_ZN3eea4wave19control_wave_kernelIfLi0ELi20ELb0ELi4E", False, 4,
+               "fp32, Omni, K = 20, T = 250 (BASELINE configs[2])"),
+    "k20f64": ("double", 0, 20, 250, "_ZN3eea4wave19control_wave_kernelIdLi0ELi20ELb0ELi1E", False, 1,
+               "fp64, Omni, K = 20, T = 250 (configs[2] fp64 twin)"),
+}
+
+
 def classify(ins):
     op = ins.split()[0]
     if op.startswith("v_mfma"):
         return "mfma"
-    if op in ("v_fma_f64", "v_fmac_f64_e32", "v_fmac_f64_e64", "v_fmac_f64"):
+    if op.startswith("v_pk_fma_f32"):
+        return "v_pkfma32"
+    if op in ("v_fma_f64", "v_fmac_f64_e32", "v_fmac_f64_e64", "v_fmac_f64", "v_fma_f32", "v_fmac_f32_e32", "v_fmac_f32_e64",
+              "v_fmac_f32", "v_fmac_f32_dpp", "v_fmac_f64_dpp"):
         return "v_fma64"
-    if op.startswith("v_mul_f64") or op.startswith("v_add_f64"):
+    if (op.startswith("v_mul_f64") or op.startswith("v_add_f64") or op.startswith("v_mul_f32") or op.startswith("v_add_f32")
+            or op.startswith("v_sub_f32") or op.startswith("v_pk_mul_f32") or op.startswith("v_pk_add_f32")):
         return "v_muladd64"
     if op.startswith("v_"):
         return "v_other"
@@ -52,29 +67,46 @@ def classify(ins):
 
 def main():
     keep = sys.argv[sys.argv.index("--keep") + 1] if "--keep" in sys.argv else None
+    case = sys.argv[sys.argv.index("--case") + 1] if "--case" in sys.argv else "metric"
+    real, model, KC, TC, symbol, lean, wpb, label = CASES[case]
     tmp = tempfile.mkdtemp()
     out = keep or os.path.join(tmp, "budget.s")
     csrc = os.path.join(ROOT, "ergodic_exploration_amd", "csrc")
-    # the kernel text with the metric point's shape as compile-time constants
+    # the kernel text with the case's shape as compile-time constants (one receding-horizon step per launch)
     text = open(os.path.join(csrc, "control_wave_impl.hpp")).read()
-    subs = [("const ControlParams<R> p, const unsigned B, const int S, const int rollout_only)\n{\n",
-             "const ControlParams<R> p_in, const unsigned B, const int S_in, const int rollout_in)\n{\n"
-             "  ControlParams<R> p = p_in;\n  p.mem_cols = nullptr;\n  p.n_mem = nullptr;\n  p.mem_stride = 0;\n"
-             "  p.traj = p.edx = p.bdx = p.rhot = nullptr;\n  p.ck = nullptr;\n  p.ck_rec = nullptr;\n"
-             "  p.ck_shared = nullptr;\n  p.ck_shared_parts = 0;\n  p.done = nullptr;\n  p.K = 10;\n"
-             "  constexpr int S = 4;\n  constexpr int rollout_only = 0;\n"),
-            ("  const int T = p.T;\n", "  constexpr int T = 200;\n")]
+    subs = [("    const ControlParams<R> p_arg, const unsigned B, const int S, const int rollout_only)\n{\n"
+             "  (void)p_arg;  // read through the kernel-argument segment below\n",
+             "    const ControlParams<R> p_arg, const unsigned B, const int S_in, const int rollout_in)\n{\n"
+             "  constexpr int S = %d;\n  constexpr int rollout_only = 0;\n" % ((TC + 63) // 64)),
+            ("  const int n_steps = ((KernArgParams*)__builtin_amdgcn_kernarg_segment_ptr())->n_steps;\n",
+             "  constexpr int n_steps = 1;\n"),
+            ("  KernArgParams* ka = (KernArgParams*)__builtin_amdgcn_kernarg_segment_ptr();  // p_arg is argument 0\n"
+             "  asm volatile(\"\" : \"+s\"(ka));\n  KernArgParams& p = *ka;\n",
+             "  ControlParams<R> p = p_arg;\n  p.mem_cols = nullptr;\n  p.n_mem = nullptr;\n  p.mem_stride = 0;\n"
+             "  p.traj = p.edx = p.bdx = p.rhot = nullptr;\n  p.ck = nullptr;\n  p.ck_rec = nullptr;\n  p.rec_ready = nullptr;\n"
+             "  p.ck_shared = nullptr;\n  p.ck_shared_parts = 0;\n  p.ck_flag = nullptr;\n  p.done = nullptr;\n  p.K = %d;\n"
+             "  p.pose_step_stride = p.u0_step_stride = 0;\n" % KC),
+            ("  const int T = p.T;\n", "  constexpr int T = %d;\n" % TC)]
     for a, b in subs:
         assert text.count(a) == 1, a
         text = text.replace(a, b)
     with open(os.path.join(tmp, "budget_impl.hpp"), "w") as f:
         f.write(text)
+    unit = os.path.join(tmp, "budget_unit.hip")
+    with open(unit, "w") as f:
+        if lean:
+            f.write("#define EEA_WAVE_KERNEL_NAME control_wave_kernel_lean\n#define EEA_WAVE_KERNEL_ATTR __attribute__((amdgpu_num_vgpr(60)))\n"
+                    "#define EEA_WAVE_KERNEL_LEAN true\n")
+        f.write('#include "budget_impl.hpp"\nnamespace eea {\ntemplate __global__ void wave::%s<%s, %d, %d, false, %d>('
+                "const ControlParams<%s>, const unsigned, const int, const int);\n}\n"
+                % ("control_wave_kernel_lean" if lean else "control_wave_kernel", real, model, KC, wpb, real))
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-fno-slp-vectorize",
+           "-mllvm", "-disable-machine-licm",
            "-I", tmp, "-I", csrc, "-include", os.path.join(ROOT, "tools", "ab", "wave_stamps.hpp"), "-S", "--cuda-device-only",
-           "-o", out, os.path.join(ROOT, "tools", "ab", "budget_kernel.hip")]
+           "-o", out, unit]
     subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
     src = open(out).read().split("\n")
-    start = next(i for i, l in enumerate(src) if re.match(r"^_ZN3eea4wave24control_wave_kernel_leanIdLi1ELi10ELb0ELi4E.*:", l))
+    start = next(i for i, l in enumerate(src) if re.match(r"^" + symbol + r".*:", l))
     end = next(i for i, l in enumerate(src) if l.startswith(".Lfunc_end") and i > start)
     blocks, order, cur = {}, [], "entry"
     blocks[cur] = []
@@ -142,8 +174,9 @@ def main():
     walk("entry", 0, collections.Counter(), -1, [], [])
     assert best["cost"] is not None, "no complete path found"
     counts = best["counts"]
-    classes = ["v_fma64", "v_muladd64", "v_other", "mfma", "lds", "vmem", "salu", "smem", "wait"]
-    print("static instruction budget per wavefront (= agent): fp64, SimpleCart, K = 10, T = 200, S = 4, no replay memory")
+    classes = ["v_fma64", "v_pkfma32", "v_muladd64", "v_other", "mfma", "lds", "vmem", "salu", "smem", "wait"]
+    print("static instruction budget per wavefront (= agent): %s, S = %d, no replay memory, one step per launch" % (label, (TC + 63) // 64))
+    print("(columns: v_fma64 = scalar FMA of the kernel's type, v_pkfma32 = packed fp32 FMA (2 per lane), v_muladd64 = mul / add)")
     print("(wavefront-uniform decisions on the counted path: %s)" % "; ".join(
         "%s %s -> %s %s" % d for d in best["decisions"]))
     print("%-52s" % "phase" + "".join("%11s" % c for c in classes) + "%11s" % "VALU all")
@@ -153,24 +186,26 @@ def main():
         if not any(row):
             continue
         name = "prologue (kernel arguments, lane -> steps)" if ph < 0 else (PHASES[ph] if ph < len(PHASES) else "epilogue")
-        valu = sum(counts.get((ph, c), 0) for c in ("v_fma64", "v_muladd64", "v_other"))
+        valu = sum(counts.get((ph, c), 0) for c in ("v_fma64", "v_pkfma32", "v_muladd64", "v_other"))
         print("%-52s" % name + "".join("%11d" % v for v in row) + "%11d" % valu)
         for c, v in zip(classes, row):
             tot[c] += v
-    valu = tot["v_fma64"] + tot["v_muladd64"] + tot["v_other"]
+    valu = tot["v_fma64"] + tot["v_pkfma32"] + tot["v_muladd64"] + tot["v_other"]
     print("%-52s" % "total" + "".join("%11d" % tot[c] for c in classes) + "%11d" % valu)
     print()
-    print("vector-pipe cycles per agent: %d VALU x 4 + %d MFMA (4x4x4, 16 cycles each) x 16 = %d"
-          % (valu, tot["mfma"], 4 * valu + 16 * tot["mfma"]))
+    # pipe time: fp64 16x16x4 64 cycles, fp64 4x4x4(4b) 16, fp32 16x16x4 32 (8 passes x 4)
+    mf = sum(v for (ph, c), v in counts.items() if c == "mfma")
+    mf_cycles = 16 if case == "metric" else (32 if real == "float" else 64)
+    print("vector-pipe cycles per agent: %d VALU x 4 + %d MFMA x %d = %d" % (valu, mf, mf_cycles, 4 * valu + mf_cycles * mf))
     # the reference formulation's work at this shape: W = 2 K^2 N + 4 K^2 T + (4 K + 140) T flop
-    K, T = 10, 200
+    K, T = KC, TC
     W = 2 * K * K * T + 4 * K * K * T + (4 * K + 140) * T
-    print("reference-formulation work W = %d flop = %d fp64 multiply-adds = %.0f full 64-lane instructions; issued: %d "
-          "fp64 FMA + %d fp64 mul/add + %d other vector + %d x 64 (MFMA: 256 multiply-adds per lane-group of 64) "
-          % (W, W // 2, W / 2 / 64, tot["v_fma64"], tot["v_muladd64"], tot["v_other"], tot["mfma"]))
-    print("lanes at T = 200: lanes 0..7 own 4 steps, lanes 8..63 three: the per-step instructions of slots 0..2 run on full "
-          "wavefronts, those of the last slot on 8 lanes -- except its gradient, which all 64 lanes take together "
-          "(8 lanes per step); 200 of 256 lane-steps carry a step (78 %)")
+    print("reference-formulation work W = %d flop = %d multiply-adds = %.0f full 64-lane instructions; issued: %d FMA + %d "
+          "packed fp32 FMA + %d mul/add + %d other vector + %d MFMA"
+          % (W, W // 2, W / 2 / 64, tot["v_fma64"], tot["v_pkfma32"], tot["v_muladd64"], tot["v_other"], tot["mfma"]))
+    peak_note = ("fp32 vector peak 157.3 TF counts 2 multiply-adds per lane and cycle-slot (v_pk_fma_f32): a scalar fp32 FMA uses "
+                 "half of it" if real == "float" else "fp64 vector peak 78.6 TF = one FMA per lane and 4-cycle issue")
+    print(peak_note)
 
 
 if __name__ == "__main__":
