@@ -751,17 +751,17 @@ def main():
         hbm_gbs = G * bytes_per_opt * Bl / launch_s / 1e9
         tflops = G * flops_per_opt * Bl / launch_s / 1e12
         traffic, traffic_source = None, None
-        for name in ("r04_control_pmc.json", "r03_control_pmc.json"):
+        for name in ("r04_control_pmc.json", "r04_control_pmc_spl1.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(pmc):
                 continue
             try:
                 with open(pmc) as f:
                     rec = json.load(f)
-                if (rec.get("agents") == B and rec.get("T") == T and rec.get("K") == K
-                        and rec.get("precision") == args.precision):
-                    traffic = rec.get("hbm_bytes_per_launch") * Bl / B  # per launch of Bl of the B agents
-                    traffic_source = ("profiles/%s (separate rocprofv3 --pmc passes of this command; NOT measured "
+                if (rec.get("T") == T and rec.get("K") == K and rec.get("precision") == args.precision
+                        and rec.get("steps_per_launch", 1) == SPL and args.model == "simple_cart" and not args.n_mem):
+                    traffic = rec.get("hbm_bytes_per_launch") * Bl / rec["agents_per_launch"]  # per launch of Bl agents x SPL steps
+                    traffic_source = ("profiles/%s (separate rocprofv3 --pmc passes of this command shape; NOT measured "
                                       "in this run)" % name)
                     break
             except Exception:

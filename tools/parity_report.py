@@ -35,6 +35,17 @@ for model in ("simple_cart", "omni"):
 t2.test_config4_full_size_f32_against_f64_oracle()
 print("BASELINE config 5 end to end (1024^2 occupancy -> phi_k K=30 -> control T=500)")
 t2.test_config5_end_to_end_against_oracle()
+print("round 4: the TIMED instances (no stage outputs: the lean fp64 K <= 10 instance etc.) against the oracle, c_k / ut / u0")
+from tests import test_gpu_timed_instances as tt  # noqa: E402
+for model, K, hor, dt, n_mem in CASES[:6] + [("omni", 10, 19.3, 0.1, 40), ("simple_cart", 10, 19.9, 0.1, 0)]:
+    t.run_batch_vs_oracle(model, K, hor, dt, B=4, n_mem=n_mem, calls=2, seed=21, stages=False)
+for prec, name, tol, tck in ((capi.PREC_F64, "f64", 1e-9, 1e-11), (capi.PREC_F32, "f32", 5e-4, 1e-5)):
+    t.run_batch_vs_oracle("omni", 20, 5.0, 0.02, B=2, n_mem=0, calls=2, seed=3, bounds=bounds, means=means,
+                          sigmas=sigmas, precision=prec, tol=tol, tol_ck=tck, stages=False)
+print("round 4: the consensus leg's exact form (no stages, d_ck_rec out, one sum record in) against the oracle's shared-c_k switch")
+for args in (("simple_cart", 10, 20.0, 0, 1), ("omni", 10, 19.7, 40, 2), ("omni", 5, 19.3, 0, 1), ("omni", 20, 5.0, 0, 1),
+             ("omni", 30, 6.0, 0, 1)):
+    tt.test_consensus_leg_exact_form_against_oracle(*args)
 for dt in (1.0, 2.0):
     print("large step increments dt=%g (bars relative to max(1, |stage|))" % dt)
     t.test_small_and_large_step_increments(dt)

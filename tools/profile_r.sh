@@ -7,16 +7,17 @@ TAG=${1:-r03}; shift || true
 OUT=gpurun_out/prof_${TAG}
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-LEGS="--cpu-seconds 0 --no-latency --no-exchange --no-phik --no-grid-tile"
+LEGS="--cpu-seconds 0 --no-latency --no-exchange --no-phik --no-grid-tile --no-other-configs"
 # 1) kernel trace + stats on the default shape: 1000 spin-up passes + 1 warm-up step + 3 timed steps of 1000 passes.
+#    (steps per launch as the default: 50; pass --steps-per-launch 1 for the one-launch-per-pass shape)
 #    tools/summarize_prof.py takes the average over the dispatches of the TIMED region only (the last steps x passes x
 #    groups control dispatches) and compares it with the ms_per_pass the same run printed
-TRACE_BENCH="python3 bench.py --steps 3 --warmup 1 --passes-per-step 1000 $LEGS $*"
+TRACE_BENCH="python3 bench.py --steps 3 --warmup 1 --passes-per-step 2000 $LEGS $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace -- $TRACE_BENCH > "$OUT/trace.log" 2>&1
 # 2) PMC passes, each in its own run (FETCH_SIZE and WRITE_SIZE do not fit one pass); counter collection serialises
 #    the dispatches, so these runs are short and skip the spin-up
 export EEA_BENCH_SPINUP_PASSES=0
-PMC_BENCH="python3 bench.py --steps 2 --warmup 1 --passes-per-step 20 $LEGS $*"
+PMC_BENCH="python3 bench.py --steps 2 --warmup 1 --passes-per-step 100 $LEGS $*"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex control_ --output-format csv -d "$OUT/pmc_fetch" -o pmc -- $PMC_BENCH > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex control_ --output-format csv -d "$OUT/pmc_write" -o pmc -- $PMC_BENCH > "$OUT/pmc_write.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY --kernel-include-regex control_ --output-format csv -d "$OUT/pmc_sq1" -o pmc -- $PMC_BENCH > "$OUT/pmc_sq1.log" 2>&1
