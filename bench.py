@@ -69,6 +69,9 @@ def parse():
                     help="the consensus leg is timed once per lag: pass i consumes the c_bar of pass i - lag.  Lag 1 is the "
                          "previous step's consensus (decentralised ergodic control); the exchange is device-bound "
                          "(eea_comm_records_exchange_bound): no host wait, no stream wait, no host thread at any lag")
+    ap.add_argument("--consensus-steps-per-launch", type=int, default=1,
+                    help="receding-horizon steps per control launch of the consensus leg (the exchange slots then rotate "
+                         "inside the launch, eea_batch_io::exch_slots)")
     ap.add_argument("--consensus-buffers", type=int, default=8, choices=range(3, 9),
                     help="record / sum buffers (and exchange slots) the consensus leg rotates through")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per leg; 0 = skip")
@@ -499,8 +502,10 @@ def main():
     d_flag = torch.zeros((1,), dtype=torch.int32, device="cuda")    # ... and the flag of the finished exchange (sequence numbers)
     d_xstatus = torch.zeros((B,), dtype=torch.int32, device="cuda")  # per-agent status of the consensus passes (timeouts)
     cstate = {"lag": LAGS[0], "seq0": 0}
-    d_arec = [torch.empty((B, L), dtype=tdt, device="cuda") for _ in range(NB)]   # per-agent records of a pass
-    d_rec = [torch.zeros((L,), dtype=tdt, device="cuda") for _ in range(NB)]      # their sum (over all ranks)
+    d_arec_all = torch.empty((NB, B, L), dtype=tdt, device="cuda")   # per-agent records of a pass, one slot per pass in flight
+    d_rec_all = torch.zeros((NB, L), dtype=tdt, device="cuda")       # their sum (over all ranks)
+    d_arec = [d_arec_all[s] for s in range(NB)]
+    d_rec = [d_rec_all[s] for s in range(NB)]
     ev_grp = [[torch.cuda.Event() for _ in range(G)] for _ in range(NB)]
     ev_x = [torch.cuda.Event() for _ in range(NB)]
     d_ck = [torch.empty((B, K2), dtype=tdt, device="cuda") for _ in range(3)]   # all-gather leg
@@ -604,6 +609,10 @@ def main():
     # eea_batch_io structs are built once per distinct buffer set, a pass is one ctypes call per group
     # receding-horizon steps per launch: the largest divisor of the passes per step that does not exceed the request
     SPL = max(d for d in range(1, max(1, args.steps_per_launch) + 1) if R % d == 0)
+    # steps per launch of the consensus leg: 1 by default -- with the consensus in the loop several steps per launch are
+    # no faster (28.5 against 26.8-27.9 us per pass: the groups of a multi-step launch run in lockstep, and the record sums
+    # of the steps ahead poll beside them), profiles/r04_exchange_cost.txt
+    SPLX = max(d for d in range(1, max(1, args.consensus_steps_per_launch) + 1) if RX % d == 0)
     shard_calls = [eng.prepared_batch(a["B"], a["pose"], a["ut"], a["u0"], mem_cols=a["mem_cols"], n_mem=a["n_mem"],
                                       mem_stride=args.n_mem, stream=a["stream"],
                                       n_steps=None if SPL == 1 else SPL) for a in gargs]
@@ -628,8 +637,28 @@ def main():
             slot = i % NB
             src = (i - lag) % NB if i >= lag else None
             seq = cstate["seq0"] + i + 1      # sequence numbers only grow (also from one timed() call to the next)
+            if not host_staged and SPLX > 1:
+                # device-bound AND SPLX steps per launch: G control launches of SPLX steps (step n: records to slot
+                # (slot + n) % NB, ready marks seq + n, waits for flag seq + n - lag), then one exchange call per step
+                if i % SPLX:
+                    return
+                for g, a in enumerate(gargs):
+                    call = exch_calls.get(("ms", g))
+                    if call is None:
+                        call = exch_calls[("ms", g)] = eng.prepared_batch(
+                            a["B"], a["pose"], a["ut"], a["u0"], mem_cols=a["mem_cols"], n_mem=a["n_mem"],
+                            mem_stride=args.n_mem, stream=a["stream"], ck_rec=d_arec_all[0][gb[g]:gb[g + 1]],
+                            rec_ready=d_ready[gb[g]:gb[g + 1]], status=d_xstatus[gb[g]:gb[g + 1]],
+                            ck_shared=d_rec_all[0], ck_shared_parts=1, ck_flag=d_flag, n_steps=SPLX,
+                            exch_slots=NB, rec_slot_stride=B * L, shared_slot_stride=L)
+                    call(seq, seq - lag, seq % NB)
+                for n in range(SPLX):
+                    exchange_records((seq + n) % NB, seq + n)
+                return
             if not host_staged:
                 # device-bound: G control launches (ready marks out, flag wait in) + ONE exchange call, nothing else
+                slot = seq % NB
+                src = (seq - lag) % NB if i >= lag else None
                 for g, a in enumerate(gargs):
                     call = exch_calls.get((g, slot, src))
                     if call is None:
@@ -695,6 +724,13 @@ def main():
         Rl = R if passes is None else passes
         if leg == "consensus":
             cstate["seq0"] += state["i"] + 8   # past every sequence number the previous consensus run used
+            if not host_staged:
+                # the first `lag` steps consume "nothing yet": zeroed sum records (agent count 0 = own c_k) behind a flag
+                # that already stands at the sequence number before the first
+                torch.cuda.synchronize()
+                d_rec_all.zero_()
+                d_flag.fill_(cstate["seq0"])
+                torch.cuda.synchronize()
         state["i"] = 0
         d_ut.zero_()      # on the compute stream ...
         fork_groups()     # ... and ordered before the first pass of every agent group
@@ -972,7 +1008,14 @@ def main():
                         "launch with an RCCL communicator), and pass i waits INSIDE its kernels, right before the first use "
                         "of c_bar, for the flag of pass i - lag; lag 1 = the previous step's consensus.  One launch per pass "
                         "and group (the headline runs %d steps per launch: pass_ms_vs_single_launch_pass is the like-for-"
-                        "like ratio)" % SPL}
+                        "like ratio)" % SPL if SPLX == 1 else
+                        "every pass: the control kernels write per-agent sum records and ready marks (write-through, half way "
+                        "through the wavefront), ONE launch per pass on the exchange stream polls the marks and adds the records "
+                        "beside the running control kernels (+ one all-reduce of the record over the ranks and a publish launch "
+                        "with an RCCL communicator), and step i waits INSIDE the kernel, right before the first use of c_bar, for "
+                        "the flag of step i - lag; lag 1 = the previous step's consensus.  %d receding-horizon steps per control "
+                        "launch, as the headline: the exchange slots rotate inside the launch (eea_batch_io::exch_slots)" % SPLX,
+                "steps_per_launch": SPLX}
             if use_dist or args.force_exchange:
                 d_all = [torch.empty((world * B, K2), dtype=tdt, device="cuda") for _ in range(2)]
                 e_s, p_ms, _ = timed("allgather", args.steps, args.warmup, passes=RX)

@@ -60,6 +60,12 @@ struct ControlParams
   unsigned rec_seq;
   const unsigned* ck_flag;
   unsigned ck_flag_seq;
+  // ... inside a multi-step launch (eea_batch_io::exch_slots > 1): step n writes its records to slot (exch_slot0 + n) %
+  // exch_slots of ck_rec (slots rec_slot_stride reals apart), marks them ready with rec_seq + n, and consumes the sum
+  // record of the slot lag = rec_seq - ck_flag_seq steps back (slots shared_slot_stride reals apart) behind flag
+  // ck_flag_seq + n; exch_slots <= 1: the same buffers every step
+  int exch_slots, exch_slot0;
+  unsigned long long rec_slot_stride, shared_slot_stride;
   R* edx;
   R* bdx;
   R* rhot;
@@ -369,14 +375,14 @@ __device__ __forceinline__ R load_agent(const R* q)
 }
 
 template <typename R, typename P>  // P: ControlParams<R>, possibly in the kernel-argument address space
-__device__ __forceinline__ R shared_ck_value(const P& p, int m, int K2, R own)
+__device__ __forceinline__ R shared_ck_value(const P& p, const R* shared, int m, int K2, R own)
 {
   // a buffer another kernel fills WHILE this one runs (device-bound exchange) is read past the L1
   const bool bound = p.ck_flag != nullptr;
-  if (p.ck_shared_parts <= 0) return bound ? load_agent(p.ck_shared + m) : p.ck_shared[m];
+  if (p.ck_shared_parts <= 0) return bound ? load_agent(shared + m) : shared[m];
   R s = R(0), n = R(0);
   for (int i = 0; i < p.ck_shared_parts; ++i) {
-    const R* const rec = p.ck_shared + static_cast<size_t>(i) * p.rec_len;
+    const R* const rec = shared + static_cast<size_t>(i) * p.rec_len;
     s += bound ? load_agent(rec + m) : rec[m];
     n += bound ? load_agent(rec + K2) : rec[K2];
   }

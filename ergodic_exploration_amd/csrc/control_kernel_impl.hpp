@@ -680,7 +680,7 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
     for (int m = tid; m < K2; m += BLK) {
       R c = s_D[m];
       // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
-      if (use_shared) c = shared_ck_value(p, m, K2, c);
+      if (use_shared) c = shared_ck_value(p, p.ck_shared, m, K2, c);
       // fourier_diff = lamdak % (ck - phik)  (ergodic_control.hpp:422)
       const R lam = (m == tid) ? lam_m : p.lamdak[m];
       const R phi = (m == tid) ? phi_m : p.phik[m];

@@ -315,6 +315,17 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
   auto cnt_of = [&](int l) { return l < q16 ? S : max(0, min(sc, rem - sc * (l - q16))); };
   R* const ut = p.ut + 3 * static_cast<size_t>(T) * b;
   const R* const pose = p.pose + 3 * (static_cast<size_t>(step) * p.pose_step_stride + b);
+  // device-bound exchange inside a multi-step launch: this step's record slot, the slot it consumes, its sequence numbers
+  R* ck_rec_step = p.ck_rec;
+  const R* ck_shared_step = p.ck_shared;
+  const unsigned rec_seq_step = p.rec_seq + static_cast<unsigned>(step);
+  const unsigned flag_seq_step = p.ck_flag_seq + static_cast<unsigned>(step);
+  if (p.exch_slots > 1) {  // wavefront-uniform
+    const int slots = p.exch_slots, sl = (p.exch_slot0 + step) % slots;
+    const int lag = static_cast<int>(p.rec_seq - p.ck_flag_seq) % slots;
+    if (ck_rec_step != nullptr) ck_rec_step += static_cast<size_t>(sl) * p.rec_slot_stride;
+    if (ck_shared_step != nullptr) ck_shared_step += static_cast<size_t>((sl - lag + slots) % slots) * p.shared_slot_stride;
+  }
   EEA_WSTAMP(0);
   // ---- controls: shift left by one column, last column zero (ergodic_control.hpp:233-234) ------------
   R vx[kMaxS], vy[kMaxS], w[kMaxS];
@@ -338,15 +349,15 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
   constexpr int kRecRounds = (ck_record_len((KC == 16 ? 16 : KC) * (KC == 16 ? 16 : KC)) + kWave - 1) / kWave;
   if (__any(bad)) {
     // the reference throws out of rk4_.solve; nothing else of this agent is touched
-    if (p.ck_rec != nullptr && !rollout_only) {  // it does not count in the sum of the records: all-zero record
+    if (ck_rec_step != nullptr && !rollout_only) {  // it does not count in the sum of the records: all-zero record
 #pragma unroll
       for (int r = 0; r < kRecRounds; ++r) {
         const int e = kWave * r + lane;
-        if (e < p.rec_len) store_agent(p.ck_rec + static_cast<size_t>(b) * p.rec_len + e, R(0));
+        if (e < p.rec_len) store_agent(ck_rec_step + static_cast<size_t>(b) * p.rec_len + e, R(0));
       }
       if (p.rec_ready != nullptr) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane == 0) store_agent(p.rec_ready + b, p.rec_seq);
+        if (lane == 0) store_agent(p.rec_ready + b, rec_seq_step);
       }
     }
     if (lane == 0 && p.status != nullptr) p.status[b] = 2;  // EEA_ERR_INVALID_TWIST
@@ -903,7 +914,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
       if (p.rec_len > K2 + 1) s_D[K2 + 1] = R(0);
     }
     lds_fence();
-    R* const rec = p.ck_rec + static_cast<size_t>(b) * p.rec_len;
+    R* const rec = ck_rec_step + static_cast<size_t>(b) * p.rec_len;
     if (p.rec_ready != nullptr) {
       // device-bound exchange: the record leaves write-through, and once it has left the agent's ready mark follows
       // (MI355X_MICROARCH.md: sc1 payload -> s_waitcnt vmcnt(0) -> sc1 flag); the record sum polls the marks
@@ -913,7 +924,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
         if (e < p.rec_len) store_agent(rec + e, s_D[e]);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) store_agent(p.rec_ready + b, p.rec_seq);
+      if (lane == 0) store_agent(p.rec_ready + b, rec_seq_step);
     } else {
 #pragma unroll
       for (int r = 0; r < kRecRounds; ++r) {
@@ -926,11 +937,11 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
   // device-bound exchange, consumer side: the shared c_k this step consumes may still be on its way -- wait for its flag
   // here, as late as possible (the first use of c_bar is D).  On a timeout the agent goes on with its own c_k and says so
   auto bind_shared_ck = [&]() -> bool {  // true: the shared c_k replaces the own one
-    if (p.ck_shared == nullptr) return false;
+    if (ck_shared_step == nullptr) return false;
     if (p.ck_flag == nullptr) return true;  // wavefront-uniform
-    bool ok = wait_flag(p.ck_flag, p.ck_flag_seq);
+    bool ok = wait_flag(p.ck_flag, flag_seq_step);
     // a producer that gave up marks its record with a negative agent count
-    if (ok && p.ck_shared_parts > 0) ok = !(load_agent(p.ck_shared + K2) < R(0));
+    if (ok && p.ck_shared_parts > 0) ok = !(load_agent(ck_shared_step + K2) < R(0));
     if (!ok && lane == 0 && p.status != nullptr) p.status[b] = 6;  // EEA_ERR_TIMEOUT
     return ok;
   };
@@ -970,7 +981,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
       cv[t] = invN * v;
       if (p.ck != nullptr && okv[t]) p.ck[static_cast<size_t>(b) * K2 + idx[t]] = cv[t];
     }
-    if (p.ck_rec != nullptr) {  // wavefront-uniform: this agent's record [c_k, 1, pad] through LDS, coalesced
+    if (ck_rec_step != nullptr) {  // wavefront-uniform: this agent's record [c_k, 1, pad] through LDS, coalesced
 #pragma unroll
       for (int t = 0; t < TS; ++t) {
         if (okv[t]) s_D[idx[t]] = cv[t];
@@ -981,7 +992,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
 #pragma unroll
     for (int t = 0; t < TS; ++t) {
       // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
-      if (use_shared) cv[t] = shared_ck_value(p, idx[t], K2, cv[t]);
+      if (use_shared) cv[t] = shared_ck_value(p, ck_shared_step, idx[t], K2, cv[t]);
       if (okv[t]) s_D[idx[t]] = lamv[t] * (cv[t] - phiv[t]);
     }
     lds_fence();
@@ -998,11 +1009,11 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
         if (k1 < K && k2 < K) {
           const R c = invN * (*accs[t])[r];
           if (p.ck != nullptr) p.ck[static_cast<size_t>(b) * K2 + k2 * K + k1] = c;
-          if (p.ck_rec != nullptr) s_D[k2 * K + k1] = c;
+          if (ck_rec_step != nullptr) s_D[k2 * K + k1] = c;
         }
       }
     }
-    if (p.ck_rec != nullptr) publish_record();  // wavefront-uniform
+    if (ck_rec_step != nullptr) publish_record();  // wavefront-uniform
     const bool use_shared = bind_shared_ck();
 #pragma unroll
     for (int t = 0; t < NT * NT; ++t) {
@@ -1013,7 +1024,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
         if (k1 < K && k2 < K) {
           R c = invN * (*accs[t])[r];
           // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
-          if (use_shared) c = shared_ck_value(p, k2 * K + k1, K2, c);
+          if (use_shared) c = shared_ck_value(p, ck_shared_step, k2 * K + k1, K2, c);
           s_D[k2 * K + k1] = lam[t][r] * (c - phi[t][r]);
         }
       }

@@ -122,6 +122,7 @@ struct eea_engine
   std::vector<std::unique_ptr<SumWs>> sum_ws;  // (pointers: a workspace in use must not move when the list grows)
   std::mutex sum_mutex;
   unsigned long sum_clock = 0;
+  std::vector<void*> retired;  // device buffers replaced while launches may still use them: freed with the engine
 
   // single-agent path
   hipStream_t stream1 = nullptr;
@@ -506,8 +507,7 @@ void fill_params(const eea_engine* e, eea::ControlParams<R>& p)
 // workspace of the sum written to `key` for up to B records.  One per distinct output buffer (concurrent sums on
 // several streams must not share tickets), found under the engine's lock (the header allows concurrent calls with
 // distinct d_sum buffers); at most kMaxSumWs of them -- a caller that passes a fresh output buffer every call recycles
-// the least recently used workspace instead of growing the list.  (Re)allocation synchronises the device once; the
-// tickets are zeroed on the launch stream.
+// the least recently used workspace instead of growing the list.  The tickets are zeroed on the launch stream.
 constexpr size_t kMaxSumWs = 32;
 template <typename R>
 eea_status sum_workspace(eea_engine* e, const void* key, unsigned B, hipStream_t s, eea_engine::SumWs** out)
@@ -534,14 +534,23 @@ eea_status sum_workspace(eea_engine* e, const void* key, unsigned B, hipStream_t
   w->last_use = ++e->sum_clock;
   const size_t need_ws = sizeof(R) * eea::ck_sum_ws_elems(B, e->K2);
   const size_t need_ctr = sizeof(unsigned) * eea::ck_sum_tickets(B, e->K2);
-  if (need_ws > w->ws.cap || need_ctr > w->ctr.cap) {
-    EEA_HIP(hipDeviceSynchronize());  // an earlier launch may still use the buffers about to be replaced
+  if (need_ws > w->ws.cap || need_ctr > w->ctr.cap || recycled) {
+    // NO device synchronisation here: a control kernel that is already running may be waiting, inside the kernel, for
+    // the very sum this call is about to launch (device-bound exchange inside a multi-step launch) -- waiting for the
+    // device would wait for that kernel's time-out.  Buffers an earlier launch may still use are retired, not freed
+    // (released with the engine); a recycled workspace gets fresh buffers for the same reason.
+    if (e->retired.size() >= 128) {  // a caller that churns output buffers: pay ONE synchronisation per 64 recycled sums
+      EEA_HIP(hipDeviceSynchronize());
+      for (void* q : e->retired) (void)hipFree(q);
+      e->retired.clear();
+    }
+    if (w->ws.p != nullptr) e->retired.push_back(w->ws.p);
+    if (w->ctr.p != nullptr) e->retired.push_back(w->ctr.p);
+    w->ws = DevBuf();
+    w->ctr = DevBuf();
     EEA_HIP(w->ws.reserve(need_ws));
     EEA_HIP(w->ctr.reserve(need_ctr));
     EEA_HIP(hipMemsetAsync(w->ctr.p, 0, w->ctr.cap, s));  // the tickets reset themselves from here on
-  } else if (recycled) {
-    // (the tickets of a finished sum are back at zero; a recycled workspace may belong to a sum still in flight)
-    EEA_HIP(hipDeviceSynchronize());
   }
   *out = w;
   return EEA_OK;
@@ -572,6 +581,10 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
   p.rec_seq = io->rec_seq;
   p.ck_flag = io->d_ck_shared != nullptr ? io->d_ck_flag : nullptr;
   p.ck_flag_seq = io->ck_flag_seq;
+  p.exch_slots = static_cast<int>(io->exch_slots);
+  p.exch_slot0 = static_cast<int>(io->exch_slot0);
+  p.rec_slot_stride = io->rec_slot_stride;
+  p.shared_slot_stride = io->shared_slot_stride;
   p.edx = static_cast<R*>(io->d_edx);
   p.bdx = static_cast<R*>(io->d_bdx);
   p.rhot = static_cast<R*>(io->d_rhot);
@@ -596,9 +609,19 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
   }
   // the workgroup-per-agent kernel takes one step per launch: a multi-step call is that many launches on the stream
   p.n_steps = 1;
+  const int slots = static_cast<int>(io->exch_slots);
+  p.exch_slots = 0;
   for (unsigned n = 0; n < n_steps; ++n) {
     p.pose = static_cast<const R*>(io->d_pose) + 3 * static_cast<size_t>(n) * pose_step_stride;
     p.u0 = static_cast<R*>(io->d_u0) + 3 * static_cast<size_t>(n) * u0_step_stride;
+    p.rec_seq = io->rec_seq + n;
+    p.ck_flag_seq = io->ck_flag_seq + n;
+    if (slots > 1) {  // the per-step exchange slots of a multi-step call
+      const int sl = static_cast<int>((io->exch_slot0 + n) % io->exch_slots);
+      const int lag = static_cast<int>(io->rec_seq - io->ck_flag_seq) % slots;
+      if (io->d_ck_rec != nullptr && !rollout_only) p.ck_rec = static_cast<R*>(io->d_ck_rec) + static_cast<size_t>(sl) * io->rec_slot_stride;
+      if (io->d_ck_shared != nullptr) p.ck_shared = static_cast<const R*>(io->d_ck_shared) + static_cast<size_t>((sl - lag + slots) % slots) * io->shared_slot_stride;
+    }
     EEA_HIP(eea::launch_control<R>(p, B, e->cfg.model, n_mem_max, rollout_only, s));
   }
   return EEA_OK;
@@ -757,6 +780,7 @@ void eea_destroy(eea_engine* e)
     w->ws.release();
     w->ctr.release();
   }
+  for (void* q : e->retired) (void)hipFree(q);
   if (e->ev_done) (void)hipEventDestroy(e->ev_done);
   if (e->ev_rebuild) (void)hipEventDestroy(e->ev_rebuild);
   if (e->h_mail) (void)hipHostFree(e->h_mail);

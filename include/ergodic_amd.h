@@ -220,6 +220,15 @@ typedef struct {
                                         c_k.  The waiting wavefronts hold their execution slots: see
                                         eea_comm_records_exchange_bound for what must fit beside them             */
   unsigned ck_flag_seq;
+  /* ... inside eea_control_batch_steps (n_steps > 1): with exch_slots > 1, step n of the launch writes its records to
+   * d_ck_rec + ((exch_slot0 + n) % exch_slots) * rec_slot_stride reals, marks them ready with rec_seq + n, waits for
+   * ck_flag_seq + n and consumes d_ck_shared + (slot of step n - lag) * shared_slot_stride reals, lag = rec_seq - ck_flag_seq:
+   * a consensus on every step of a multi-step launch -- the host only issues one eea_comm_records_exchange_bound per step
+   * (sequence number rec_seq + n, the same slot), in any order relative to the control launch.  Before the first launch:
+   * *d_ck_flag = rec_seq - 1 of that launch and zeroed sum records (an agent count of 0 means "own c_k"), so that the
+   * first lag steps have something to consume.  exch_slots <= 1: the same buffers and numbers every step. */
+  unsigned exch_slots, exch_slot0;
+  size_t rec_slot_stride, shared_slot_stride;
 } eea_batch_io;
 
 /* length in reals of one sum record (eea_batch_io::d_ck_rec): K^2 + 1 rounded up to an even number */
