@@ -77,6 +77,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per leg; 0 = skip")
     ap.add_argument("--no-latency", action="store_true", help="skip the B = 1 dependent-call leg")
     ap.add_argument("--no-phik", action="store_true", help="skip the phi_k legs (roofline_phik)")
+    ap.add_argument("--no-single-launch", action="store_true",
+                    help="skip the short one-launch-per-pass leg behind the headline leg (counter-collection runs: every "
+                         "control dispatch of the run then has the headline's shape)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the legs of the other single-GPU BASELINE configs (configs[1], configs[2] fp32 + fp64)")
     ap.add_argument("--phik-grid", type=int, default=16384, help="side of the square fp64 grid of the phi_k leg")
@@ -769,7 +772,7 @@ def main():
     elapsed, pass_ms, enqueue_s = timed("shard", args.steps, args.warmup)
     # the same passes as one launch per pass (short: 3 x 400 passes), device work contiguous with the headline leg
     single_pass_ms = pass_ms
-    if SPL > 1:
+    if SPL > 1 and not args.no_single_launch:
         _, single_pass_ms, single_enqueue_s = timed("shard1", 3, 1, passes=400)
 
     out = None

@@ -17,7 +17,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -o trace --
 # 2) PMC passes, each in its own run (FETCH_SIZE and WRITE_SIZE do not fit one pass); counter collection serialises
 #    the dispatches, so these runs are short and skip the spin-up
 export EEA_BENCH_SPINUP_PASSES=0
-PMC_BENCH="python3 bench.py --steps 2 --warmup 1 --passes-per-step 100 $LEGS $*"
+PMC_BENCH="python3 bench.py --steps 2 --warmup 1 --passes-per-step 100 --no-single-launch $LEGS $*"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --kernel-include-regex control_ --output-format csv -d "$OUT/pmc_fetch" -o pmc -- $PMC_BENCH > "$OUT/pmc_fetch.log" 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --kernel-include-regex control_ --output-format csv -d "$OUT/pmc_write" -o pmc -- $PMC_BENCH > "$OUT/pmc_write.log" 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY --kernel-include-regex control_ --output-format csv -d "$OUT/pmc_sq1" -o pmc -- $PMC_BENCH > "$OUT/pmc_sq1.log" 2>&1

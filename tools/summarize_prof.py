@@ -52,7 +52,8 @@ def main():
             G = int(bench["config"]["agent_groups"])
             SPL = int(bench["config"].get("steps_per_launch", 1))   # receding-horizon steps (passes) per launch
             # the shard leg is followed by the short one-launch-per-pass leg (3 + 1 steps of 400 passes) when SPL > 1
-            tail = (3 + 1) * 400 * G if SPL > 1 else 0
+            tail = (3 + 1) * 400 * G if (SPL > 1 and "single_launch_per_pass" in bench and
+                                         bench["single_launch_per_pass"]["ms_per_pass"] != bench["ms_per_pass"]) else 0
             n_timed = int(bench["steps"]) * int(bench["config"]["passes_per_step"]) // SPL * G
             timed = disp[-(n_timed + tail):len(disp) - tail] if tail else disp[-n_timed:]
             dur = [e - s for s, e in timed]
