@@ -69,9 +69,6 @@ def parse():
                     help="the consensus leg is timed once per lag: pass i consumes the c_bar of pass i - lag.  Lag 1 is the "
                          "previous step's consensus (decentralised ergodic control); the exchange is device-bound "
                          "(eea_comm_records_exchange_bound): no host wait, no stream wait, no host thread at any lag")
-    ap.add_argument("--consensus-steps-per-launch", type=int, default=1,
-                    help="receding-horizon steps per control launch of the consensus leg (the exchange slots then rotate "
-                         "inside the launch, eea_batch_io::exch_slots)")
     ap.add_argument("--consensus-buffers", type=int, default=8, choices=range(3, 9),
                     help="record / sum buffers (and exchange slots) the consensus leg rotates through")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget per leg; 0 = skip")
@@ -612,10 +609,6 @@ def main():
     # eea_batch_io structs are built once per distinct buffer set, a pass is one ctypes call per group
     # receding-horizon steps per launch: the largest divisor of the passes per step that does not exceed the request
     SPL = max(d for d in range(1, max(1, args.steps_per_launch) + 1) if R % d == 0)
-    # steps per launch of the consensus leg: 1 by default -- with the consensus in the loop several steps per launch are
-    # no faster (28.5 against 26.8-27.9 us per pass: the groups of a multi-step launch run in lockstep, and the record sums
-    # of the steps ahead poll beside them), profiles/r04_exchange_cost.txt
-    SPLX = max(d for d in range(1, max(1, args.consensus_steps_per_launch) + 1) if RX % d == 0)
     shard_calls = [eng.prepared_batch(a["B"], a["pose"], a["ut"], a["u0"], mem_cols=a["mem_cols"], n_mem=a["n_mem"],
                                       mem_stride=args.n_mem, stream=a["stream"],
                                       n_steps=None if SPL == 1 else SPL) for a in gargs]
@@ -640,24 +633,6 @@ def main():
             slot = i % NB
             src = (i - lag) % NB if i >= lag else None
             seq = cstate["seq0"] + i + 1      # sequence numbers only grow (also from one timed() call to the next)
-            if not host_staged and SPLX > 1:
-                # device-bound AND SPLX steps per launch: G control launches of SPLX steps (step n: records to slot
-                # (slot + n) % NB, ready marks seq + n, waits for flag seq + n - lag), then one exchange call per step
-                if i % SPLX:
-                    return
-                for g, a in enumerate(gargs):
-                    call = exch_calls.get(("ms", g))
-                    if call is None:
-                        call = exch_calls[("ms", g)] = eng.prepared_batch(
-                            a["B"], a["pose"], a["ut"], a["u0"], mem_cols=a["mem_cols"], n_mem=a["n_mem"],
-                            mem_stride=args.n_mem, stream=a["stream"], ck_rec=d_arec_all[0][gb[g]:gb[g + 1]],
-                            rec_ready=d_ready[gb[g]:gb[g + 1]], status=d_xstatus[gb[g]:gb[g + 1]],
-                            ck_shared=d_rec_all[0], ck_shared_parts=1, ck_flag=d_flag, n_steps=SPLX,
-                            exch_slots=NB, rec_slot_stride=B * L, shared_slot_stride=L)
-                    call(seq, seq - lag, seq % NB)
-                for n in range(SPLX):
-                    exchange_records((seq + n) % NB, seq + n)
-                return
             if not host_staged:
                 # device-bound: G control launches (ready marks out, flag wait in) + ONE exchange call, nothing else
                 slot = seq % NB
@@ -1011,14 +986,8 @@ def main():
                         "launch with an RCCL communicator), and pass i waits INSIDE its kernels, right before the first use "
                         "of c_bar, for the flag of pass i - lag; lag 1 = the previous step's consensus.  One launch per pass "
                         "and group (the headline runs %d steps per launch: pass_ms_vs_single_launch_pass is the like-for-"
-                        "like ratio)" % SPL if SPLX == 1 else
-                        "every pass: the control kernels write per-agent sum records and ready marks (write-through, half way "
-                        "through the wavefront), ONE launch per pass on the exchange stream polls the marks and adds the records "
-                        "beside the running control kernels (+ one all-reduce of the record over the ranks and a publish launch "
-                        "with an RCCL communicator), and step i waits INSIDE the kernel, right before the first use of c_bar, for "
-                        "the flag of step i - lag; lag 1 = the previous step's consensus.  %d receding-horizon steps per control "
-                        "launch, as the headline: the exchange slots rotate inside the launch (eea_batch_io::exch_slots)" % SPLX,
-                "steps_per_launch": SPLX}
+                        "like ratio).  Every wait of this protocol is for work that was enqueued BEFORE the waiter, whatever the "
+                        "stream -> hardware-queue mapping: that is why it is one step per launch" % SPL}
             if use_dist or args.force_exchange:
                 d_all = [torch.empty((world * B, K2), dtype=tdt, device="cuda") for _ in range(2)]
                 e_s, p_ms, _ = timed("allgather", args.steps, args.warmup, passes=RX)

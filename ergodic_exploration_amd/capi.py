@@ -41,9 +41,7 @@ class BatchIO(C.Structure):
                 ("d_traj", C.c_void_p), ("d_ck", C.c_void_p), ("d_edx", C.c_void_p),
                 ("d_bdx", C.c_void_p), ("d_rhot", C.c_void_p), ("d_status", C.c_void_p),
                 ("d_ck_shared", C.c_void_p), ("d_ck_rec", C.c_void_p), ("ck_shared_parts", C.c_uint),
-                ("d_rec_ready", C.c_void_p), ("rec_seq", C.c_uint), ("d_ck_flag", C.c_void_p), ("ck_flag_seq", C.c_uint),
-                ("exch_slots", C.c_uint), ("exch_slot0", C.c_uint), ("rec_slot_stride", C.c_size_t),
-                ("shared_slot_stride", C.c_size_t)]
+                ("d_rec_ready", C.c_void_p), ("rec_seq", C.c_uint), ("d_ck_flag", C.c_void_p), ("ck_flag_seq", C.c_uint)]
 
 
 class CollisionCfg(C.Structure):
@@ -302,8 +300,7 @@ class Engine:
     def control_batch(self, B, pose, ut, u0, mem_cols=None, n_mem=None, mem_stride=0, traj=None,
                       ck=None, edx=None, bdx=None, rhot=None, status=None, stream=None, ck_shared=None,
                       ck_rec=None, ck_shared_parts=0, n_steps=None, pose_step_stride=0, u0_step_stride=0,
-                      rec_ready=None, rec_seq=0, ck_flag=None, ck_flag_seq=0, exch_slots=0, exch_slot0=0,
-                      rec_slot_stride=0, shared_slot_stride=0):
+                      rec_ready=None, rec_seq=0, ck_flag=None, ck_flag_seq=0):
         """n_steps (ABI 4, eea_control_batch_steps): that many consecutive control() calls per agent in one launch;
         pose / u0 rows per step by the strides (in agents; 0 = the same row every step)."""
         io = BatchIO()
@@ -314,8 +311,6 @@ class Engine:
         io.d_traj, io.d_ck, io.d_edx, io.d_bdx = _ptr(traj), _ptr(ck), _ptr(edx), _ptr(bdx)
         io.d_rhot, io.d_status = _ptr(rhot), _ptr(status)
         io.d_rec_ready, io.rec_seq, io.d_ck_flag, io.ck_flag_seq = _ptr(rec_ready), rec_seq, _ptr(ck_flag), ck_flag_seq
-        io.exch_slots, io.exch_slot0 = exch_slots, exch_slot0
-        io.rec_slot_stride, io.shared_slot_stride = rec_slot_stride, shared_slot_stride
         if n_steps is None:
             check(lib().eea_control_batch(self.h, B, C.byref(io), C.c_void_p(stream or 0)))
         else:
@@ -324,7 +319,7 @@ class Engine:
 
     def prepared_batch(self, B, pose, ut, u0, mem_cols=None, n_mem=None, mem_stride=0, ck=None, ck_shared=None,
                        stream=None, ck_rec=None, ck_shared_parts=0, n_steps=None, pose_step_stride=0, u0_step_stride=0,
-                       rec_ready=None, ck_flag=None, status=None, exch_slots=0, rec_slot_stride=0, shared_slot_stride=0):
+                       rec_ready=None, ck_flag=None, status=None):
         """A callable that issues eea_control_batch with these (fixed) device buffers: one ctypes call per pass, the
         eea_batch_io is built once (a pass of 4096 agents takes ~30 us on the device; building the struct from
         tensors every pass costs about as much on the host)."""
@@ -337,17 +332,11 @@ class Engine:
         io.d_rec_ready, io.d_ck_flag, io.d_status = _ptr(rec_ready), _ptr(ck_flag), _ptr(status)
         fn, h, ref, st = lib().eea_control_batch, self.h, C.byref(io), C.c_void_p(stream or 0)
         keep = (io, pose, ut, u0, mem_cols, n_mem, ck, ck_shared, ck_rec, rec_ready, ck_flag, status)
-        io.exch_slots, io.rec_slot_stride, io.shared_slot_stride = exch_slots, rec_slot_stride, shared_slot_stride
         if rec_ready is not None or ck_flag is not None:
-            # device-bound exchange: the sequence numbers change from pass to pass -- call(rec_seq, ck_flag_seq[, slot0])
-            fns = lib().eea_control_batch_steps
-
-            def call_bound(rec_seq=0, ck_flag_seq=0, exch_slot0=0, _keep=keep):
-                io.rec_seq, io.ck_flag_seq, io.exch_slot0 = rec_seq, ck_flag_seq, exch_slot0
-                if n_steps is None:
-                    rc = fn(h, B, ref, st)
-                else:
-                    rc = fns(h, B, ref, n_steps, pose_step_stride, u0_step_stride, st)
+            # device-bound exchange: the sequence numbers change from pass to pass -- call(rec_seq, ck_flag_seq)
+            def call_bound(rec_seq=0, ck_flag_seq=0, _keep=keep):
+                io.rec_seq, io.ck_flag_seq = rec_seq, ck_flag_seq
+                rc = fn(h, B, ref, st)
                 if rc != 0:
                     check(rc)
             return call_bound

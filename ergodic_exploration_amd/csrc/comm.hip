@@ -15,6 +15,7 @@
 
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "abi_util.hpp"
 #include "common.hpp"
@@ -135,6 +136,7 @@ struct eea_comm
   // read the PUBLISHED copy, eea_comm_records_exchange_bound)
   void* d_xrec[EEA_COMM_SLOTS] = {};
   size_t xrec_cap[EEA_COMM_SLOTS] = {};
+  std::vector<void*> retired;
 };
 
 namespace
@@ -221,6 +223,7 @@ void eea_comm_destroy(eea_comm* c)
   for (void* q : c->d_xrec) {
     if (q) (void)hipFree(q);
   }
+  for (void* q : c->retired) (void)hipFree(q);
   delete c;
 }
 
@@ -381,8 +384,8 @@ eea_status eea_comm_records_exchange_async(eea_engine* e, eea_comm* c, unsigned 
 // shared c_k (~45 % into the wavefront's lifetime).  Caller's duties: rotate d_ck_rec / d_sum over >= 3 buffers (slot =
 // the buffer index; d_rec_ready and d_flag may be shared by all buffers: sequence numbers only grow), and keep every
 // batch that consumes a flag small enough that the producers it waits for can be resident beside it (two agent groups
-// per GPU are: each holds half of the execution slots) -- a consumer that cannot be served gives up after tens of
-// milliseconds with EEA_ERR_TIMEOUT in d_status and its own c_k.
+// per GPU are: each holds half of the execution slots) -- a consumer that cannot be served gives up after about a
+// second with EEA_ERR_TIMEOUT in d_status and its own c_k.
 eea_status eea_comm_records_exchange_bound(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_rec,
                                            const unsigned* d_rec_ready, unsigned seq, void* d_sum, unsigned* d_flag, int slot)
 {
@@ -397,7 +400,8 @@ eea_status eea_comm_records_exchange_bound(eea_engine* e, eea_comm* c, unsigned 
   }
   const size_t bytes = eea_real_size(e) * eea_ck_record_len(e);
   if (c->xrec_cap[slot] < bytes) {
-    if (c->d_xrec[slot]) (void)hipFree(c->d_xrec[slot]);
+    // (a buffer that is too small is retired, not freed: hipFree waits for the whole device)
+    if (c->d_xrec[slot]) c->retired.push_back(c->d_xrec[slot]);
     c->d_xrec[slot] = nullptr;
     c->xrec_cap[slot] = 0;
     EEA_HIP(hipMalloc(&c->d_xrec[slot], bytes));

@@ -60,12 +60,6 @@ struct ControlParams
   unsigned rec_seq;
   const unsigned* ck_flag;
   unsigned ck_flag_seq;
-  // ... inside a multi-step launch (eea_batch_io::exch_slots > 1): step n writes its records to slot (exch_slot0 + n) %
-  // exch_slots of ck_rec (slots rec_slot_stride reals apart), marks them ready with rec_seq + n, and consumes the sum
-  // record of the slot lag = rec_seq - ck_flag_seq steps back (slots shared_slot_stride reals apart) behind flag
-  // ck_flag_seq + n; exch_slots <= 1: the same buffers every step
-  int exch_slots, exch_slot0;
-  unsigned long long rec_slot_stride, shared_slot_stride;
   R* edx;
   R* bdx;
   R* rhot;
@@ -390,9 +384,11 @@ __device__ __forceinline__ R shared_ck_value(const P& p, const R* shared, int m,
 }
 
 // Device-bound exchange, consumer side: wait (bounded) until *flag has reached seq.  One lane polls past the L1 with a
-// sleep between polls (MI355X_MICROARCH.md "polling-cost"); ~1 us per poll, 30 000 polls: tens of milliseconds, then the
-// caller reports EEA_ERR_TIMEOUT and goes on with the agent's own c_k.  Wavefront-uniform result.
-constexpr int kFlagPolls = 30000;
+// sleep between polls (MI355X_MICROARCH.md "polling-cost"); ~2 us per poll, 400 000 polls: about a second, then the
+// caller reports EEA_ERR_TIMEOUT and goes on with the agent's own c_k.  Wavefront-uniform result.  The bound is a safety
+// net against a producer that can never become resident, not a pacing device (every wait of the protocol is for work
+// enqueued before the waiter), and generous: a loaded box must not turn a long queue into a time-out.
+constexpr int kFlagPolls = 400000;
 __device__ __forceinline__ bool wait_flag(const unsigned* flag, unsigned seq)
 {
   for (int i = 0; i < kFlagPolls; ++i) {

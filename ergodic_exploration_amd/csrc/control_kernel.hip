@@ -125,7 +125,7 @@ __device__ __forceinline__ bool last_arrival(unsigned* ticket, unsigned members)
 // drained write-through record) and starts as soon as they are there, while the control kernels are still in their
 // backward halves; the wavefront that completes the last slice of the sum publishes flag = seq behind the drained sum
 // record, which is what the consuming control kernels wait for (ControlParams::ck_flag).  A unit whose agents never
-// report (tens of milliseconds) makes the record's agent count negative: consumers then keep their own c_k and report
+// report (about a second) makes the record's agent count negative: consumers then keep their own c_k and report
 // EEA_ERR_TIMEOUT.
 template <typename R>
 __global__ __launch_bounds__(kWave) __attribute__((amdgpu_num_vgpr(16))) void ck_records_sum_kernel(

@@ -258,6 +258,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
   // agent-derived (step maps, LDS addresses, masks, pointers) is carried across the loop -- hoisted, those invariants
   // cost the body ~460 B of scratch per lane; recomputed they cost what they cost a launch.
   typedef const __attribute__((address_space(4))) ControlParams<R> KernArgParams;
+  const int wave_of_block = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int n_steps = ((KernArgParams*)__builtin_amdgcn_kernarg_segment_ptr())->n_steps;
   for (int step = 0; step < n_steps; ++step) {
   // ... and the launch parameters are re-read (scalar loads where they are used, as in a launch) through a pointer that
@@ -265,10 +266,13 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
   KernArgParams* ka = (KernArgParams*)__builtin_amdgcn_kernarg_segment_ptr();  // p_arg is argument 0
   asm volatile("" : "+s"(ka));
   KernArgParams& p = *ka;
-  unsigned tid_opaque = threadIdx.x;
-  asm volatile("" : "+v"(tid_opaque));
-  const int lane = tid_opaque & (kWave - 1);
-  const int wv = __builtin_amdgcn_readfirstlane(tid_opaque / kWave);
+  // (the lane id comes from the hardware every step -- v_mbcnt, through volatile asm so that it is neither hoisted nor kept
+  // alive across the body -- and the wavefront's index from a scalar register: no vector register of the thread id
+  // survives the step)
+  int lane;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+  int wv = wave_of_block;
+  asm volatile("" : "+s"(wv));
   const unsigned b = blockIdx.x * WPB + wv;
   if (b >= B) return;  // wavefront-uniform
   EEA_WSTAMP_RT(10);
@@ -315,17 +319,13 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
   auto cnt_of = [&](int l) { return l < q16 ? S : max(0, min(sc, rem - sc * (l - q16))); };
   R* const ut = p.ut + 3 * static_cast<size_t>(T) * b;
   const R* const pose = p.pose + 3 * (static_cast<size_t>(step) * p.pose_step_stride + b);
-  // device-bound exchange inside a multi-step launch: this step's record slot, the slot it consumes, its sequence numbers
-  R* ck_rec_step = p.ck_rec;
-  const R* ck_shared_step = p.ck_shared;
-  const unsigned rec_seq_step = p.rec_seq + static_cast<unsigned>(step);
-  const unsigned flag_seq_step = p.ck_flag_seq + static_cast<unsigned>(step);
-  if (p.exch_slots > 1) {  // wavefront-uniform
-    const int slots = p.exch_slots, sl = (p.exch_slot0 + step) % slots;
-    const int lag = static_cast<int>(p.rec_seq - p.ck_flag_seq) % slots;
-    if (ck_rec_step != nullptr) ck_rec_step += static_cast<size_t>(sl) * p.rec_slot_stride;
-    if (ck_shared_step != nullptr) ck_shared_step += static_cast<size_t>((sl - lag + slots) % slots) * p.shared_slot_stride;
-  }
+  // device-bound exchange: records out / shared c_k in, with their sequence numbers (the same for every step of a
+  // multi-step launch: a step must never wait for an exchange the host enqueues AFTER this launch -- that would need
+  // truly concurrent hardware queues)
+  R* const ck_rec_step = p.ck_rec;
+  const R* const ck_shared_step = p.ck_shared;
+  const unsigned rec_seq_step = p.rec_seq;
+  const unsigned flag_seq_step = p.ck_flag_seq;
   EEA_WSTAMP(0);
   // ---- controls: shift left by one column, last column zero (ergodic_control.hpp:233-234) ------------
   R vx[kMaxS], vy[kMaxS], w[kMaxS];
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
     }
     return;
   }
-  if (lane == 0 && p.status != nullptr) p.status[b] = 0;
+  if (lane == 0 && p.status != nullptr && step == 0) p.status[b] = 0;  // (a time-out of an earlier step of the launch stays)
   EEA_WSTAMP(1);
 
   const R dt = p.dt, dt6 = p.dt6;

@@ -535,10 +535,9 @@ eea_status sum_workspace(eea_engine* e, const void* key, unsigned B, hipStream_t
   const size_t need_ws = sizeof(R) * eea::ck_sum_ws_elems(B, e->K2);
   const size_t need_ctr = sizeof(unsigned) * eea::ck_sum_tickets(B, e->K2);
   if (need_ws > w->ws.cap || need_ctr > w->ctr.cap || recycled) {
-    // NO device synchronisation here: a control kernel that is already running may be waiting, inside the kernel, for
-    // the very sum this call is about to launch (device-bound exchange inside a multi-step launch) -- waiting for the
-    // device would wait for that kernel's time-out.  Buffers an earlier launch may still use are retired, not freed
-    // (released with the engine); a recycled workspace gets fresh buffers for the same reason.
+    // NO device synchronisation here (a per-pass call must not stall every stream of the device): buffers an
+    // earlier launch may still use are retired, not freed (released with the engine, or in one sweep when many have
+    // piled up); a recycled workspace gets fresh buffers for the same reason.
     if (e->retired.size() >= 128) {  // a caller that churns output buffers: pay ONE synchronisation per 64 recycled sums
       EEA_HIP(hipDeviceSynchronize());
       for (void* q : e->retired) (void)hipFree(q);
@@ -581,10 +580,6 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
   p.rec_seq = io->rec_seq;
   p.ck_flag = io->d_ck_shared != nullptr ? io->d_ck_flag : nullptr;
   p.ck_flag_seq = io->ck_flag_seq;
-  p.exch_slots = static_cast<int>(io->exch_slots);
-  p.exch_slot0 = static_cast<int>(io->exch_slot0);
-  p.rec_slot_stride = io->rec_slot_stride;
-  p.shared_slot_stride = io->shared_slot_stride;
   p.edx = static_cast<R*>(io->d_edx);
   p.bdx = static_cast<R*>(io->d_bdx);
   p.rhot = static_cast<R*>(io->d_rhot);
@@ -609,19 +604,9 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
   }
   // the workgroup-per-agent kernel takes one step per launch: a multi-step call is that many launches on the stream
   p.n_steps = 1;
-  const int slots = static_cast<int>(io->exch_slots);
-  p.exch_slots = 0;
   for (unsigned n = 0; n < n_steps; ++n) {
     p.pose = static_cast<const R*>(io->d_pose) + 3 * static_cast<size_t>(n) * pose_step_stride;
     p.u0 = static_cast<R*>(io->d_u0) + 3 * static_cast<size_t>(n) * u0_step_stride;
-    p.rec_seq = io->rec_seq + n;
-    p.ck_flag_seq = io->ck_flag_seq + n;
-    if (slots > 1) {  // the per-step exchange slots of a multi-step call
-      const int sl = static_cast<int>((io->exch_slot0 + n) % io->exch_slots);
-      const int lag = static_cast<int>(io->rec_seq - io->ck_flag_seq) % slots;
-      if (io->d_ck_rec != nullptr && !rollout_only) p.ck_rec = static_cast<R*>(io->d_ck_rec) + static_cast<size_t>(sl) * io->rec_slot_stride;
-      if (io->d_ck_shared != nullptr) p.ck_shared = static_cast<const R*>(io->d_ck_shared) + static_cast<size_t>((sl - lag + slots) % slots) * io->shared_slot_stride;
-    }
     EEA_HIP(eea::launch_control<R>(p, B, e->cfg.model, n_mem_max, rollout_only, s));
   }
   return EEA_OK;
@@ -1085,6 +1070,11 @@ eea_status eea_control_batch_steps(eea_engine* e, unsigned B, const eea_batch_io
   if (n_steps == 0 || n_steps > (1u << 20)) return fail(EEA_ERR_INVALID_ARGUMENT, "n_steps must be in 1 .. 2^20");
   if ((pose_step_stride != 0 && pose_step_stride < B) || (u0_step_stride != 0 && u0_step_stride < B)) {
     return fail(EEA_ERR_INVALID_ARGUMENT, "a step stride is 0 (the same row every step) or >= B agents");
+  }
+  if (n_steps > 1 && (io->d_rec_ready != nullptr || io->d_ck_flag != nullptr)) {
+    // a step of the launch would wait, inside the kernel, for an exchange the host can only enqueue after this call: that
+    // needs truly concurrent hardware queues (streams may share one) -- the device-bound exchange is one step per launch
+    return fail(EEA_ERR_UNSUPPORTED, "the device-bound exchange (d_rec_ready / d_ck_flag) takes one step per launch");
   }
   if (!e->have_phik) return fail(EEA_ERR_NO_TARGET, "no phi_k: call eea_config_domain or eea_set_target_grid first");
   eea_status st = use_device(e);

@@ -215,20 +215,11 @@ typedef struct {
   const unsigned* d_ck_flag;/* in (with d_ck_shared): the kernel waits until *d_ck_flag has reached ck_flag_seq
                                         ((int)(*d_ck_flag - ck_flag_seq) >= 0) right before the first use of the shared
                                         c_k, and reads d_ck_shared past its L1: "late binding" -- the call can be
-                                        launched before the exchange that fills d_ck_shared has run.  Bounded (tens
-                                        of milliseconds): then d_status[b] = EEA_ERR_TIMEOUT and the agent uses its own
+                                        launched before the exchange that fills d_ck_shared has run.  Bounded (about a
+                                        second): then d_status[b] = EEA_ERR_TIMEOUT and the agent uses its own
                                         c_k.  The waiting wavefronts hold their execution slots: see
                                         eea_comm_records_exchange_bound for what must fit beside them             */
   unsigned ck_flag_seq;
-  /* ... inside eea_control_batch_steps (n_steps > 1): with exch_slots > 1, step n of the launch writes its records to
-   * d_ck_rec + ((exch_slot0 + n) % exch_slots) * rec_slot_stride reals, marks them ready with rec_seq + n, waits for
-   * ck_flag_seq + n and consumes d_ck_shared + (slot of step n - lag) * shared_slot_stride reals, lag = rec_seq - ck_flag_seq:
-   * a consensus on every step of a multi-step launch -- the host only issues one eea_comm_records_exchange_bound per step
-   * (sequence number rec_seq + n, the same slot), in any order relative to the control launch.  Before the first launch:
-   * *d_ck_flag = rec_seq - 1 of that launch and zeroed sum records (an agent count of 0 means "own c_k"), so that the
-   * first lag steps have something to consume.  exch_slots <= 1: the same buffers and numbers every step. */
-  unsigned exch_slots, exch_slot0;
-  size_t rec_slot_stride, shared_slot_stride;
 } eea_batch_io;
 
 /* length in reals of one sum record (eea_batch_io::d_ck_rec): K^2 + 1 rounded up to an even number */
@@ -244,7 +235,7 @@ eea_status eea_ck_records_sum(eea_engine* e, unsigned B, const void* d_ck_rec, v
  * write the records -- every unit of the sum polls the ready marks of its 32 agents (d_rec_ready[b] == seq,
  * eea_batch_io::d_rec_ready / rec_seq of the producing calls) and starts when they are there.  d_flag != NULL: *d_flag = seq
  * is published (write-through, behind the drained sum record) by the wavefront that completes the sum -- what
- * eea_batch_io::d_ck_flag of the consuming calls waits for.  Agents that never report within tens of milliseconds make the
+ * eea_batch_io::d_ck_flag of the consuming calls waits for.  Agents that never report within about a second make the
  * record's agent count negative (consumers then keep their own c_k and report EEA_ERR_TIMEOUT).  Same summation tree, same
  * bits as eea_ck_records_sum. */
 eea_status eea_ck_records_sum_bound(eea_engine* e, unsigned B, const void* d_ck_rec, const unsigned* d_rec_ready, unsigned seq,
@@ -265,7 +256,10 @@ eea_status eea_control_batch(eea_engine* e, unsigned B, const eea_batch_io* io, 
  * pose sequence replayed through the controller (the replay harness of exploration.hpp:197-292 per agent), a
  * closed-loop simulation driven from the host in chunks, or a throughput run.  Bitwise the same d_ut / d_u0 as the n_steps
  * separate calls (tests/test_gpu_multi_step.py).  The other per-step outputs (d_ck, d_ck_rec, d_traj, stage outputs,
- * d_status) hold the LAST step's values; d_ck_shared / replay-memory columns are read unchanged by every step.  The
+ * d_status) hold the LAST step's values; d_ck_shared / replay-memory columns are read unchanged by every step; the
+ * device-bound exchange fields (d_rec_ready / d_ck_flag) are refused with n_steps > 1 (EEA_ERR_UNSUPPORTED): a step would
+ * wait inside the kernel for an exchange the host can only enqueue after this call, which needs truly concurrent
+ * hardware queues -- every wait of that protocol is for work enqueued BEFORE the waiter.  The
  * agent's wavefront carries on with its own stored controls (read back through L2) instead of the host launching again:
  * no launch gap, no kernel tail, no cold loads between steps.  Horizons / bases outside the wavefront-per-agent kernel's
  * range (T > 256, K > 16 and != 20) are issued as n_steps launches on the stream with the same semantics. */
@@ -336,7 +330,7 @@ eea_status eea_comm_records_exchange_async(eea_engine* e, eea_comm* c, unsigned 
  * flag must leave room for what it waits for: the producers of that flag (control kernels of other agent groups, the
  * record sum's single-wavefront workgroups, the all-reduce) have to become resident BESIDE the waiting wavefronts -- two
  * agent groups per GPU of at most half its execution slots each do (the fp64 K <= 10 instance leaves registers for the
- * sum beside a full set of control wavefronts); a waiter that cannot be served gives up after tens of milliseconds
+ * sum beside a full set of control wavefronts); a waiter that cannot be served gives up after about a second
  * (EEA_ERR_TIMEOUT in d_status, own c_k), it never hangs.  Host threads: none; the calling thread issues 1-3 launches. */
 eea_status eea_comm_records_exchange_bound(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_rec,
                                            const unsigned* d_rec_ready, unsigned seq, void* d_sum, unsigned* d_flag, int slot);

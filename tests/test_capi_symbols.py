@@ -32,7 +32,7 @@ def test_library_exports_only_the_documented_abi():
 def test_struct_layouts_match_header():
     # sizes the C compiler gives the ABI structs (kept in sync with ergodic_amd.h by hand)
     assert C.sizeof(capi.Config) == 3 * 4 + 4 + 4 * 8 + 8 + 15 * 8  # ints, pad, doubles, K+pad, arrays
-    assert C.sizeof(capi.BatchIO) == 15 * 8 + 4 * 8 + 3 * 8  # ABI 3 (15 slots) + ready / flag fields + the per-step exchange slots (ABI 4)
+    assert C.sizeof(capi.BatchIO) == 15 * 8 + 4 * 8  # ABI 3 (15 slots) + d_rec_ready, rec_seq, d_ck_flag, ck_flag_seq (ABI 4)
     assert C.sizeof(capi.CollisionCfg) == 3 * 8 + 2 * 4 + 4 * 8
 
 

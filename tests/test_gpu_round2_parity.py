@@ -387,49 +387,28 @@ def test_consensus_pass_device_bound_exchange(lag, rccl, K, horizon):
     eng.close()
 
 
-@pytest.mark.parametrize("lag", [1, 2])
-@pytest.mark.parametrize("K,horizon,spl", [(10, 20.0, 3), (10, 20.0, 4), (30, 6.0, 3)])
-def test_consensus_inside_multi_step_launches(lag, K, horizon, spl):
-    """The device-bound exchange INSIDE eea_control_batch_steps (bench.py's consensus leg): one control launch per group
-    covers `spl` receding-horizon steps -- step n writes its records to exchange slot (slot0 + n) % slots, marks them
-    ready with rec_seq + n and waits in-kernel for the flag of step n - lag -- while the host issues one
-    eea_comm_records_exchange_bound per step.  Bitwise the synchronised one-call-at-a-time sequence after 12 steps, for the
-    wavefront kernel (in-kernel step loop) and the workgroup kernel (the engine issues the steps as launches)."""
-    rng = np.random.default_rng(31)
-    B, G, NB, passes = 300, 2, 6, 12
-    eng, _ = make_pair("omni", K, horizon, n_oracles=0)
-    T, K2, L = eng.T, eng.K2, eng.ck_record_len
-    d_pose = dev(random_poses(rng, B))
-    ut0 = rng.uniform(-0.3, 0.3, (B, T, 3))
-    gb = [0, 130, B]
-    ut_a, u0_a, sums_a = _consensus_reference(eng, B, gb, d_pose, ut0, lag, passes, L)
-    comm = capi.Comm(0, 1, 0, None)
-    streams = [torch.cuda.Stream() for _ in range(G)]
-    ut_b, u0_b = dev(ut0), torch.empty((B, 3), dtype=torch.float64, device="cuda")
-    arecs = torch.zeros((NB, B, L), dtype=torch.float64, device="cuda")
-    sums_b = torch.zeros((NB, L), dtype=torch.float64, device="cuda")   # zero records: agent count 0 = "own c_k"
+def test_device_bound_exchange_is_one_step_per_launch():
+    """eea_control_batch_steps refuses the device-bound exchange fields with n_steps > 1: a step of the launch would wait,
+    inside the kernel, for an exchange the host can only enqueue AFTER the launch -- that needs truly concurrent hardware
+    queues, and streams may share one (measured in round 4: the same test passed or ran into the time-out depending on
+    which streams the process had created before).  Every wait of the protocol is for work enqueued BEFORE the waiter."""
+    eng, _ = make_pair("omni", 10, 20.0, n_oracles=0)
+    B, T, L = 8, eng.T, eng.ck_record_len
+    d_pose = dev(random_poses(np.random.default_rng(0), B))
+    ut = torch.zeros((B, T, 3), dtype=torch.float64, device="cuda")
+    u0 = torch.empty((B, 3), dtype=torch.float64, device="cuda")
+    arec = torch.zeros((B, L), dtype=torch.float64, device="cuda")
     ready = torch.zeros((B,), dtype=torch.int32, device="cuda")
-    seq0 = 1000
-    flag = torch.full((1,), seq0, dtype=torch.int32, device="cuda")     # stands at the number before the first step
-    status = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    flag = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    rec = torch.zeros((L,), dtype=torch.float64, device="cuda")
+    for kw in (dict(ck_rec=arec, rec_ready=ready, rec_seq=1), dict(ck_shared=rec, ck_shared_parts=1, ck_flag=flag, ck_flag_seq=0)):
+        with pytest.raises(capi.EngineError) as ei:
+            eng.control_batch(B, d_pose, ut, u0, n_steps=3, **kw)
+        assert ei.value.status == capi.ERR_UNSUPPORTED
+    # (plain records / a plain shared c_k are fine with several steps per launch)
+    eng.control_batch(B, d_pose, ut, u0, n_steps=3, ck_rec=arec, ck_shared=rec, ck_shared_parts=1)
     torch.cuda.synchronize()
-    for i in range(0, passes, spl):
-        seq = seq0 + i + 1
-        for g in range(G):
-            sl = slice(gb[g], gb[g + 1])
-            eng.control_batch(gb[g + 1] - gb[g], d_pose[sl], ut_b[sl], u0_b[sl], ck_rec=arecs[0][sl],
-                              rec_ready=ready[sl], rec_seq=seq, status=status[sl], ck_shared=sums_b[0], ck_shared_parts=1,
-                              ck_flag=flag, ck_flag_seq=seq - lag, n_steps=spl, exch_slots=NB, exch_slot0=seq % NB,
-                              rec_slot_stride=B * L, shared_slot_stride=L, stream=streams[g].cuda_stream)
-        for n in range(spl):
-            comm.records_exchange_bound(eng, B, arecs[(seq + n) % NB], ready, seq + n, sums_b[(seq + n) % NB], flag,
-                                        (seq + n) % NB)
-    torch.cuda.synchronize()
-    assert (status.cpu().numpy() == 0).all()
-    assert int(flag.item()) == seq0 + passes
-    assert torch.equal(ut_a, ut_b) and torch.equal(u0_a, u0_b)
-    assert torch.equal(sums_a[passes - 1], sums_b[(seq0 + passes) % NB])
-    comm.close()
+    assert torch.isfinite(ut).all()
     eng.close()
 
 
@@ -489,8 +468,8 @@ print("PINNED_OK cpus=%%d us_per_pass=%%.1f timeouts=%%d flag=%%d" %% (len(os.sc
 
 
 def test_device_bound_exchange_times_out_instead_of_hanging():
-    """A consumer whose flag never arrives, and a record sum whose producers never report, give up after tens of
-    milliseconds: per-agent EEA_ERR_TIMEOUT, the agent's OWN c_k in the gradient (bitwise the call without a shared c_k);
+    """A consumer whose flag never arrives, and a record sum whose producers never report, give up after about a
+    second: per-agent EEA_ERR_TIMEOUT, the agent's OWN c_k in the gradient (bitwise the call without a shared c_k);
     a sum that gave up marks its record with a negative agent count, which its consumers report the same way."""
     rng = np.random.default_rng(29)
     for K, horizon in ((10, 20.0), (30, 6.0)):
