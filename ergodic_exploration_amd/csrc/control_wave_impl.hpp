@@ -33,11 +33,10 @@
 // (control_kernel_impl.hpp); the engine picks.  rollout_only (optTraj / path) stops after the forward half,
 // so a rollout and the trajectory a control call reports are bitwise the same function of (pose, controls).
 //
-// This header has two parts: helpers (under the include guard) and the kernel itself, which can be included a second
-// time under another name with a register cap (control_wave_kernel.hip: the "lean" fp64 K <= 10 instance; the
-// attribute takes a literal only, so it cannot depend on the template arguments).
 #ifndef EEA_CONTROL_WAVE_HELPERS_HPP
 #define EEA_CONTROL_WAVE_HELPERS_HPP
+
+#include <type_traits>
 
 #include "common.hpp"
 
@@ -72,12 +71,7 @@ __host__ __device__ constexpr int tile_elems(int K)
   const int d = d_elems(K) + 2 * kMaxS * kWave + kTailScratch;
   return ((t > d ? t : d) + 3) & ~3;
 }
-// the lean instance parks two more rows [64]: the x and y basis sines of the last slot
-__host__ __device__ constexpr int lean_park_elems() { return 2 * kWave; }
-__host__ __device__ constexpr int wave_lds_elems(int K, bool lean = false)
-{
-  return park_elems() + tile_elems(K) + (lean ? lean_park_elems() : 0);
-}
+__host__ __device__ constexpr int wave_lds_elems(int K) { return park_elems() + tile_elems(K); }
 
 // orders this wavefront's own LDS writes before its own LDS reads (DS operations of one wavefront execute in
 // order; this stops the compiler from moving them across)
@@ -226,13 +220,7 @@ constexpr int grad_block(int KC) { return KC <= 12 ? KC : (KC == 16 ? 8 : 10); }
 }  // namespace eea
 #endif  // EEA_CONTROL_WAVE_HELPERS_HPP
 
-// ---- the kernel (re-includable: EEA_WAVE_KERNEL_NAME / _ATTR / _LEAN) ------------------------------------------------
-#ifndef EEA_WAVE_KERNEL_NAME
-#define EEA_WAVE_KERNEL_NAME control_wave_kernel
-#define EEA_WAVE_KERNEL_ATTR
-#define EEA_WAVE_KERNEL_LEAN false
-#endif
-
+// ---- the kernel --------------------------------------------------------------------------------------------------------
 namespace eea
 {
 namespace wave
@@ -240,16 +228,16 @@ namespace wave
 // KC: compile-time K (5, 10, 20) or 16 = any K <= 16 at run time (loops unrolled to 16, guarded).
 // STAGES: the optional per-stage outputs (traj, edx, bdx, rhot) are compiled in.
 // WPB: wavefronts (= agents) per workgroup; they share nothing.
-// LEAN instance (fp64, K <= 10, no stage outputs): 120 registers instead of 122 -- the allocation granule is 8, so four
-// wavefronts per SIMD leave 32 registers free, room for the wavefronts of the record sum (control_kernel.hip) BESIDE a
-// fully resident control kernel.  The two registers come from parking the last slot's basis sines in LDS from the
-// basis phase to the end of the gradient (lean_park_elems: the workgroup then uses a quarter of the CU's LDS exactly).
+// Registers: the fp64 K <= 10 instances without stage outputs -- what bench.py times -- compile to 116-119 registers,
+// no scratch (tests/test_capi_symbols.py reads it from the code object): the allocation granule is 8, so four wavefronts
+// per SIMD leave 32 registers free, room for the wavefronts of the record sum (control_kernel.hip) BESIDE a fully
+// resident control kernel.  (Rounds 3-4 needed a second, register-capped compilation of this text with two values parked
+// in LDS to get there; since the lane id and the launch arguments are re-derived per step it fits by itself.)
 template <typename R, int MODEL, int KC, bool STAGES, int WPB>
-__global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE_KERNEL_ATTR void EEA_WAVE_KERNEL_NAME(
-    const ControlParams<R> p_arg, const unsigned B, const int S, const int rollout_only)
+__global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void control_wave_kernel(
+    const ControlParams<R> p_arg, const unsigned B, const int S_arg, const int rollout_arg)
 {
   (void)p_arg;  // read through the kernel-argument segment below
-  constexpr bool kParkSine = EEA_WAVE_KERNEL_LEAN;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   // Receding-horizon steps of this agent in ONE launch (eea_control_batch_steps): step n is a complete control() call
   // from the pose of row n and the controls step n - 1 left in ut -- the wavefront reads its own stores back (from L2:
@@ -273,6 +261,11 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
   asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
   int wv = wave_of_block;
   asm volatile("" : "+s"(wv));
+  // (the same for the two scalar launch arguments: hoisted out of the step loop, the ~20 wavefront-uniform predicates of
+  // the unrolled slot loops -- S > j, S == 4, ... -- were parked in the lanes of a vector register and read back with
+  // v_readlane every step; recomputed they are scalar compares)
+  int S = S_arg, rollout_only = rollout_arg;
+  asm volatile("" : "+s"(S), "+s"(rollout_only));
   const unsigned b = blockIdx.x * WPB + wv;
   if (b >= B) return;  // wavefront-uniform
   EEA_WSTAMP_RT(10);
@@ -289,12 +282,11 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
   const int K2 = K * K;
   constexpr int KS = (KC == 16) ? 16 : tab_stride(KC);
 
-  R* const sm = reinterpret_cast<R*>(smem_raw) + static_cast<size_t>(wv) * wave_lds_elems(KC == 16 ? 16 : KC, kParkSine);
+  R* const sm = reinterpret_cast<R*>(smem_raw) + static_cast<size_t>(wv) * wave_lds_elems(KC == 16 ? 16 : KC);
   R* const tabx = sm;                       // [32 rows][KS]
   R* const taby = tabx + kStageRows * KS;
   R* const s_cp = sm + tile_elems(KC == 16 ? 16 : KC);  // cos of the post-step heading, [j][lane]
   R* const s_sp = s_cp + kMaxS * kWave;                 // sin
-  R* const s_sine = s_sp + kMaxS * kWave;               // lean instance: [y, x][lane] basis sines of the last slot
   R* const s_D = tabx;                      // D[k2 * K + k1]   (after the contraction)
   R* const s_g = tabx + d_elems(KC == 16 ? 16 : KC);  // barrier gradient parked during the gradient, [2 j + r][lane]
 
@@ -500,10 +492,6 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
       } else {
         sincospi_r(x * p.inv_lx, &s1x[j], &c1x[j]);
         sincospi_r(y * p.inv_ly, &s1y[j], &c1y[j]);
-      }
-      if (kParkSine && j == kMaxS - 1) {  // not needed before the end of the gradient
-        s_sine[lane] = s1y[j];
-        s_sine[kWave + lane] = s1x[j];
       }
       // gradBarrier (:453-474): 25 * (2 [x > lx - eps] (x - (lx - eps)) + 2 [x < eps] (x - eps)) per axis.  The
       // indicator times the difference is max(difference, 0) / min(difference, 0) (x > a <=> x - a > 0 in IEEE
@@ -1178,8 +1166,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
           ub = un;
         }
       }
-      const R sx = (kParkSine && j == kMaxS - 1) ? s_sine[kWave + lane] : s1x[j];
-      const R sy = (kParkSine && j == kMaxS - 1) ? s_sine[lane] : s1y[j];
+      const R sx = s1x[j], sy = s1y[j];
       const R exj = (-p.pi_lx * sx * accx) * p.expl_weight;
       const R eyj = (-p.pi_ly * sy * accy) * p.expl_weight;
       if (STAGES) {
@@ -1210,7 +1197,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
       if (lane < 8) {
         s_tail[lane] = c1x[jt];
         s_tail[8 + lane] = c1y[jt];
-        s_tail[16 + lane] = kParkSine ? s_sine[lane] : s1y[jt];
+        s_tail[16 + lane] = s1y[jt];
       }
       lds_fence();
       const R cxs = s_tail[st], cys = s_tail[8 + st], sys = s_tail[16 + st];
@@ -1284,7 +1271,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
       }
       lds_fence();
       const R accx = s_tail[2 * (lane & 7)], accy = s_tail[2 * (lane & 7) + 1];
-      const R sx = kParkSine ? s_sine[kWave + lane] : s1x[jt];
+      const R sx = s1x[jt];
       const R exj = (-p.pi_lx * sx * accx) * p.expl_weight;
       const R eyj = (-p.pi_ly * accy) * p.expl_weight;  // (sin b is in the row factors)
       if (STAGES) {
@@ -1345,6 +1332,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
     }
   }
   R r0[kMaxS], r1[kMaxS];  // inclusive suffix within the lane, then the co-state after step j
+  R tot0, tot1, tot2;      // the wavefront totals of the three co-state scans (wavefront-uniform)
   {
     R s0 = R(0), s1 = R(0);
 #pragma unroll
@@ -1361,7 +1349,9 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
     }
     // suffix over the lanes = wavefront total - inclusive prefix
     const R i0s = wave_inclusive_scan_dpp(s0), i1s = wave_inclusive_scan_dpp(s1);
-    const R o0 = read_lane63(i0s) - i0s, o1 = read_lane63(i1s) - i1s;
+    tot0 = read_lane63(i0s);
+    tot1 = read_lane63(i1s);
+    const R o0 = tot0 - i0s, o1 = tot1 - i1s;
 #pragma unroll
     for (int j = 0; j < kMaxS; ++j) {
       r0[j] += o0;
@@ -1393,13 +1383,23 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
       r2[j] = s2;
     }
     const R i2s = wave_inclusive_scan_dpp(s2);
-    const R o2 = read_lane63(i2s) - i2s;
+    tot2 = read_lane63(i2s);
+    const R o2 = tot2 - i2s;
 #pragma unroll
     for (int j = 0; j < kMaxS; ++j) r2[j] += o2;
   }
 
   EEA_WSTAMP(8);
   // ---- u_i = clamp(-Rinv B(x_i)^T rho_i)  (ergodic_control.hpp:438-451) ---------------------------------
+  // std::clamp lets a NaN pass (both comparisons are false); min(max(u, lo), hi) -- 2 instructions per component instead of
+  // 2 compares + 4 selects + the moves that feed them: 125 -> ~30 vector instructions per agent -- would turn it into the
+  // lower limit.  A NaN anywhere in the agent's state or gradients reaches one of the three co-state scan totals (they
+  // sum every step's g and every step's A(x, u) rho terms), so ONE wavefront-uniform test picks the form: the fast one
+  // when the totals are numbers, the comparing one otherwise (signed zeros: max / min may return +0 where std::clamp
+  // returns -0; equal as numbers).
+  const bool nan_free = __all((tot0 == tot0) && (tot1 == tot1) && (tot2 == tot2));
+  auto update_controls = [&](auto fast_tag) {
+  constexpr bool kFast = decltype(fast_tag)::value;
 #pragma unroll
   for (int j = 0; j < kMaxS; ++j) {
     if (j < cnt) {
@@ -1419,7 +1419,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         const R ur = (p.Rinv[r] * n0 + p.Rinv[r + 3] * n1) + p.Rinv[r + 6] * n2;
-        u[r] = clamp_std(ur, p.umin[r], p.umax[r]);
+        u[r] = kFast ? fmin(fmax(ur, p.umin[r]), p.umax[r]) : clamp_std(ur, p.umin[r], p.umax[r]);
       }
       ut[3 * i + 0] = u[0];
       ut[3 * i + 1] = u[1];
@@ -1442,6 +1442,9 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) EEA_WAVE
       }
     }
   }
+  };
+  if (nan_free) update_controls(std::true_type{});  // wavefront-uniform
+  else update_controls(std::false_type{});
   EEA_WSTAMP(9);
   if (step + 1 < n_steps) {  // wavefront-uniform: the next step reads the controls just stored (and reuses the LDS)
     // only THIS wavefront reads them back: work-group scope -- the stores drained (s_waitcnt vmcnt(0)), the CU's own

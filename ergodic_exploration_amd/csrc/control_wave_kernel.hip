@@ -1,13 +1,5 @@
 // Instantiations and dispatch of the wavefront-per-agent control kernel (control_wave_impl.hpp).
 #include "control_wave_impl.hpp"
-// the same kernel text once more: the lean instance (<= 120 registers: the request is in register pairs on gfx90a+)
-#undef EEA_WAVE_KERNEL_NAME
-#undef EEA_WAVE_KERNEL_ATTR
-#undef EEA_WAVE_KERNEL_LEAN
-#define EEA_WAVE_KERNEL_NAME control_wave_kernel_lean
-#define EEA_WAVE_KERNEL_ATTR __attribute__((amdgpu_num_vgpr(60)))
-#define EEA_WAVE_KERNEL_LEAN true
-#include "control_wave_impl.hpp"
 
 // wavefronts (agents) per workgroup: they share nothing; 4 keeps the dispatch count low
 #ifndef EEA_WAVE_WPB
@@ -25,15 +17,8 @@ hipError_t launch_wave_one(const ControlParams<R>& p, unsigned B, bool rollout_o
   // wavefronts), single agents 11 times (the registers allow 12)
   constexpr int WPB = (KC == 20 && sizeof(R) == 8) ? 1 : EEA_WAVE_WPB;
   const int S = (p.T + kWave - 1) / kWave;
-  // fp64, K <= 10, no stage outputs: the lean instance (room beside it for the record sum's wavefronts)
-  constexpr bool LEAN = sizeof(R) == 8 && KC <= 10 && !STAGES;
-  const size_t lds = static_cast<size_t>(WPB) * wave::wave_lds_elems(KC, LEAN) * sizeof(R);
-  void (*kern)(const ControlParams<R>, const unsigned, const int, const int) = nullptr;
-  if constexpr (LEAN) {
-    kern = wave::control_wave_kernel_lean<R, MODEL, KC, STAGES, WPB>;
-  } else {
-    kern = wave::control_wave_kernel<R, MODEL, KC, STAGES, WPB>;
-  }
+  const size_t lds = static_cast<size_t>(WPB) * wave::wave_lds_elems(KC) * sizeof(R);
+  void (*kern)(const ControlParams<R>, const unsigned, const int, const int) = wave::control_wave_kernel<R, MODEL, KC, STAGES, WPB>;
   if (lds > 64 * 1024) {
     const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                              hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));

@@ -104,3 +104,32 @@ def test_library_reads_no_environment_variable():
     import subprocess
     out = subprocess.run(["nm", "-D", "--undefined-only", capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
     assert "getenv" not in out
+
+
+def test_timed_control_instances_leave_room_for_the_record_sum():
+    """The fp64 K <= 10 instances of the wavefront kernel -- what bench.py times -- must stay at <= 120 registers without
+    scratch: four wavefronts per SIMD then leave 32 registers (allocation granule 8) for the record sum's wavefronts
+    BESIDE a fully resident control kernel, and the record sum itself must fit into those 32.  Read from
+    the gfx950 code objects of the build (tools/kernel_resources.py); until round 4 a second, register-capped compilation
+    of the kernel text guaranteed this."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import subprocess
+    import kernel_resources as kr
+    build = os.path.join(os.path.dirname(capi.LIB_PATH), "..", "csrc", "build")
+    def demangled(path):
+        out = {}
+        for k in kr.kernels(path):
+            if "vgpr_count" in k:
+                name = subprocess.run(["c++filt", k["name"]], capture_output=True, text=True).stdout.strip()
+                out[name] = k
+        return out
+    wave = demangled(os.path.join(build, "control_wave_kernel.o"))
+    seen = 0
+    for name, k in wave.items():
+        if "control_wave_kernel<double, " in name and (", 10, " in name or ", 5, " in name):
+            assert int(k["vgpr_count"]) <= 120 and int(k["private_segment_fixed_size"]) == 0, (name, k)
+            seen += 1
+    assert seen == 8   # 2 models x K in {5, 10} x stage outputs on / off
+    sums = [k for n, k in demangled(os.path.join(build, "control_kernel.o")).items() if "ck_records_sum_kernel" in n]
+    assert len(sums) == 2 and all(int(k["vgpr_count"]) <= 32 and int(k["group_segment_fixed_size"]) == 0 for k in sums), sums

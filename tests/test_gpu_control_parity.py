@@ -32,7 +32,7 @@ def run_batch_vs_oracle(model, K, horizon, dt, B, n_mem, calls, seed, precision=
                         tol=TOL, tol_ck=TOL_CK, bounds=MAP_BOUNDS, means=MEANS, sigmas=SIGMAS, tol_u_rho=0.0,
                         stages=True):
     """stages=False: no per-stage output pointers are passed, which selects the kernel instances compiled WITHOUT the
-    stage outputs -- the ones bench.py times (the lean fp64 K <= 10 instance among them, control_wave_kernel.hip); c_k,
+    stage outputs -- the ones bench.py times (STAGES = false, control_wave_kernel.hip); c_k,
     the warm-start matrix ut (every step's control: the view of the co-state that is left) and u0 are compared, on the
     same bars as with stages.
     tol_u_rho (fp32 runs only): u = clamp(-Rinv B^T rho) inherits the co-state's ABSOLUTE rounding error wherever

@@ -34,7 +34,7 @@ def _inputs(model, eng, B, n_steps, n_mem, seed, tdt=torch.float64):
 
 
 @pytest.mark.parametrize("model,K,horizon,n_mem,precision", [
-    ("simple_cart", 10, 20.0, 0, capi.PREC_F64),    # the metric point: lean instance
+    ("simple_cart", 10, 20.0, 0, capi.PREC_F64),    # the metric point
     ("omni", 10, 19.5, 40, capi.PREC_F64),          # cooperative last slot + replay memory
     ("omni", 5, 0.5, 0, capi.PREC_F64),             # config 1
     ("omni", 20, 5.0, 0, capi.PREC_F32),            # config 3 shape, fp32

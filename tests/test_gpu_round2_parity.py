@@ -348,7 +348,7 @@ def test_consensus_pass_device_bound_exchange(lag, rccl, K, horizon):
     host wait, no stream wait, no event anywhere: the record sum polls the agents' ready marks, the consuming kernels poll
     the exchange's flag right before the first use of c_bar.  Bitwise the synchronised sequence after 9 passes, lag 1
     (the previous pass's c_bar), 2 and 4; local communicator and a real one-rank RCCL communicator (sum -> ncclAllReduce
-    -> publish); the wavefront kernel (lean instance) and the workgroup kernel (K = 30).  No agent may report a timeout."""
+    -> publish); the wavefront kernel and the workgroup kernel (K = 30).  No agent may report a timeout."""
     rng = np.random.default_rng(23)
     B, G, NB, passes = 300, 2, 6, 9
     eng, _ = make_pair("omni", K, horizon, n_oracles=0)

@@ -2,9 +2,10 @@
 
 Every stage-wise parity test passes stage output pointers, which selects the instances compiled with STAGES = true
 (csrc/control_wave_kernel.hip launch_control_wave).  The headline of bench.py runs the instances WITHOUT stage outputs --
-for fp64, K <= 10 the separately compiled "lean" instance (register cap, last-slot basis sines parked in LDS), and in the
-consensus leg that instance with per-agent sum records out (d_ck_rec) and ONE sum record in (d_ck_shared,
-ck_shared_parts = 1).  Same kernel text, but another compilation: these tests run the shape-boundary cases of
+compiled with STAGES = false (until round 4 a separately compiled, register-capped "lean" instance for fp64, K <= 10; now
+one kernel text, one compilation per shape), and in the consensus leg that instance with per-agent sum records out
+(d_ck_rec) and ONE sum record in (d_ck_shared, ck_shared_parts = 1).  Another template instance than the stage-wise
+tests run: these tests run the shape-boundary cases of
 test_gpu_control_parity.py again with stages=False (c_k, the whole warm-start matrix ut and u0 against the oracle, the
 same bars) and the consensus leg's exact form against the oracle's shared-c_k switch
 (reference ergodic_control.hpp:418-451; the oracle's eo_control_set_shared_ck).
@@ -23,7 +24,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("steps", [193, 194, 197, 199, 200, 136, 72])
 def test_timed_top_heavy_horizons_and_cooperative_last_slot(steps):
-    """lean x the cooperative last slot at r = 1, 2, 5, 7, 8 (T = 193 .. 200) and the two / three-slot shapes"""
+    """timed instance x the cooperative last slot at r = 1, 2, 5, 7, 8 (T = 193 .. 200) and the two / three-slot shapes"""
     run_batch_vs_oracle("simple_cart", 10, steps * 0.1, 0.1, B=4, n_mem=0, calls=2, seed=71, stages=False)
     run_batch_vs_oracle("omni", 10, steps * 0.1, 0.1, B=3, n_mem=40, calls=2, seed=72, stages=False)
     run_batch_vs_oracle("omni", 5, steps * 0.1, 0.1, B=3, n_mem=0, calls=2, seed=73, stages=False)
@@ -38,7 +39,7 @@ def test_timed_steps_per_lane_boundaries(steps):
 
 @pytest.mark.parametrize("steps", [2, 3, 4, 29, 32, 33, 36, 37, 66, 72, 73, 125, 129, 140, 141, 217])
 def test_timed_contraction_row_group_boundaries(steps):
-    """K = 10 and K = 5 (the two lean instances), with and without replay memory; K = 10 in fp32 (no-stages instance)"""
+    """K = 10 and K = 5 (the block-contraction instances), with and without replay memory; K = 10 in fp32 (no-stages instance)"""
     run_batch_vs_oracle("simple_cart", 10, steps * 0.125, 0.125, B=3, n_mem=0, calls=2, seed=61, stages=False)
     run_batch_vs_oracle("omni", 5, steps * 0.125, 0.125, B=2, n_mem=30, calls=2, seed=62, stages=False)
     run_batch_vs_oracle("omni", 10, steps * 0.125, 0.125, B=2, n_mem=33, calls=2, seed=64, precision=capi.PREC_F32,
@@ -51,7 +52,7 @@ def test_timed_contraction_row_group_boundaries(steps):
     ("omni", 10, 5.0, 0.1, 7),           # yaml as shipped, memory <= batch
     ("simple_cart", 10, 5.0, 0.1, 100),  # yaml as shipped, full memory batch
     ("omni", 10, 20.0, 0.1, 0),          # metric point, omni
-    ("simple_cart", 10, 20.0, 0.1, 100), # metric point with a full memory batch (lean x n_mem = 100 at T = 200)
+    ("simple_cart", 10, 20.0, 0.1, 100), # metric point with a full memory batch (timed instance x n_mem = 100 at T = 200)
 ])
 def test_timed_baseline_shapes_f64(model, K, horizon, dt, n_mem):
     run_batch_vs_oracle(model, K, horizon, dt, B=6, n_mem=n_mem, calls=3, seed=11, stages=False)
@@ -76,7 +77,7 @@ def test_timed_random_shapes_against_oracle(seed):
     n_mem = int(rng.choice([0, 0, 1, 5, 33, 100]))
     B = 2 if K * K * (steps + n_mem) > 60000 else 4
     run_batch_vs_oracle(model, K, steps * 0.0625, 0.0625, B=B, n_mem=n_mem, calls=2, seed=seed, stages=False)
-    # and the two lean shapes with the same seed's horizon / memory
+    # and the K = 10 shape with the same seed's horizon / memory
     run_batch_vs_oracle(model, 10, steps * 0.0625, 0.0625, B=3, n_mem=n_mem, calls=2, seed=seed + 100, stages=False)
 
 
@@ -84,7 +85,7 @@ def test_timed_random_shapes_against_oracle(seed):
                                                        ("omni", 10, 19.7, 40, 2), ("omni", 5, 19.3, 0, 1),
                                                        ("omni", 20, 5.0, 0, 1), ("omni", 30, 6.0, 0, 1)])
 def test_consensus_leg_exact_form_against_oracle(model, K, horizon, n_mem, lag):
-    """The consensus leg of bench.py as it is launched: NO stage pointers (lean instance at K <= 10), per-agent sum
+    """The consensus leg of bench.py as it is launched: NO stage pointers (the STAGES = false instances), per-agent sum
     records out (d_ck_rec), ONE sum record [sum_a c_k, count, pad] of an earlier pass in (d_ck_shared with
     ck_shared_parts = 1) -- the kernel forms c_bar = sum / count itself.  The oracle is fed that quotient through
     eo_control_set_shared_ck; ut / u0 <= 1e-9, the record's own c_k part against the oracle's c_k <= 1e-11, over four

@@ -29,7 +29,7 @@ PHASES = ["load + shift controls", "heading increments + scan", "heading sin/cos
 
 CASES = {
     # name: (real type, model id, K, T, kernel symbol prefix, lean, WPB, label)
-    "metric": ("double", 1, 10, 200, "_ZN3eea4wave24control_wave_kernel_leanIdLi1ELi10ELb0ELi4E", True, 4,
+    "metric": ("double", 1, 10, 200, "_ZN3eea4wave19control_wave_kernelIdLi1ELi10ELb0ELi4E", False, 4,
                "fp64, SimpleCart, K = 10, T = 200"),
     "k20f32": ("float", 0, 20, 250, "_ZN3eea4wave19control_wave_kernelIfLi0ELi20ELb0ELi4E", False, 4,
                "fp32, Omni, K = 20, T = 250 (BASELINE configs[2])"),
@@ -74,9 +74,7 @@ def main():
     csrc = os.path.join(ROOT, "ergodic_exploration_amd", "csrc")
     # the kernel text with the case's shape as compile-time constants (one receding-horizon step per launch)
     text = open(os.path.join(csrc, "control_wave_impl.hpp")).read()
-    subs = [("    const ControlParams<R> p_arg, const unsigned B, const int S, const int rollout_only)\n{\n"
-             "  (void)p_arg;  // read through the kernel-argument segment below\n",
-             "    const ControlParams<R> p_arg, const unsigned B, const int S_in, const int rollout_in)\n{\n"
+    subs = [("  int S = S_arg, rollout_only = rollout_arg;\n  asm volatile(\"\" : \"+s\"(S), \"+s\"(rollout_only));\n",
              "  constexpr int S = %d;\n  constexpr int rollout_only = 0;\n" % ((TC + 63) // 64)),
             ("  const int n_steps = ((KernArgParams*)__builtin_amdgcn_kernarg_segment_ptr())->n_steps;\n",
              "  constexpr int n_steps = 1;\n"),
@@ -94,12 +92,9 @@ def main():
         f.write(text)
     unit = os.path.join(tmp, "budget_unit.hip")
     with open(unit, "w") as f:
-        if lean:
-            f.write("#define EEA_WAVE_KERNEL_NAME control_wave_kernel_lean\n#define EEA_WAVE_KERNEL_ATTR __attribute__((amdgpu_num_vgpr(60)))\n"
-                    "#define EEA_WAVE_KERNEL_LEAN true\n")
         f.write('#include "budget_impl.hpp"\nnamespace eea {\ntemplate __global__ void wave::%s<%s, %d, %d, false, %d>('
                 "const ControlParams<%s>, const unsigned, const int, const int);\n}\n"
-                % ("control_wave_kernel_lean" if lean else "control_wave_kernel", real, model, KC, wpb, real))
+                % ("control_wave_kernel", real, model, KC, wpb, real))
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-fno-slp-vectorize",
            "-mllvm", "-disable-machine-licm",
            "-I", tmp, "-I", csrc, "-include", os.path.join(ROOT, "tools", "ab", "wave_stamps.hpp"), "-S", "--cuda-device-only",

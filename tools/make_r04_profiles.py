@@ -42,7 +42,7 @@ def main():
     tr = g50["timed_region"]
     rec = {"command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --passes-per-step 2000 "
                       "(default shape: clock spin-up on, two agent groups, 50 receding-horizon steps per launch; tools/profile_r.sh)",
-           "kernel": "control_wave_kernel_lean<double, SimpleCart, 10>", "agents": bench["config"]["agents_per_gpu"],
+           "kernel": "control_wave_kernel<double, SimpleCart, 10, STAGES = false>", "agents": bench["config"]["agents_per_gpu"],
            "T": bench["config"]["horizon_steps"], "K": bench["config"]["num_basis"], "precision": bench["dtype"],
            "steps_per_launch": tr.get("steps_per_launch", 1),
            "agents_per_launch": tr["agents_per_launch"], "concurrent_launches": tr["concurrent_launches"],
@@ -68,7 +68,7 @@ def main():
         apl = tr_["agents_per_launch"]
         pmc = {"agents_per_launch": apl, "steps_per_launch": spl, "T": T, "K": bench["config"]["num_basis"],
                "precision": bench["dtype"], "agents": bench["config"]["agents_per_gpu"],
-               "kernel": "control_wave_kernel_lean<double, SimpleCart, 10> (r04), %d agents x %d receding-horizon steps per launch" % (apl, spl),
+               "kernel": "control_wave_kernel<double, SimpleCart, 10, STAGES = false> (r04), %d agents x %d receding-horizon steps per launch" % (apl, spl),
                "fetch_size_kib": src["pmc_mean_per_dispatch"].get("FETCH_SIZE"),
                "write_size_kib": src["pmc_mean_per_dispatch"].get("WRITE_SIZE"),
                "hbm_read_bytes_x2_corrected": src["hbm_read_bytes_x2_corrected"], "hbm_write_bytes": src["hbm_write_bytes_raw"],

@@ -35,7 +35,7 @@ for model in ("simple_cart", "omni"):
 t2.test_config4_full_size_f32_against_f64_oracle()
 print("BASELINE config 5 end to end (1024^2 occupancy -> phi_k K=30 -> control T=500)")
 t2.test_config5_end_to_end_against_oracle()
-print("round 4: the TIMED instances (no stage outputs: the lean fp64 K <= 10 instance etc.) against the oracle, c_k / ut / u0")
+print("round 4: the TIMED instances (no stage outputs: STAGES = false) against the oracle, c_k / ut / u0")
 from tests import test_gpu_timed_instances as tt  # noqa: E402
 for model, K, hor, dt, n_mem in CASES[:6] + [("omni", 10, 19.3, 0.1, 40), ("simple_cart", 10, 19.9, 0.1, 0)]:
     t.run_batch_vs_oracle(model, K, hor, dt, B=4, n_mem=n_mem, calls=2, seed=21, stages=False)
