@@ -54,6 +54,7 @@ namespace wave
 {
 constexpr int kMaxS = 4;        // steps per lane
 constexpr int kStageRows = 32;  // points staged per matrix-core pass (8 MFMAs)
+constexpr int kRow1 = 68;  // K = 20 fp32 outer-product tile: row stride in elements (= 4 mod 64: consecutive modes 4 banks apart)
 constexpr int kTailScratch = 24;  // [3][8]: cos a, cos b, sin b of the <= 8 points of a cooperative last slot
 
 __host__ __device__ constexpr int tab_stride(int K) { return (K + 1) & ~1; }  // even: 16-byte rows
@@ -67,7 +68,8 @@ __host__ __device__ constexpr int tile_elems(int K)
 {
   // the tiles of the contraction; afterwards D [K^2], the parked barrier gradient [2][kMaxS][64] and kTailScratch reals
   // of hand-over space for the cooperative last slot (inside the tiles' footprint at K = 10)
-  const int t = 2 * kStageRows * tab_stride(K);
+  // (K = 20, fp32: the outer-product form's tile [20 modes][kRow1] -- 32 x points, 32 y points, 4 pad -- is the larger)
+  const int t = (K == 20) ? 20 * kRow1 : 2 * kStageRows * tab_stride(K);
   const int d = d_elems(K) + 2 * kMaxS * kWave + kTailScratch;
   return ((t > d ? t : d) + 3) & ~3;
 }
@@ -137,6 +139,13 @@ __device__ __forceinline__ double mfma4(double a, double b, double c)
   return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ float mfma4(float, float, float c) { return c; }  // fp32 keeps the 16x16x4 form
+
+// v_mfma_f32_4x4x1_16b_f32: sixteen independent 4x4 outer products D_b += a_b b_b^T in 8 cycles, the same multiply-adds
+// per cycle as the 16x16x4 instruction (tools/ubench/mfma4x4x1.hip).  Layout (probed on the MI355X): lane l = 4 b + i
+// supplies a_b[i] and b_b[i]; lane 4 b + j holds column j of D_b, D_b[r][j] in register r.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 mfma1(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 mfma1(double, double, f32x4 c) { return c; }  // (fp64 never takes this form)
 
 // LDS byte address of a pointer into the workgroup's shared memory (for DS instructions written by hand)
 __device__ __forceinline__ unsigned lds_addr(const void* q)
@@ -706,7 +715,72 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
     if (rows_valid > 16) mma4_group(1);  // wavefront-uniform
   };
 
-  if constexpr (kBlock4) {
+  // ---- fp32, K = 17 .. 20: the contraction as 4x4 outer products --------------------------------------------------
+  // Two 16-mode tiles per axis multiply 1024 accumulator entries for the 400 modes of K = 20 (39 %): 256 instructions of
+  // 32 cycles = a third of the agent's pipe time (profiles/r04_k20_f32_isa_budget.txt).  v_mfma_f32_4x4x1_16b multiplies
+  // sixteen independent 4x4 blocks for ONE point in 8 cycles: the 25 pairs (I, J) of 4-mode blocks are the blocks of TWO
+  // instructions per point (25 of 32 blocks in use, 78 %) -- 512 x 8 cycles, half the pipe time, and every accumulator
+  // entry is a complete sum over the points: no rotation at the end.  Block b = 3 I + s of both instructions has the x
+  // modes 4 I .. 4 I + 3 (ONE A operand for both), and the y blocks J = s (first instruction) and J = 4 - s (second;
+  // s = 2: none, its second block and block 15 multiply something finite that nobody reads).
+  // Tile: [mode][kRow1] with 32 x points, then 32 y points per row, so that one ds_read_b128 brings a lane's mode for
+  // FOUR points: 3 reads per 8 instructions.  kRow1 = 4 mod 64 puts consecutive modes 4 banks apart; modes m and
+  // m + 16 share banks, and no group of 16 lanes reads both: a group holds <= 2 consecutive x blocks, y blocks {0,1,2}
+  // in the first and {4,3} in the second instruction.
+  constexpr bool kBlock1 = sizeof(R) == 4 && KC == 20;
+  f32x4 bacc1 = f32x4{ 0, 0, 0, 0 }, bacc2 = bacc1;
+  const int b1blk = (lane >> 2) < 14 ? (lane >> 2) : 14, b1i = lane & 3;
+  const int b1I = b1blk / 3, b1s = b1blk - 3 * b1I;
+  const int b1J1 = b1s, b1J2 = b1s < 2 ? 4 - b1s : 3;
+  const R* const op1A = tabx + (4 * b1I + b1i) * kRow1;
+  const R* const op1B1 = tabx + (4 * b1J1 + b1i) * kRow1 + 32;
+  const R* const op1B2 = tabx + (4 * b1J2 + b1i) * kRow1 + 32;
+  // pass over the points of half h of the wavefront (the first nl_valid lanes of the wavefront hold a valid point):
+  // lanes 0..31 run the recurrence of one axis of their row's point, lanes 32..63 the other axis (stage_cos), one
+  // 4-byte store per mode; then the valid groups of 4 points
+  auto stage_and_mma1 = [&](R c_axis, int h, int nl_valid) {
+    if constexpr (kBlock1) {
+      {
+        Tab1 t = tab1_init(c_axis, 32 * h + row < nl_valid);
+        R* const dst = tabx + ((lo ? h : 1 - h) ? 32 : 0) + row;  // (stage_cos: lower lanes x in h = 0, y in h = 1)
+#pragma unroll
+        for (int q = 0; q < 10; ++q) {
+          dst[(2 * q) * kRow1] = t.a;
+          dst[(2 * q + 1) * kRow1] = t.b;
+          tab1_step(t);
+        }
+      }
+      const int rows_valid = nl_valid - 32 * h;  // > 0
+      lds_fence();
+#pragma unroll
+      for (int g = 0; g < kStageRows / 4; ++g) {
+        if (4 * g < rows_valid) {  // wavefront-uniform
+          const f32x4 a = *reinterpret_cast<const f32x4*>(op1A + 4 * g);
+          const f32x4 y1 = *reinterpret_cast<const f32x4*>(op1B1 + 4 * g);
+          const f32x4 y2 = *reinterpret_cast<const f32x4*>(op1B2 + 4 * g);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            bacc1 = mfma1(a[q], y1[q], bacc1);
+            bacc2 = mfma1(a[q], y2[q], bacc2);
+          }
+        }
+      }
+      lds_fence();
+    }
+  };
+
+  if constexpr (kBlock1) {
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      if (j < S) {
+        const int nl = lanes_in_slot(j);
+        R cl, cu;
+        stage_cos(c1x[j], c1y[j], cl, cu);
+        stage_and_mma1(cl, 0, nl);
+        if (nl > 32) stage_and_mma1(cu, 1, nl);
+      }
+    }
+  } else if constexpr (kBlock4) {
     // Rollout points, software-pipelined as below: the operands of a pass (12 reads) are read first, then the tile is
     // free and the recurrence + stores of the NEXT pass are issued between the matrix instructions of the first
     // 16-row group (pinned with scheduling barriers); the second group is skipped when it holds no valid point.
@@ -882,7 +956,10 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
       const int nl = nmem - c0;  // > 0
       R cl, cu;
       stage_cos(ca, cb, cl, cu);
-      if constexpr (kBlock4) {
+      if constexpr (kBlock1) {
+        stage_and_mma1(cl, 0, nl);
+        if (nl > 32) stage_and_mma1(cu, 1, nl);
+      } else if constexpr (kBlock4) {
         stage_and_mma4(cl, 0, nl);
         if (nl > 32) stage_and_mma4(cu, 1, nl);
       } else {
@@ -892,7 +969,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
     }
   }
 
-  if constexpr (!kBlock4) load_lam_phi();
+  if constexpr (!kBlock4 && !kBlock1) load_lam_phi();
   EEA_WSTAMP(5);
   // the agent's sum record (eea_batch_io::d_ck_rec): c_k is in s_D [0, K^2) (before D takes the place), element K^2 = 1
   // (this agent counts), pad 0; read back one element per lane: coalesced stores to p.ck_rec [b]
@@ -982,6 +1059,48 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
       // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
       if (use_shared) cv[t] = shared_ck_value(p, ck_shared_step, idx[t], K2, cv[t]);
       if (okv[t]) s_D[idx[t]] = lamv[t] * (cv[t] - phiv[t]);
+    }
+    lds_fence();
+  } else if constexpr (kBlock1) {
+    // lane 4 b + j, register r of the first (second) accumulator: c(k1 = 4 I + r, k2 = 4 J1 (J2) + j), complete
+    const R invN = R(1) / static_cast<R>(N);
+    const bool blk_ok = (lane >> 2) < 15;
+    R cv[2][4], lamv[2][4], phiv[2][4];
+    int idx[2][4];
+    bool okv[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int k2 = 4 * (t ? b1J2 : b1J1) + b1i;
+      const bool tv = blk_ok && (t == 0 || b1s < 2) && k2 < K;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int k1 = 4 * b1I + r;
+        okv[t][r] = tv && k1 < K;
+        idx[t][r] = okv[t][r] ? k2 * K + k1 : 0;
+        lamv[t][r] = p.lamdak[idx[t][r]];
+        phiv[t][r] = p.phik[idx[t][r]];
+        cv[t][r] = invN * static_cast<R>(t ? bacc2[r] : bacc1[r]);
+        if (p.ck != nullptr && okv[t][r]) p.ck[static_cast<size_t>(b) * K2 + idx[t][r]] = cv[t][r];
+      }
+    }
+    if (ck_rec_step != nullptr) {  // wavefront-uniform
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          if (okv[t][r]) s_D[idx[t][r]] = cv[t][r];
+        }
+      }
+      publish_record();
+    }
+    const bool use_shared = bind_shared_ck();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (use_shared) cv[t][r] = shared_ck_value(p, ck_shared_step, idx[t][r], K2, cv[t][r]);
+        if (okv[t][r]) s_D[idx[t][r]] = lamv[t][r] * (cv[t][r] - phiv[t][r]);
+      }
     }
     lds_fence();
   } else {

@@ -1,0 +1,107 @@
+// Microbenchmark (gfx950): v_mfma_f32_4x4x1_16b_f32 -- sixteen independent 4x4 outer products per instruction.
+// Operand layout (two probe runs: A = lane + 1, B = 1 and A = 1, B = lane + 1) and throughput with 1 / 2 / 4
+// independent accumulators, alone and against co-resident v_pk_fma_f32, and v_mfma_f32_16x16x4_f32 for comparison.
+// hipcc --offload-arch=gfx950 -O3 -o mfma4x4x1 mfma4x4x1.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__global__ void probe(float* out)
+{
+  const int lane = threadIdx.x;
+  const f4 z = f4{ 0, 0, 0, 0 };
+  const f4 da = __builtin_amdgcn_mfma_f32_4x4x1f32(static_cast<float>(lane + 1), 1.0f, z, 0, 0, 0);
+  const f4 db = __builtin_amdgcn_mfma_f32_4x4x1f32(1.0f, static_cast<float>(lane + 1), z, 0, 0, 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    out[(0 * 64 + lane) * 4 + r] = da[r];
+    out[(1 * 64 + lane) * 4 + r] = db[r];
+  }
+}
+
+// NM matrix instructions on NACC accumulators + NV packed fp32 multiply-adds per iteration
+template <int KIND, int NM, int NACC, int NV>
+__global__ void rate(float* out, long long* cyc, int iters, float a, float b)
+{
+  f4 acc[NACC];
+#pragma unroll
+  for (int c = 0; c < NACC; ++c) acc[c] = f4{ 0, 0, 0, 0 };
+  f2 v[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = f2{ a * (c + 1) + threadIdx.x, b };
+  const f2 b2 = f2{ b, b }, a2 = f2{ a, a };
+  const float av = a + threadIdx.x, bv = b - threadIdx.x;
+  __syncthreads();
+  const long long t0 = __builtin_readcyclecounter();
+#pragma unroll 1
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      if (KIND == 0) acc[m % NACC] = __builtin_amdgcn_mfma_f32_4x4x1f32(av, bv, acc[m % NACC], 0, 0, 0);
+      else acc[m % NACC] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, acc[m % NACC], 0, 0, 0);
+    }
+#pragma unroll
+    for (int c = 0; c < NV; ++c) v[c & 7] = __builtin_elementwise_fma(v[c & 7], b2, a2);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  asm volatile("s_nop 0" ::: "memory");
+  const long long t1 = __builtin_readcyclecounter();
+  float s = 0;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) s += v[c].x + v[c].y;
+#pragma unroll
+  for (int c = 0; c < NACC; ++c) s += acc[c][0] + acc[c][1] + acc[c][2] + acc[c][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+  if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * (blockDim.x / 64) + threadIdx.x / 64] = t1 - t0;
+}
+
+int main()
+{
+  hipDeviceProp_t p;
+  (void)hipGetDeviceProperties(&p, 0);
+  const int cus = p.multiProcessorCount;
+  float* d_probe;
+  (void)hipMalloc(&d_probe, sizeof(float) * 512);
+  hipLaunchKernelGGL(probe, dim3(1), dim3(64), 0, 0, d_probe);
+  std::vector<float> pr(512);
+  (void)hipMemcpy(pr.data(), d_probe, sizeof(float) * 512, hipMemcpyDeviceToHost);
+  printf("# v_mfma_f32_4x4x1_16b_f32 probe: D[lane][vgpr] = A(lane x) * B(lane y): the A lane and the B lane of every entry\n");
+  for (int l = 0; l < 64; ++l) {
+    printf("D lane %2d:", l);
+    for (int r = 0; r < 4; ++r) printf("  v%d = A%02d x B%02d", r, static_cast<int>(pr[l * 4 + r]) - 1, static_cast<int>(pr[(64 + l) * 4 + r]) - 1);
+    printf("\n");
+  }
+  float* out;
+  long long* cyc;
+  (void)hipMalloc(&out, sizeof(float) * 1024 * cus);
+  (void)hipMalloc(&cyc, sizeof(long long) * 16 * cus);
+  const int iters = 2000;
+  std::vector<long long> h(16 * cus);
+#define RATE(KIND, NM, NACC, NV, WAVES, WHAT)                                                                   \
+  do {                                                                                                          \
+    for (int r = 0; r < 2; ++r)                                                                                 \
+      hipLaunchKernelGGL((rate<KIND, NM, NACC, NV>), dim3(cus), dim3(64 * WAVES), 0, 0, out, cyc, iters, 1.0f, 0.5f); \
+    (void)hipDeviceSynchronize();                                                                               \
+    (void)hipMemcpy(h.data(), cyc, sizeof(long long) * WAVES * cus, hipMemcpyDeviceToHost);                     \
+    double s = 0;                                                                                               \
+    for (int i = 0; i < WAVES * cus; ++i) s += static_cast<double>(h[i]);                                       \
+    printf("%-64s %2d wavefront(s) per SIMD: %7.1f cycles per iteration and wavefront\n", WHAT, WAVES / 4,      \
+           s / (WAVES * cus) / iters);                                                                          \
+  } while (0)
+  RATE(0, 8, 1, 0, 4, "8 x 4x4x1_16b, 1 accumulator (dependent)");
+  RATE(0, 8, 2, 0, 4, "8 x 4x4x1_16b, 2 accumulators");
+  RATE(0, 8, 4, 0, 4, "8 x 4x4x1_16b, 4 accumulators");
+  RATE(0, 8, 8, 0, 4, "8 x 4x4x1_16b, 8 accumulators");
+  RATE(0, 8, 2, 0, 16, "8 x 4x4x1_16b, 2 accumulators");
+  RATE(0, 8, 4, 0, 16, "8 x 4x4x1_16b, 4 accumulators");
+  RATE(1, 4, 4, 0, 4, "4 x 16x16x4, 4 accumulators");
+  RATE(1, 4, 4, 0, 16, "4 x 16x16x4, 4 accumulators");
+  RATE(0, 0, 1, 16, 4, "16 v_pk_fma_f32");
+  RATE(0, 8, 4, 16, 4, "8 x 4x4x1_16b (4 acc) + 16 v_pk_fma_f32, same wavefront");
+  RATE(0, 8, 4, 16, 16, "8 x 4x4x1_16b (4 acc) + 16 v_pk_fma_f32, same wavefront");
+  RATE(0, 0, 1, 16, 16, "16 v_pk_fma_f32");
+  return 0;
+}
