@@ -715,7 +715,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
     if (rows_valid > 16) mma4_group(1);  // wavefront-uniform
   };
 
-  // ---- fp32, K = 17 .. 20: the contraction as 4x4 outer products --------------------------------------------------
+  // ---- fp32, K = 20: the contraction as 4x4 outer products --------------------------------------------------
   // Two 16-mode tiles per axis multiply 1024 accumulator entries for the 400 modes of K = 20 (39 %): 256 instructions of
   // 32 cycles = a third of the agent's pipe time (profiles/r04_k20_f32_isa_budget.txt).  v_mfma_f32_4x4x1_16b multiplies
   // sixteen independent 4x4 blocks for ONE point in 8 cycles: the 25 pairs (I, J) of 4-mode blocks are the blocks of TWO
@@ -1162,8 +1162,106 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   // tools/ubench/exec_mask.hip); instead all 64 lanes take them together, 8 lanes per step (below the loop).
   constexpr bool kCoopTail = sizeof(R) == 8 && (KC == 10 || KC == 5);
   const bool coop_tail = kCoopTail && top_heavy && S == kMaxS;  // wavefront-uniform
+  // fp32, K = 20 (BASELINE configs[2]): TWO steps of the lane at a time, every operation of the pass PACKED over the pair
+  // (v_pk_fma_f32: (G_j(k1), G_j+1(k1)) += D(k1,k2) (cos b_k2 y_j, cos b_k2 y_j+1) with the element of D as the scalar
+  // of both halves, likewise H, the four Chebyshev recurrences and the weighted sums).  Round 3's form packed pairs of x
+  // MODES of one step: its recurrences and weighted sums (a third of the gradient's instructions) stayed scalar, at half
+  // the packed rate.  The second step of a pair beyond S runs on zeros and is dropped.
+  constexpr bool kPairGrad = sizeof(R) == 4 && KC == 20;
+  if constexpr (kPairGrad) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    auto splat = [](float v) { return f2{ v, v }; };
+#pragma unroll
+    for (int jp = 0; jp < kMaxS; jp += 2) {
+      if (STAGES) ex[jp] = ey[jp] = ex[jp + 1] = ey[jp + 1] = R(0);
+      asm volatile("" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
+      if (jp < S) {  // wavefront-uniform
+        constexpr int KB = grad_block(KC);
+        const f2 cxp = f2{ static_cast<float>(c1x[jp]), static_cast<float>(c1x[jp + 1]) };
+        const f2 cyp = f2{ static_cast<float>(c1y[jp]), static_cast<float>(c1y[jp + 1]) };
+        const f2 twox = cxp + cxp, twoy = cyp + cyp;
+        f2 accx = splat(0.0f), accy = splat(0.0f);
+        f2 ta = splat(1.0f), tb = cxp;            // T_k, T_{k+1} of the x angles at the block's first mode
+        f2 ua = splat(0.0f), ub = splat(1.0f);    // U_{k-1}, U_k
+#pragma unroll
+        for (int kb0 = 0; kb0 < KC; kb0 += KB) {
+          if (kb0 > 0) {  // one block at a time (registers)
+            asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          f2 cx2[KB], G2[KB];
+#pragma unroll
+          for (int i = 0; i < KB; ++i) {
+            cx2[i] = ta;
+            const f2 tn = __builtin_elementwise_fma(twox, tb, -ta);
+            ta = tb;
+            tb = tn;
+          }
+          // row k2 = 0: cos(0 y) = 1 and k2 sin(0) = 0: only G takes part (k1 = 0 is not special-cased: cos(0 x) = 1 is
+          // in the table and G(0) is never used)
+#pragma unroll
+          for (int q = 0; q < KB / 2; ++q) {
+            const f2 d = *reinterpret_cast<const f2*>(s_D + kb0 + 2 * q);
+            G2[2 * q] = splat(d.x);
+            G2[2 * q + 1] = splat(d.y);
+          }
+          f2 um = splat(0.0f), u0 = splat(1.0f);  // U_{k2-2}, U_{k2-1} of the y angles
+          f2 tm = splat(1.0f), t0 = cyp;          // T_{k2-1}, T_{k2}
+#pragma unroll
+          for (int k2 = 1; k2 < KC; ++k2) {
+            if (k2 < K) {  // wavefront-uniform, always true (kRowGuard)
+              const R* const row = s_D + k2 * K + kb0;
+              f2 h2;
+#pragma unroll
+              for (int q = 0; q < KB / 2; ++q) {
+                const f2 d = *reinterpret_cast<const f2*>(row + 2 * q);  // D(k1, k2), D(k1 + 1, k2): rows start even
+                G2[2 * q] = __builtin_elementwise_fma(splat(d.x), t0, G2[2 * q]);
+                h2 = (q == 0) ? splat(d.x) * cx2[0] : __builtin_elementwise_fma(splat(d.x), cx2[2 * q], h2);
+                G2[2 * q + 1] = __builtin_elementwise_fma(splat(d.y), t0, G2[2 * q + 1]);
+                h2 = __builtin_elementwise_fma(splat(d.y), cx2[2 * q + 1], h2);
+              }
+              accy = __builtin_elementwise_fma(u0 * splat(static_cast<float>(k2)), h2, accy);
+              const f2 un = __builtin_elementwise_fma(twoy, u0, -um);
+              um = u0;
+              u0 = un;
+              const f2 tn = __builtin_elementwise_fma(twoy, t0, -tm);
+              tm = t0;
+              t0 = tn;
+            }
+          }
+          // edx_x: sum_k1 k1 U_{k1-1}(cos a x) G(k1) over this block
+#pragma unroll
+          for (int i = 0; i < KB; ++i) {
+            const int k1 = kb0 + i;
+            if (k1 > 0) accx = __builtin_elementwise_fma(ua * splat(static_cast<float>(k1)), G2[i], accx);
+            const f2 un = __builtin_elementwise_fma(twox, ub, -ua);
+            ua = ub;
+            ub = un;
+          }
+        }
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+          const int j = jp + e;
+          if (j < S) {  // wavefront-uniform
+            const R exj = (-p.pi_lx * s1x[j] * static_cast<R>(e ? accx.y : accx.x)) * p.expl_weight;
+            const R eyj = (-p.pi_ly * s1y[j] * static_cast<R>(e ? accy.y : accy.x)) * p.expl_weight;
+            if (STAGES) {
+              ex[j] = exj;
+              ey[j] = eyj;
+            } else {
+              const bool act = j < cnt;
+              g0[j] = act ? exj + s_g[(2 * j + 0) * kWave + lane] : R(0);
+              g1[j] = act ? eyj + s_g[(2 * j + 1) * kWave + lane] : R(0);
+            }
+          }
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int j = 0; j < kMaxS; ++j) {
+    if (kPairGrad) break;
     if (STAGES) ex[j] = ey[j] = R(0);
     // one step at a time: the rows of D are re-read per step; without the fence the compiler keeps them (and
     // the arrays of all four steps) in registers across the unrolled steps and spills
@@ -1191,52 +1289,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
           ta = tb;
           tb = tn;
         }
-        if constexpr (sizeof(R) == 4 && KC == 20) {
-          // fp32, K = 20 (the BASELINE config 3 shape; at K = 10 the packed form spills and is 4 % slower): the two
-          // multiply-adds per element of D as PACKED operations on pairs of x modes
-          // (v_pk_fma_f32) -- (G(k1), G(k1+1)) += (d, d') cos(b_k2 y) and (ha, hb) += (d, d') (cos a_k1 x, cos a_k1+1 x):
-          // the even / odd chains of the scalar form are the two halves of the pair, the pairs of D come out of LDS
-          // as they lie (rows start at even offsets).  k1 = 0 is not special-cased: cos(0 x) = 1 is in the table and
-          // G(0) is never used.
-          typedef float f2 __attribute__((ext_vector_type(2)));
-          constexpr int KP = KB / 2;
-          f2 cx2[KP], G2[KP];
-#pragma unroll
-          for (int q = 0; q < KP; ++q) {
-            cx2[q] = f2{ static_cast<float>(cxa[2 * q]), static_cast<float>(cxa[2 * q + 1]) };
-            G2[q] = *reinterpret_cast<const f2*>(s_D + kb0 + 2 * q);  // row k2 = 0: cos(0 y) = 1
-          }
-          float um = 0.0f, u0 = 1.0f;                          // U_{k2-2}, U_{k2-1} of the y angle
-          // T_{k2-1}, T_{k2} kept as pairs of equal halves: the recurrence is one packed instruction and the G
-          // updates need no broadcast to build
-          const f2 two2 = f2{ static_cast<float>(twoy), static_cast<float>(twoy) };
-          f2 tm2 = f2{ 1.0f, 1.0f }, t02 = f2{ static_cast<float>(c1y[j]), static_cast<float>(c1y[j]) };
-#pragma unroll
-          for (int k2 = 1; k2 < KA; ++k2) {
-            if (!kRowGuard || k2 < K) {  // wavefront-uniform
-              const R* const row = s_D + k2 * K + kb0;
-              f2 h2;
-#pragma unroll
-              for (int q = 0; q < KP; ++q) {
-                const f2 d = *reinterpret_cast<const f2*>(row + 2 * q);
-                G2[q] = __builtin_elementwise_fma(d, t02, G2[q]);
-                h2 = (q == 0) ? d * cx2[q] : __builtin_elementwise_fma(d, cx2[q], h2);
-              }
-              accy = fma_k(static_cast<R>(u0 * (h2.x + h2.y)), k2, accy);
-              const float un = static_cast<float>(twoy) * u0 - um;
-              um = u0;
-              u0 = un;
-              const f2 tn2 = __builtin_elementwise_fma(two2, t02, -tm2);
-              tm2 = t02;
-              t02 = tn2;
-            }
-          }
-#pragma unroll
-          for (int q = 0; q < KP; ++q) {
-            G[2 * q] = static_cast<R>(G2[q].x);
-            G[2 * q + 1] = static_cast<R>(G2[q].y);
-          }
-        } else {
+        {
         // row k2 = 0: cos(0 y) = 1 and k2 sin(0) = 0: only G takes part (G(0) is never used: k1 sin(0) = 0)
         {
           const R* const row = s_D + kb0;

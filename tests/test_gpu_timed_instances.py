@@ -71,10 +71,12 @@ def test_timed_config3_shape_f64_and_f32():
 @pytest.mark.parametrize("K", [17, 18, 19, 20])
 @pytest.mark.parametrize("steps,n_mem", [(250, 0), (200, 100), (64, 33), (37, 1), (3, 0), (129, 65)])
 def test_fp32_outer_product_contraction_shapes(K, steps, n_mem):
-    """fp32, K = 17 .. 20 (the instance of BASELINE config 3): c_k by 4x4 outer products (v_mfma_f32_4x4x1, two
-    instructions per point: control_wave_impl.hpp, kBlock1) -- every K the instance serves, full and partial point
-    groups, replay-memory columns (full 64-column rounds, a partial one, a single column), with stage outputs and without,
-    against the fp64 oracle at the fp32 bars of test_config3_shape_f64_and_f32"""
+    """fp32, K = 20 (the wavefront instance of BASELINE config 3): c_k by 4x4 outer products (v_mfma_f32_4x4x1, two
+    instructions per point: control_wave_impl.hpp, kBlock1) and the gradient packed over pairs of steps (kPairGrad) --
+    full and partial point groups, one to four steps per lane (odd counts: the second step of a pair is dropped),
+    replay-memory columns (full 64-column rounds, a partial one, a single column), with stage outputs and without, against
+    the fp64 oracle at the fp32 bars of test_config3_shape_f64_and_f32.  K = 17 .. 19 next to it: the neighbours of
+    the shape run the workgroup-per-agent kernel in fp32 (the engine's choice, csrc/control_wave_kernel.hip)."""
     model = "omni" if (K + steps) % 2 else "simple_cart"
     for stages in (True, False):
         run_batch_vs_oracle(model, K, steps * 0.02, 0.02, B=3, n_mem=n_mem, calls=2, seed=100 * K + steps,
