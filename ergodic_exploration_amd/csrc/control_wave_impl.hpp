@@ -1062,45 +1062,40 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
     }
     lds_fence();
   } else if constexpr (kBlock1) {
-    // lane 4 b + j, register r of the first (second) accumulator: c(k1 = 4 I + r, k2 = 4 J1 (J2) + j), complete
+    // lane 4 b + j, register r of the first (second) accumulator: c(k1 = 4 I + r, k2 = 4 J1 (J2) + j), complete.  The
+    // four registers are four consecutive modes of row k2 (K = 20: 16-byte aligned): lambda_k, phi_k and D in fours
     const R invN = R(1) / static_cast<R>(N);
     const bool blk_ok = (lane >> 2) < 15;
-    R cv[2][4], lamv[2][4], phiv[2][4];
-    int idx[2][4];
-    bool okv[2][4];
+    f32x4 cv[2], lamv[2], phiv[2];
+    int idx[2];
+    bool okv[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const int k2 = 4 * (t ? b1J2 : b1J1) + b1i;
-      const bool tv = blk_ok && (t == 0 || b1s < 2) && k2 < K;
+      okv[t] = blk_ok && (t == 0 || b1s < 2);
+      idx[t] = okv[t] ? (4 * (t ? b1J2 : b1J1) + b1i) * KC + 4 * b1I : 0;
+      lamv[t] = *reinterpret_cast<const f32x4*>(p.lamdak + idx[t]);
+      phiv[t] = *reinterpret_cast<const f32x4*>(p.phik + idx[t]);
+      cv[t] = (t ? bacc2 : bacc1) * static_cast<float>(invN);
+      if (p.ck != nullptr && okv[t]) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int k1 = 4 * b1I + r;
-        okv[t][r] = tv && k1 < K;
-        idx[t][r] = okv[t][r] ? k2 * K + k1 : 0;
-        lamv[t][r] = p.lamdak[idx[t][r]];
-        phiv[t][r] = p.phik[idx[t][r]];
-        cv[t][r] = invN * static_cast<R>(t ? bacc2[r] : bacc1[r]);
-        if (p.ck != nullptr && okv[t][r]) p.ck[static_cast<size_t>(b) * K2 + idx[t][r]] = cv[t][r];
+        for (int r = 0; r < 4; ++r) p.ck[static_cast<size_t>(b) * K2 + idx[t] + r] = cv[t][r];
       }
     }
     if (ck_rec_step != nullptr) {  // wavefront-uniform
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          if (okv[t][r]) s_D[idx[t][r]] = cv[t][r];
-        }
+        if (okv[t]) *reinterpret_cast<f32x4*>(s_D + idx[t]) = cv[t];
       }
       publish_record();
     }
     const bool use_shared = bind_shared_ck();
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
+      if (use_shared) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        if (use_shared) cv[t][r] = shared_ck_value(p, ck_shared_step, idx[t][r], K2, cv[t][r]);
-        if (okv[t][r]) s_D[idx[t][r]] = lamv[t][r] * (cv[t][r] - phiv[t][r]);
+        for (int r = 0; r < 4; ++r) cv[t][r] = shared_ck_value(p, ck_shared_step, idx[t] + r, K2, static_cast<R>(cv[t][r]));
       }
+      if (okv[t]) *reinterpret_cast<f32x4*>(s_D + idx[t]) = lamv[t] * (cv[t] - phiv[t]);
     }
     lds_fence();
   } else {

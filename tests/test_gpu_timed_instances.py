@@ -96,10 +96,12 @@ def test_timed_random_shapes_against_oracle(seed):
     run_batch_vs_oracle(model, 10, steps * 0.0625, 0.0625, B=3, n_mem=n_mem, calls=2, seed=seed + 100, stages=False)
 
 
-@pytest.mark.parametrize("model,K,horizon,n_mem,lag", [("simple_cart", 10, 20.0, 0, 1), ("omni", 10, 20.0, 0, 1),
-                                                       ("omni", 10, 19.7, 40, 2), ("omni", 5, 19.3, 0, 1),
-                                                       ("omni", 20, 5.0, 0, 1), ("omni", 30, 6.0, 0, 1)])
-def test_consensus_leg_exact_form_against_oracle(model, K, horizon, n_mem, lag):
+@pytest.mark.parametrize("model,K,horizon,n_mem,lag,precision", [
+    ("simple_cart", 10, 20.0, 0, 1, capi.PREC_F64), ("omni", 10, 20.0, 0, 1, capi.PREC_F64),
+    ("omni", 10, 19.7, 40, 2, capi.PREC_F64), ("omni", 5, 19.3, 0, 1, capi.PREC_F64),
+    ("omni", 20, 5.0, 0, 1, capi.PREC_F64), ("omni", 30, 6.0, 0, 1, capi.PREC_F64),
+    ("omni", 20, 5.0, 33, 1, capi.PREC_F32), ("simple_cart", 10, 5.0, 7, 1, capi.PREC_F32)])
+def test_consensus_leg_exact_form_against_oracle(model, K, horizon, n_mem, lag, precision):
     """The consensus leg of bench.py as it is launched: NO stage pointers (the STAGES = false instances), per-agent sum
     records out (d_ck_rec), ONE sum record [sum_a c_k, count, pad] of an earlier pass in (d_ck_shared with
     ck_shared_parts = 1) -- the kernel forms c_bar = sum / count itself.  The oracle is fed that quotient through
@@ -107,20 +109,23 @@ def test_consensus_leg_exact_form_against_oracle(model, K, horizon, n_mem, lag):
     passes (the first `lag` without a shared c_k), two agent groups as in the bench."""
     rng = np.random.default_rng(4242)
     B = 6
-    eng, ors = make_pair(model, K, horizon, n_oracles=B)
+    f32 = precision == capi.PREC_F32
+    tdt = torch.float32 if f32 else torch.float64
+    tol, tol_ck = (5e-4, 1e-5) if f32 else (TOL, TOL_CK)   # fp32 engine against the fp64 oracle: the fp32 bars
+    eng, ors = make_pair(model, K, horizon, n_oracles=B, precision=precision)
     T, K2, L = eng.T, eng.K2, eng.ck_record_len
     poses = random_poses(rng, B)
     ut0 = rng.uniform(-0.5, 0.5, (B, T, 3))
     if model == "simple_cart":
         ut0[:, :, 1] = 0.0
     mem = random_poses(rng, B * n_mem).reshape(B, n_mem, 3) if n_mem else None
-    d_pose, d_ut = dev(poses), dev(ut0)
-    d_u0 = torch.empty((B, 3), dtype=torch.float64, device="cuda")
-    d_mem = dev(mem) if n_mem else None
+    d_pose, d_ut = dev(poses, tdt), dev(ut0, tdt)
+    d_u0 = torch.empty((B, 3), dtype=tdt, device="cuda")
+    d_mem = dev(mem, tdt) if n_mem else None
     d_nmem = torch.full((B,), n_mem, dtype=torch.int32, device="cuda") if n_mem else None
     passes = 4
-    arec = [torch.full((B, L), float("nan"), dtype=torch.float64, device="cuda") for _ in range(passes)]
-    sums = [torch.full((L,), float("nan"), dtype=torch.float64, device="cuda") for _ in range(passes)]
+    arec = [torch.full((B, L), float("nan"), dtype=tdt, device="cuda") for _ in range(passes)]
+    sums = [torch.full((L,), float("nan"), dtype=tdt, device="cuda") for _ in range(passes)]
     for b in range(B):
         ors[b].ut = ut0[b].T
     gb = [0, 4, B]
@@ -135,17 +140,20 @@ def test_consensus_leg_exact_form_against_oracle(model, K, horizon, n_mem, lag):
                               ck_shared=sums[src] if src >= 0 else None, ck_shared_parts=1 if src >= 0 else 0)
         eng.ck_records_sum(B, arec[i], sums[i])
         torch.cuda.synchronize()
-        rec = arec[i].cpu().numpy()
-        s = sums[i].cpu().numpy()
+        rec = arec[i].cpu().numpy().astype(np.float64)
+        s = sums[i].cpu().numpy().astype(np.float64)
         assert s[K2] == B and (rec[:, K2] == 1).all()
         cbar = None
         if src >= 0:
-            sp = sums[src].cpu().numpy()
+            sp = sums[src].cpu().numpy().astype(np.float64)
             cbar = sp[:K2] / sp[K2]
-        ut, u0 = d_ut.cpu().numpy(), d_u0.cpu().numpy()
+        ut, u0 = d_ut.cpu().numpy().astype(np.float64), d_u0.cpu().numpy().astype(np.float64)
+        # the oracle sees what the engine was given (poses / replay memory rounded to the engine's type)
+        pose_in = d_pose.cpu().numpy().astype(np.float64)
+        mem_in = d_mem.cpu().numpy().astype(np.float64) if n_mem else None
         for b in range(B):
             ors[b].set_shared_ck(cbar)
-            u, st = ors[b].control(MAP_BOUNDS, poses[b], mem[b].T if n_mem else None, stages=True)
+            u, st = ors[b].control(MAP_BOUNDS, pose_in[b], mem_in[b].T if n_mem else None, stages=True)
             worst["ck"] = max(worst["ck"], float(np.abs(rec[b, :K2] - st["ck"]).max()))
             worst["ut"] = max(worst["ut"], float(np.abs(ut[b].T - st["ut"]).max()))
             worst["u0"] = max(worst["u0"], float(np.abs(u0[b] - u).max()))
@@ -155,7 +163,7 @@ def test_consensus_leg_exact_form_against_oracle(model, K, horizon, n_mem, lag):
     if os.environ.get("EEA_PRINT_WORST"):
         print("worst consensus leg (no stages, ck_rec out, 1 sum record in, lag %d)" % lag, model, K, T, n_mem,
               {k: "%.2e" % v for k, v in worst.items()})
-    assert worst["ck"] <= TOL_CK and worst["ut"] <= TOL and worst["u0"] <= TOL, worst
+    assert worst["ck"] <= tol_ck and worst["ut"] <= tol and worst["u0"] <= tol, worst
 
 
 def test_shared_ck_with_no_contributing_agent():

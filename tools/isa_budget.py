@@ -188,9 +188,10 @@ def main():
     valu = tot["v_fma64"] + tot["v_pkfma32"] + tot["v_muladd64"] + tot["v_other"]
     print("%-52s" % "total" + "".join("%11d" % tot[c] for c in classes) + "%11d" % valu)
     print()
-    # pipe time: fp64 16x16x4 64 cycles, fp64 4x4x4(4b) 16, fp32 16x16x4 32 (8 passes x 4)
+    # pipe time: fp64 16x16x4 64 cycles, fp64 4x4x4(4b) 16, fp32 4x4x1(16b) 8 (tools/ubench/mfma4x4x1.hip: the same
+    # multiply-adds per cycle as the 16x16x4 form's 1024 in 32)
     mf = sum(v for (ph, c), v in counts.items() if c == "mfma")
-    mf_cycles = 16 if case == "metric" else (32 if real == "float" else 64)
+    mf_cycles = 16 if case == "metric" else (8 if real == "float" else 64)
     print("vector-pipe cycles per agent: %d VALU x 4 + %d MFMA x %d = %d" % (valu, mf, mf_cycles, 4 * valu + mf_cycles * mf))
     # the reference formulation's work at this shape: W = 2 K^2 N + 4 K^2 T + (4 K + 140) T flop
     K, T = KC, TC

@@ -45,7 +45,15 @@ for prec, name, tol, tck in ((capi.PREC_F64, "f64", 1e-9, 1e-11), (capi.PREC_F32
 print("round 4: the consensus leg's exact form (no stages, d_ck_rec out, one sum record in) against the oracle's shared-c_k switch")
 for args in (("simple_cart", 10, 20.0, 0, 1), ("omni", 10, 19.7, 40, 2), ("omni", 5, 19.3, 0, 1), ("omni", 20, 5.0, 0, 1),
              ("omni", 30, 6.0, 0, 1)):
+    tt.test_consensus_leg_exact_form_against_oracle(*args, capi.PREC_F64)
+print("... and on the fp32 engine (bars 5e-4 / 1e-5): K = 20 and K = 10 with replay memory, T = 50 (at T = 200 the fp32 co-state error, relative to |rho| ~ 1e5, is what the controls inherit: the stage-wise tests use the rho-relative bar there)")
+for args in (("omni", 20, 5.0, 33, 1, capi.PREC_F32), ("simple_cart", 10, 5.0, 7, 1, capi.PREC_F32)):
     tt.test_consensus_leg_exact_form_against_oracle(*args)
+print("round 4: fp32 K = 20 (outer-product contraction, gradient packed over pairs of steps), 1 .. 4 steps per lane")
+for steps, n_mem in ((250, 0), (200, 100), (129, 65), (64, 33), (37, 1)):
+    for stages in (True, False):
+        t.run_batch_vs_oracle("omni", 20, steps * 0.02, 0.02, B=3, n_mem=n_mem, calls=2, seed=2000 + steps,
+                              precision=capi.PREC_F32, tol=5e-4, tol_ck=1e-5, stages=stages)
 for dt in (1.0, 2.0):
     print("large step increments dt=%g (bars relative to max(1, |stage|))" % dt)
     t.test_small_and_large_step_increments(dt)
