@@ -1166,6 +1166,13 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   if constexpr (kPairGrad) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     auto splat = [](float v) { return f2{ v, v }; };
+    // The pairs of D are read as 8-byte pairs, alternately through two pointers the compiler cannot prove equal: merged
+    // into 16-byte reads, the fourth element of each costs a register move before it can be the scalar of a packed
+    // instruction (op_sel reaches the halves of an aligned register PAIR only).
+    int zoff = 0;
+    asm volatile("" : "+s"(zoff));
+    const R* const s_Dz = s_D + zoff;
+    auto d_pair = [&](int k2, int k1) { return *reinterpret_cast<const f2*>(((k1 & 2) ? s_Dz : s_D) + k2 * K + k1); };
 #pragma unroll
     for (int jp = 0; jp < kMaxS; jp += 2) {
       if (STAGES) ex[jp] = ey[jp] = ex[jp + 1] = ey[jp + 1] = R(0);
@@ -1197,20 +1204,19 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
           // in the table and G(0) is never used)
 #pragma unroll
           for (int q = 0; q < KB / 2; ++q) {
-            const f2 d = *reinterpret_cast<const f2*>(s_D + kb0 + 2 * q);
-            G2[2 * q] = splat(d.x);
-            G2[2 * q + 1] = splat(d.y);
+            const f2 d = d_pair(0, kb0 + 2 * q);
+            G2[2 * q] = __builtin_elementwise_fma(splat(d.x), splat(1.0f), splat(0.0f));  // (one instruction, not two moves)
+            G2[2 * q + 1] = __builtin_elementwise_fma(splat(d.y), splat(1.0f), splat(0.0f));
           }
           f2 um = splat(0.0f), u0 = splat(1.0f);  // U_{k2-2}, U_{k2-1} of the y angles
           f2 tm = splat(1.0f), t0 = cyp;          // T_{k2-1}, T_{k2}
 #pragma unroll
           for (int k2 = 1; k2 < KC; ++k2) {
             if (k2 < K) {  // wavefront-uniform, always true (kRowGuard)
-              const R* const row = s_D + k2 * K + kb0;
               f2 h2;
 #pragma unroll
               for (int q = 0; q < KB / 2; ++q) {
-                const f2 d = *reinterpret_cast<const f2*>(row + 2 * q);  // D(k1, k2), D(k1 + 1, k2): rows start even
+                const f2 d = d_pair(k2, kb0 + 2 * q);  // D(k1, k2), D(k1 + 1, k2): rows start even
                 G2[2 * q] = __builtin_elementwise_fma(splat(d.x), t0, G2[2 * q]);
                 h2 = (q == 0) ? splat(d.x) * cx2[0] : __builtin_elementwise_fma(splat(d.x), cx2[2 * q], h2);
                 G2[2 * q + 1] = __builtin_elementwise_fma(splat(d.y), t0, G2[2 * q + 1]);
