@@ -354,6 +354,63 @@ def other_config_legs(args, torch, capi, np, spl):
             "cases": res}
 
 
+# the reference's own use of the path: ONE robot, one control() per tick (exploration.hpp:232).  The BASELINE shapes:
+TICK_SHAPES = [
+    dict(name="configs[0]", model="omni", K=5, dt=0.1, horizon=0.5, prec="f64"),
+    dict(name="configs[1]", model="simple_cart", K=10, dt=0.1, horizon=2.0, prec="f64"),
+    dict(name="configs[2]", model="omni", K=20, dt=0.02, horizon=5.0, prec="f32"),
+    dict(name="configs[2] in fp64", model="omni", K=20, dt=0.02, horizon=5.0, prec="f64"),
+    dict(name="configs[3] (one agent of the batch)", model="simple_cart", K=10, dt=0.1, horizon=20.0, prec="f64"),
+    dict(name="configs[4] (control call)", model="omni", K=30, dt=0.1, horizon=50.0, prec="f64"),
+]
+
+
+def single_robot_ticks(torch, capi, np):
+    """Dependent eea_control calls of ONE agent at every BASELINE shape: wall time per call including the host round trip
+    (the call returns u0 on the host, as ErgodicControl::control does)."""
+    res = []
+    for c in TICK_SHAPES:
+        if c["model"] == "simple_cart":
+            model, rdiag, lim = capi.MODEL_SIMPLE_CART, [1.0, 0.0, 2.0], np.array([1.0, 0.0, 2.0])
+        else:
+            model, rdiag, lim = capi.MODEL_OMNI, [1.0, 1.0, 2.0], np.array([1.0, 1.0, 2.0])
+        eng = capi.Engine(capi.make_config(model, c["dt"], c["horizon"], 0.1, 1.0, c["K"], np.diag(rdiag), -lim, lim,
+                                           precision=capi.PREC_F32 if c["prec"] == "f32" else capi.PREC_F64))
+        eng.set_target_gaussians(MEANS, SIGMAS)
+        eng.config_domain(MAP_BOUNDS)
+        x = np.array([3.0, 2.0, 0.3])
+        for _ in range(20):
+            eng.control(MAP_BOUNDS, x)
+        n = 300
+        t0 = time.perf_counter()
+        for _ in range(n):
+            eng.control(MAP_BOUNDS, x)
+        lat = (time.perf_counter() - t0) / n
+        res.append({"config": c["name"], "kinematics": c["model"], "num_basis": c["K"], "horizon_steps": eng.T,
+                    "dtype": c["prec"], "gpu_us_per_call": 1e6 * lat})
+        eng.close()
+    return res
+
+
+def cpu_ticks(seconds_each=0.3):
+    """The CPU port's control() at the same shapes (1 thread): us per call, a bounded sample per shape."""
+    import numpy as np
+    from oracle import pyoracle as po
+    res = {}
+    for c in TICK_SHAPES:
+        if c["model"] == "simple_cart":
+            model, rdiag, lim = po.MODEL_SIMPLE_CART, [1.0, 0.0, 2.0], np.array([1.0, 0.0, 2.0])
+        else:
+            model, rdiag, lim = po.MODEL_OMNI, [1.0, 1.0, 2.0], np.array([1.0, 1.0, 2.0])
+        cfg = po.make_config(model, c["dt"], c["horizon"], 0.1, 1.0, c["K"], np.diag(rdiag), -lim, lim)
+        pose = np.array([[3.0, 2.0, 0.3]])
+        sec, _ = po.bench_control(cfg, MEANS, SIGMAS, MAP_BOUNDS, pose, 2, 1)
+        calls = max(2, min(2000, int(seconds_each / max(sec / 2, 1e-7))))
+        sec, _ = po.bench_control(cfg, MEANS, SIGMAS, MAP_BOUNDS, pose, calls, 1)
+        res[c["name"]] = 1e6 * sec / calls
+    return res
+
+
 def dry_run(args):
     """EEA_BENCH_DRYRUN=1: the launch plumbing without a GPU (CPU test of `--gpus N`): the ranks rendezvous over
     gloo, take the max over ranks of a dummy time like the real legs do, run the grid-tile leg's partition + collective
@@ -856,6 +913,14 @@ def main():
             lat = (time.perf_counter() - t0) / n
             out["latency_mode"] = {"value": 1.0 / lat, "unit": "optimisations/s", "us_per_call": 1e6 * lat,
                                    "note": "B = 1, dependent eea_control calls incl. host round trip"}
+            try:
+                out["single_robot_tick"] = {
+                    "note": "the reference's own use: ONE robot, one control() per tick (exploration.hpp:232) -- dependent "
+                            "eea_control calls at every BASELINE shape, wall time per call incl. the host round trip; "
+                            "cpu_port_us_per_call = the oracle's control() at the same shape, 1 thread, this host",
+                    "cases": single_robot_ticks(torch, capi, np)}
+            except Exception as exc:  # noqa: BLE001 -- the headline line must not die with a secondary leg
+                out["single_robot_tick"] = {"error": repr(exc)}
         if world == 1 and not args.no_phik and not f32:
             try:
                 out.update(phik_legs(args, torch, capi, np))
@@ -1027,6 +1092,13 @@ def main():
         one, allc = cpu_baseline(args, args.cpu_seconds)
         out["cpu_baseline"] = one
         out["cpu_baseline_all_cores"] = allc
+        if isinstance(out.get("single_robot_tick", {}).get("cases"), list):
+            try:
+                cpu = cpu_ticks()
+                for c in out["single_robot_tick"]["cases"]:
+                    c["cpu_port_us_per_call"] = cpu.get(c["config"])
+            except Exception as exc:  # noqa: BLE001
+                out["single_robot_tick"]["cpu_error"] = repr(exc)
     emit()
 
 

@@ -165,6 +165,7 @@ def main():
                 decisions = decisions + [(block, op, target, "not taken")]
                 continue
             counts[(phase, classify(ins))] += 1
+            counts[(phase, "op:" + op)] += 1
 
     walk("entry", 0, collections.Counter(), -1, [], [])
     assert best["cost"] is not None, "no complete path found"
@@ -185,6 +186,12 @@ def main():
         print("%-52s" % name + "".join("%11d" % v for v in row) + "%11d" % valu)
         for c, v in zip(classes, row):
             tot[c] += v
+    if "--opcodes" in sys.argv:   # the executed vector opcodes per phase (what "other" is made of)
+        for ph in range(-1, 10):
+            ops = sorted(((v, c[3:]) for (q, c), v in counts.items() if q == ph and c.startswith("op:v_")), reverse=True)
+            if ops:
+                name = "prologue" if ph < 0 else (PHASES[ph] if ph < len(PHASES) else "epilogue")
+                print("   [%s] " % name + ", ".join("%s x%d" % (o, v) for v, o in ops))
     valu = tot["v_fma64"] + tot["v_pkfma32"] + tot["v_muladd64"] + tot["v_other"]
     print("%-52s" % "total" + "".join("%11d" % tot[c] for c in classes) + "%11d" % valu)
     print()
