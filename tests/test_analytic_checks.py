@@ -6,6 +6,10 @@ against a second restatement:
   1. stationary trajectory  =>  c_k = fourierBasis(x)                 (basis.cpp:79-89,109-120)
   2. single-cell target     =>  phi_k = fourierBasis(cell)            (basis.cpp:122-133)
   3. c_k == phi_k           =>  edx == 0, rho == 0, u == clamp(0)     (ergodic_control.hpp:418-451, integrator.hpp:154-194)
+  4. (round 4) the closed form of EVERY stage for arbitrary controls, each evaluated from the previous stage's own
+     output (tests/analytic_chain.py): RK4 on heading-only kinematics = Simpson's rule, c_k = the mean of the basis,
+     edx = q sum lambda_k (c_k - phi_k) grad f_k, the barrier, RK4 on the linear co-state equation with nilpotent A^T =
+     its two-term flow, u = clamp(-Rinv B^T rho).  The GPU version of 4 does not touch the oracle at all.
 
 Checked for the oracle (CPU) and for the HIP path (GPU), up to K = 32 -- which also says on which side of the
 1e-11 bar the kernels' Chebyshev tables sit at the largest basis.
@@ -82,6 +86,55 @@ def test_oracle_zero_gradient_gives_zero_costate(model):
     assert np.abs(st["bdx"]).max() == 0.0                  # the rollout stays inside the map: no barrier
     assert np.abs(st["edx"]).max() == 0.0 and np.abs(st["rhot"]).max() == 0.0
     assert np.abs(st["ut"]).max() == 0.0 and np.abs(u).max() == 0.0
+
+
+CHAIN_CASES = [  # model, K, horizon, dt, n_mem, pose (the last two start at / beyond the border: the barrier is active)
+    ("omni", 10, 4.0, 0.1, 0, (3.7, 1.9, 0.4)),
+    ("simple_cart", 10, 4.0, 0.1, 7, (8.1, 3.3, -2.6)),
+    ("omni", 5, 0.5, 0.1, 0, (0.2, 0.7, 3.0)),
+    ("omni", 7, 3.0, 0.05, 3, (10.97, 4.99, 1.2)),
+    ("simple_cart", 12, 2.5, 0.125, 0, (-1.02, -0.9, 0.7)),
+]
+CHAIN_MODELS = {"omni": (po.MODEL_OMNI, [1.0, 1.0, 2.0], [1.0, 1.0, 2.0]),
+                "simple_cart": (po.MODEL_SIMPLE_CART, [1.0, 0.0, 2.0], [1.0, 0.0, 2.0])}
+
+
+def _chain_inputs(model, T, n_mem, seed):
+    rng = np.random.default_rng(seed)
+    ut = rng.uniform(-0.6, 0.6, (3, T))
+    ut[2] = rng.uniform(-1.5, 1.5, T)
+    if model == "simple_cart":
+        ut[1] = 0.0
+    shifted = np.concatenate([ut[:, 1:], np.zeros((3, 1))], axis=1)   # ergodic_control.hpp:233-234
+    mem = None
+    if n_mem:
+        mem = np.stack([rng.uniform(-0.5, 10.5, n_mem), rng.uniform(-0.5, 4.5, n_mem), rng.uniform(-3, 3, n_mem)])
+    return ut, shifted, mem
+
+
+def _assert_chain(errs, tol, tol_ck):
+    for k, (e, mag) in errs.items():
+        bar = (tol_ck if k == "ck" else tol) * max(1.0, mag)
+        assert e <= bar, (k, e, mag, errs)
+
+
+@pytest.mark.parametrize("model,K,horizon,dt,n_mem,pose", CHAIN_CASES)
+def test_oracle_every_stage_against_its_closed_form(model, K, horizon, dt, n_mem, pose):
+    from tests.analytic_chain import chain_errors
+    om, rdiag, lim = CHAIN_MODELS[model]
+    lim = np.array(lim)
+    o = po.ErgodicControl(om, dt, horizon, 0.1, 1.0, K, np.diag(rdiag), -lim, lim)
+    o.set_target(MEANS, SIGMAS)
+    o.config_target(BOUNDS)
+    ut, shifted, mem = _chain_inputs(model, o.T, n_mem, 17 * K + o.T)
+    o.ut = ut
+    _, st = o.control(BOUNDS, np.array(pose), mem, stages=True)
+    errs = chain_errors(model, K, dt, 1.0, rdiag, -lim, lim, BOUNDS, pose, shifted, st, o.phik, mem)
+    # the stages are double-precision sums of up to K^2 T terms: 1e-12 relative to the stage's size (measured <= 4e-14)
+    _assert_chain(errs, 1e-12, 1e-14)
+    if pose[0] > 10.9 or pose[0] < -1.0:
+        assert errs["bdx"][1] > 0.0                                        # the barrier took part ...
+        assert (np.abs(st["ut"]) == lim[:, None])[lim > 0].any()           # ... and so did the clamp
 
 
 # ---------------------------------------------------------------------------------------------------------------
@@ -169,4 +222,46 @@ def test_gpu_zero_gradient_gives_zero_costate(model, K, horizon):
     assert float(outs["bdx"].abs().max()) == 0.0
     assert float(outs["edx"].abs().max()) == 0.0 and float(outs["rhot"].abs().max()) == 0.0
     assert float(d_ut.abs().max()) == 0.0 and float(d_u0.abs().max()) == 0.0
+    eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,K,horizon,dt,n_mem,pose", CHAIN_CASES + [
+    ("omni", 20, 1.0, 0.02, 0, (4.0, 2.0, 0.1)),          # K = 20 wavefront instance (2 x 2 tiles in fp64)
+    ("omni", 30, 4.0, 0.1, 5, (6.0, 1.0, -1.0)),          # workgroup-per-agent kernel
+    ("simple_cart", 10, 19.6, 0.1, 0, (2.0, 3.0, 2.0)),   # four steps per lane, cooperative last slot (T = 196)
+])
+def test_gpu_every_stage_against_its_closed_form(model, K, horizon, dt, n_mem, pose):
+    """The HIP path's stage outputs against the closed forms of tests/analytic_chain.py -- no oracle anywhere in this
+    test: engine -> stage outputs -> mpmath.  Bars: the parity bars (1e-9 relative to the stage, c_k 1e-11)."""
+    torch, capi = _gpu()
+    from tests.analytic_chain import chain_errors
+    _, rdiag, lim = CHAIN_MODELS[model]
+    lim = np.array(lim)
+    em = capi.MODEL_OMNI if model == "omni" else capi.MODEL_SIMPLE_CART
+    eng = capi.Engine(capi.make_config(em, dt, horizon, 0.1, 1.0, K, np.diag(rdiag), -lim, lim))
+    eng.set_target_gaussians(MEANS, SIGMAS)
+    eng.config_domain(BOUNDS)
+    T = eng.T
+    ut, shifted, mem = _chain_inputs(model, T, n_mem, 17 * K + T)
+    B = 3   # three agents, the same inputs at batch positions 0 .. 2 (the middle one is checked)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).cuda()
+    d_pose = dev(np.tile(np.array(pose), (B, 1)))
+    d_ut = dev(np.tile(ut.T[None], (B, 1, 1)))
+    d_u0 = torch.empty((B, 3), dtype=torch.float64, device="cuda")
+    outs = {k: torch.empty((B, T, 3), dtype=torch.float64, device="cuda") for k in ("traj", "edx", "bdx", "rhot")}
+    d_ck = torch.empty((B, K * K), dtype=torch.float64, device="cuda")
+    d_mem = dev(np.tile(mem.T[None], (B, 1, 1))) if n_mem else None
+    d_nmem = torch.full((B,), n_mem, dtype=torch.int32, device="cuda") if n_mem else None
+    eng.control_batch(B, d_pose, d_ut, d_u0, mem_cols=d_mem, n_mem=d_nmem, mem_stride=n_mem, ck=d_ck, **outs)
+    torch.cuda.synchronize()
+    st = {k: v[1].cpu().numpy().T for k, v in outs.items()}
+    st["ck"] = d_ck[1].cpu().numpy()
+    st["ut"] = d_ut[1].cpu().numpy().T
+    errs = chain_errors(model, K, dt, 1.0, rdiag, -lim, lim, BOUNDS, pose, shifted, st, eng.phik(), mem)
+    import os
+    if os.environ.get("EEA_PRINT_WORST"):
+        print("closed-form chain", model, K, T, n_mem, {k: "%.1e (|stage| %.1e)" % v for k, v in errs.items()})
+    _assert_chain(errs, 1e-9, 1e-11)
+    assert np.abs(d_u0[1].cpu().numpy() - st["ut"][:, 0]).max() == 0.0   # u0 = ut.col(0) (ergodic_control.hpp:310)
     eng.close()

@@ -24,7 +24,7 @@ cp gpurun_out/prof_r04_k20_f32/summary.txt "$OUT/k20_f32_summary.txt"; cp gpurun
 EEA_PHASE_WARMUP=1000 python3 tools/phase_timing.py 4096 > "$OUT/phase_timing.txt" 2>&1
 EEA_PHASE_WARMUP=1000 python3 tools/phase_timing.py 2048 >> "$OUT/phase_timing.txt" 2>&1
 python3 tools/parity_report.py > "$OUT/parity_report.txt" 2>&1
-EEA_PRINT_WORST=1 python3 -m pytest tests/test_analytic_checks.py -m gpu -q -s 2>&1 | grep -E "digits|passed|failed" > "$OUT/analytic_checks.txt"
+EEA_PRINT_WORST=1 python3 -m pytest tests/test_analytic_checks.py -m gpu -q -s 2>&1 | grep -E "digits|closed-form|passed|failed" > "$OUT/analytic_checks.txt"
 python3 tools/exchange_cost.py > "$OUT/exchange_cost.txt" 2>&1
 python3 tools/exchange_cost.py --rccl >> "$OUT/exchange_cost.txt" 2>&1
 for impl in 0 1; do
