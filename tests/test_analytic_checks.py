@@ -137,6 +137,43 @@ def test_oracle_every_stage_against_its_closed_form(model, K, horizon, dt, n_mem
         assert (np.abs(st["ut"]) == lim[:, None])[lim > 0].any()           # ... and so did the clamp
 
 
+def phik_gaussians_mp(K, bounds, res, nx, ny, means, sigmas):
+    """configTarget for a Gaussian target as formulas (target.hpp:91-102, target.cpp:78-90, basis.cpp:122-133,
+    ergodic_control.hpp:387-411): g(p) = sum_g exp(-1/2 sum_d (p_d - (mu_d - origin_d))^2 / sigma_d^2) on the grid whose
+    coordinates are accumulated sums of the resolution, phi = g / sum g, phi_k = sum_cells phi f_k(cell); col = k2 K + k1"""
+    lx, ly = mp.mpf(bounds[1]) - mp.mpf(bounds[0]), mp.mpf(bounds[3]) - mp.mpf(bounds[2])
+    xs, ys = [mp.mpf(v) for v in accumulated(nx, res)], [mp.mpf(v) for v in accumulated(ny, res)]
+    gx = [[mp.exp(-((x - (mp.mpf(m[0]) - mp.mpf(bounds[0]))) ** 2) / (2 * mp.mpf(sg[0]) ** 2)) for x in xs]
+          for m, sg in zip(means, sigmas)]
+    gy = [[mp.exp(-((y - (mp.mpf(m[1]) - mp.mpf(bounds[2]))) ** 2) / (2 * mp.mpf(sg[1]) ** 2)) for y in ys]
+          for m, sg in zip(means, sigmas)]
+    G = len(means)
+    mass = sum(sum(gx[g]) * sum(gy[g]) for g in range(G))
+    cx = [[mp.cos(k * mp.pi * x / lx) for x in xs] for k in range(K)]
+    cy = [[mp.cos(k * mp.pi * y / ly) for y in ys] for k in range(K)]
+    ax = [[sum(a * b for a, b in zip(gx[g], cx[k])) for k in range(K)] for g in range(G)]   # the sums factor per axis
+    ay = [[sum(a * b for a, b in zip(gy[g], cy[k])) for k in range(K)] for g in range(G)]
+    return np.array([float(sum(ax[g][k1] * ay[g][k2] for g in range(G)) / mass) for k2 in range(K) for k1 in range(K)])
+
+
+PHIK_CASES = [  # K, bounds, resolution, means, sigmas
+    (6, (0.0, 3.0, 0.0, 2.0), 0.1, [[1.0, 0.7]], [[0.4, 0.3]]),
+    (10, BOUNDS, 0.1, MEANS, SIGMAS),
+    (12, (-2.0, 4.4, 1.0, 3.55), 0.05, [[0.5, 2.0], [3.9, 3.4], [-1.5, 1.2]], [[0.8, 0.3], [0.2, 0.6], [1.1, 1.1]]),
+]
+
+
+@pytest.mark.parametrize("K,bounds,res,means,sigmas", PHIK_CASES)
+def test_oracle_gaussian_target_phik_against_the_formulas(K, bounds, res, means, sigmas):
+    o = po.ErgodicControl(po.MODEL_OMNI, 0.1, 1.0, res, 1.0, K, RINV, -LIM, LIM)
+    o.set_target(means, sigmas)
+    o.config_target(bounds)
+    # grid size: round(l / resolution) + 1 (grid.hpp:61-64, ergodic_control.hpp:383-385; pinned by the survey anchors)
+    nx, ny = int(round((bounds[1] - bounds[0]) / res)) + 1, int(round((bounds[3] - bounds[2]) / res)) + 1
+    ref = phik_gaussians_mp(K, bounds, res, nx, ny, means, sigmas)
+    assert abs(ref[0] - 1.0) < 1e-15 and np.abs(o.phik - ref).max() < 1e-14
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # HIP path (through the C ABI)
 # ---------------------------------------------------------------------------------------------------------------
@@ -265,3 +302,30 @@ def test_gpu_every_stage_against_its_closed_form(model, K, horizon, dt, n_mem, p
     _assert_chain(errs, 1e-9, 1e-11)
     assert np.abs(d_u0[1].cpu().numpy() - st["ut"][:, 0]).max() == 0.0   # u0 = ut.col(0) (ergodic_control.hpp:310)
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("impl", [0, 1])
+@pytest.mark.parametrize("K,bounds,res,means,sigmas", PHIK_CASES + [
+    (20, (0.0, 25.5, 0.0, 25.5), 0.1, [[6.0, 6.0], [19.0, 12.0]], [[3.0, 3.0], [3.0, 3.0]]),   # BASELINE configs[2] grid
+])
+def test_gpu_gaussian_target_phik_against_the_formulas(K, bounds, res, means, sigmas, impl):
+    """configTarget's phi_k of a Gaussian target on the HIP path -- both rebuild implementations (per-axis factors in one
+    launch; Target::fill + streaming spatialCoeff) -- against the formulas at 40 digits: no oracle in the loop."""
+    torch, capi = _gpu()
+    capi.set_option(capi.OPT_REBUILD_IMPL, impl)
+    try:
+        eng = capi.Engine(capi.make_config(capi.MODEL_OMNI, 0.1, 1.0, res, 1.0, K, RINV, -LIM, LIM))
+        eng.set_target_gaussians(means, sigmas)
+        eng.config_domain(bounds)
+        _, nx, ny = eng.target_grid()
+        got = eng.phik()
+        eng.close()
+    finally:
+        capi.set_option(capi.OPT_REBUILD_IMPL, 0)
+    ref = phik_gaussians_mp(K, bounds, res, nx, ny, means, sigmas)
+    err = float(np.abs(got - ref).max())
+    import os
+    if os.environ.get("EEA_PRINT_WORST"):
+        print("closed-form phi_k, rebuild implementation %d, K = %d, %d x %d grid: %.1e" % (impl, K, nx, ny, err))
+    assert err < 1e-11
