@@ -183,8 +183,13 @@ __device__ __forceinline__ void wait_operands4(double (&qa)[2][NB], double (&qb)
     asm volatile("s_waitcnt lgkmcnt(0)"
                  : "+v"(qa[0][0]), "+v"(qa[0][1]), "+v"(qa[1][0]), "+v"(qa[1][1]), "+v"(qb[0][0]), "+v"(qb[0][1]),
                    "+v"(qb[1][0]), "+v"(qb[1][1]));
+  } else if constexpr (NB == 5) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(qa[0][0]), "+v"(qa[0][1]), "+v"(qa[0][2]), "+v"(qa[0][3]), "+v"(qa[0][4]), "+v"(qa[1][0]), "+v"(qa[1][1]),
+                   "+v"(qa[1][2]), "+v"(qa[1][3]), "+v"(qa[1][4]), "+v"(qb[0][0]), "+v"(qb[0][1]), "+v"(qb[0][2]), "+v"(qb[0][3]),
+                   "+v"(qb[0][4]), "+v"(qb[1][0]), "+v"(qb[1][1]), "+v"(qb[1][2]), "+v"(qb[1][3]), "+v"(qb[1][4]));
   } else {
-    static_assert(NB == 2 || NB == 3, "block contraction: K = 5 or 10");
+    static_assert(NB == 2 || NB == 3 || NB == 5, "block contraction: K = 5, 10 or 20");
   }
 }
 
@@ -220,10 +225,18 @@ __device__ __forceinline__ R wrap_pi_fast(R rad)
   return rad - pi;
 }
 
-// waves per SIMD the kernel is compiled for: 4 (128 registers) for K <= 10 and for fp32
-constexpr int waves_per_simd(int KC, int real_size) { return (KC <= 10 || real_size == 4) ? 4 : 3; }
+// waves per SIMD the kernel is compiled for: 4 (128 registers) for K <= 10 and for fp32; fp64 K = 20: 2 (the block
+// contraction's 25 accumulators + the gradient's 20-mode families: 233 registers, no scratch; compiled for 3 it spills
+// 264 B per lane and is 1.5 % slower)
+constexpr int waves_per_simd(int KC, int real_size)
+{
+  return (KC == 20) ? (real_size == 8 ? 2 : 4) : ((KC <= 10 || real_size == 4) ? 4 : 3);
+}
 // k1 block of the gradient: cosine and G arrays of this many modes are in registers at a time
-constexpr int grad_block(int KC) { return KC <= 12 ? KC : (KC == 16 ? 8 : 10); }
+// K = 20: ALL 20 modes at once in both precisions -- in two blocks of 10 the y recurrences and the weighted sums of H run
+// once per block, and the pass is 6 % (fp32: 37.3 -> 34.9 us, 128 registers + 16-24 B of scratch per lane; compiled for 3
+// wavefronts per SIMD without scratch: 35.5) / 17 % (fp64: 87.6 -> 72.6 us) slower than the instruction counts say
+constexpr int grad_block(int KC) { return KC <= 12 ? KC : (KC == 16 ? 8 : 20); }
 
 }  // namespace wave
 }  // namespace eea
@@ -643,7 +656,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   // at the end by two row rotations.  (Round 2's block form gave the four blocks four different (I, J) pairs of the
   // same 4 points: every instruction then needs its own operands -- 288 LDS reads per agent -- and the phase became
   // LDS-bound, tools/ab/block4_contraction.patch.)
-  constexpr bool kBlock4 = sizeof(R) == 8 && (KC == 10 || KC == 5);
+  constexpr bool kBlock4 = sizeof(R) == 8 && (KC == 10 || KC == 5 || KC == 20);
   constexpr int NB = (KC + 3) / 4;          // 4-mode blocks per axis
   R cacc[kBlock4 ? NB : 1][kBlock4 ? NB : 1];
 #pragma unroll
@@ -659,10 +672,13 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   // (K = 10), i.e. at multiples of 4 dwords: EVEN rows (40 m mod 64 = all multiples of 8) for lanes 0..31, odd rows for
   // lanes 32..63.  Round 3's map (row = 4 b + k: rows {0,1,4,5,...} in one lane group) put every window on half of
   // another one's banks: 2 extra LDS cycles per operand read (SQ_LDS_BANK_CONFLICT 390 per agent, profiles/r04_lds_conflicts.txt)
+  // K = 20: rows 40 dwords apart, 8 consecutive rows tile the 64 banks: rows 0..7 for lanes 0..31, 8..15 for lanes 32..63.
 #ifdef EEA_OROW_R03
   const int orow = 4 * ((lane >> 2) & 3) + (lane >> 4), oi = lane & 3;
 #else
-  const int orow = 4 * ((lane >> 2) & 3) + 2 * ((lane >> 4) & 1) + (lane >> 5), oi = lane & 3;
+  const int orow = (KC == 20) ? 8 * (lane >> 5) + 4 * ((lane >> 4) & 1) + ((lane >> 2) & 3)
+                              : 4 * ((lane >> 2) & 3) + 2 * ((lane >> 4) & 1) + (lane >> 5);
+  const int oi = lane & 3;
 #endif
   R qa[2][kBlock4 ? NB : 1], qb[2][kBlock4 ? NB : 1];
   const unsigned oaddr = lds_addr(tabx + orow * KS + oi);
