@@ -198,8 +198,15 @@ def main():
     # pipe time: fp64 16x16x4 64 cycles, fp64 4x4x4(4b) 16, fp32 4x4x1(16b) 8 (tools/ubench/mfma4x4x1.hip: the same
     # multiply-adds per cycle as the 16x16x4 form's 1024 in 32)
     mf = sum(v for (ph, c), v in counts.items() if c == "mfma")
-    mf_cycles = 16 if case == "metric" else (8 if real == "float" else 64)
-    print("vector-pipe cycles per agent: %d VALU x 4 + %d MFMA x %d = %d" % (valu, mf, mf_cycles, 4 * valu + mf_cycles * mf))
+    MF_CYCLES = {"v_mfma_f64_4x4x4_4b_f64": 16, "v_mfma_f64_16x16x4_f64": 64, "v_mfma_f32_4x4x1_16b_f32": 8,
+                 "v_mfma_f32_16x16x4_f32": 32}
+    mf_by_op = collections.Counter()
+    for (ph, c), v in counts.items():
+        if c.startswith("op:v_mfma"):
+            mf_by_op[c[3:]] += v
+    mf_total = sum(MF_CYCLES[o] * v for o, v in mf_by_op.items())
+    print("vector-pipe cycles per agent: %d VALU x 4 + %s = %d" % (
+        valu, " + ".join("%d %s x %d" % (v, o, MF_CYCLES[o]) for o, v in mf_by_op.items()) or "0 MFMA", 4 * valu + mf_total))
     # the reference formulation's work at this shape: W = 2 K^2 N + 4 K^2 T + (4 K + 140) T flop
     K, T = KC, TC
     W = 2 * K * K * T + 4 * K * K * T + (4 * K + 140) * T
