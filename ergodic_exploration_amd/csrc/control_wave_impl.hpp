@@ -236,7 +236,9 @@ constexpr int waves_per_simd(int KC, int real_size)
 // K = 20: ALL 20 modes at once in both precisions -- in two blocks of 10 the y recurrences and the weighted sums of H run
 // once per block, and the pass is 6 % (fp32: 37.3 -> 34.9 us, 128 registers + 16-24 B of scratch per lane; compiled for 3
 // wavefronts per SIMD without scratch: 35.5) / 17 % (fp64: 87.6 -> 72.6 us) slower than the instruction counts say
-constexpr int grad_block(int KC) { return KC <= 12 ? KC : (KC == 16 ? 8 : 20); }
+// (the K <= 16 instance likewise: all 16 modes at once, 150-157 registers in fp64 = 3 wavefronts per SIMD, still 7-9 % faster
+// than two blocks of 8 at 4 wavefronts per SIMD: K = 16 69.5 -> 64.1 us, K = 12 54.0 -> 50.0, fp32 K = 16 39.3 -> 35.8)
+constexpr int grad_block(int KC) { return KC; }
 
 }  // namespace wave
 }  // namespace eea
