@@ -272,6 +272,11 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   typedef const __attribute__((address_space(4))) ControlParams<R> KernArgParams;
   const int wave_of_block = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int n_steps = ((KernArgParams*)__builtin_amdgcn_kernarg_segment_ptr())->n_steps;
+  // The controls a step leaves for the next one are handed over in LDS (the tiles and the park are dead between the
+  // update and the next forward half): s_next[r][step index], read back one column to the right
+  // (ergodic_control.hpp:233-234).  Reading them back from L2 put that latency at the head of every step of every wavefront
+  // (all wait at once: nothing to overlap with) -- 8 % of a 50-step launch; carried in registers they pushed the metric
+  // instance over its 128.  (ut is still stored every step: the backward half re-reads the controls it needs from there.)
   for (int step = 0; step < n_steps; ++step) {
   // ... and the launch parameters are re-read (scalar loads where they are used, as in a launch) through a pointer that
   // is opaque per step: hoisted out of the loop they would all be live through the body (106 scalar registers + spills)
@@ -346,19 +351,36 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   // ---- controls: shift left by one column, last column zero (ergodic_control.hpp:233-234) ------------
   R vx[kMaxS], vy[kMaxS], w[kMaxS];
   bool bad = false;
+  if (step == 0) {  // wavefront-uniform
 #pragma unroll
-  for (int j = 0; j < kMaxS; ++j) {
-    vx[j] = vy[j] = w[j] = R(0);
-    if (j < S) {
-      const int src = rollout_only ? i0 + j : i0 + j + 1;  // optTraj rolls the controls out as they are
-      if (j < cnt && src < T) {
-        vx[j] = ut[3 * src + 0];
-        vy[j] = ut[3 * src + 1];
-        w[j] = ut[3 * src + 2];
+    for (int j = 0; j < kMaxS; ++j) {
+      vx[j] = vy[j] = w[j] = R(0);
+      if (j < S) {
+        const int src = rollout_only ? i0 + j : i0 + j + 1;  // optTraj rolls the controls out as they are
+        if (j < cnt && src < T) {
+          vx[j] = ut[3 * src + 0];
+          vy[j] = ut[3 * src + 1];
+          w[j] = ut[3 * src + 2];
+        }
+        // SimpleCart::operator() rejects a lateral velocity (cart.hpp:167-170)
+        if (MODEL == kModelSimpleCart && j < cnt && !(fabs(vy[j]) < R(1.0e-12))) bad = true;
       }
-      // SimpleCart::operator() rejects a lateral velocity (cart.hpp:167-170)
-      if (MODEL == kModelSimpleCart && j < cnt && !(fabs(vy[j]) < R(1.0e-12))) bad = true;
     }
+  } else {  // the kernel's own output of the step before
+    const R* const s_next = sm + i0 + 1;
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      vx[j] = vy[j] = w[j] = R(0);
+      if (j < S) {
+        if (j < cnt && i0 + j + 1 < T) {
+          vx[j] = s_next[0 * kMaxS * kWave + j];
+          vy[j] = s_next[1 * kMaxS * kWave + j];
+          w[j] = s_next[2 * kMaxS * kWave + j];
+        }
+        if (MODEL == kModelSimpleCart && j < cnt && !(fabs(vy[j]) < R(1.0e-12))) bad = true;
+      }
+    }
+    lds_fence();  // (read before the forward half writes the park and the tiles)
   }
   const R x0 = pose[0], y0 = pose[1], th0 = pose[2];
   // record elements per lane of an agent's sum record (K^2 + 1 reals rounded up to even)
@@ -1615,6 +1637,11 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
       ut[3 * i + 0] = u[0];
       ut[3 * i + 1] = u[1];
       ut[3 * i + 2] = u[2];
+      if (step + 1 < n_steps) {  // wavefront-uniform: hand-over to the next step
+        sm[0 * kMaxS * kWave + i] = u[0];
+        sm[1 * kMaxS * kWave + i] = u[1];
+        sm[2 * kMaxS * kWave + i] = u[2];
+      }
       if (STAGES && p.rhot != nullptr) {
         R* const o = p.rhot + 3 * (static_cast<size_t>(T) * b + i);
         o[0] = r0[j];
@@ -1637,7 +1664,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   if (nan_free) update_controls(std::true_type{});  // wavefront-uniform
   else update_controls(std::false_type{});
   EEA_WSTAMP(9);
-  if (step + 1 < n_steps) {  // wavefront-uniform: the next step reads the controls just stored (and reuses the LDS)
+  if (step + 1 < n_steps) {  // wavefront-uniform: the next step's backward half re-reads the controls just stored (and the LDS is reused)
     // only THIS wavefront reads them back: work-group scope -- the stores drained (s_waitcnt vmcnt(0)), the CU's own
     // write-through L1 is coherent for its own wavefronts.  (Agent scope writes back and invalidates the L2 on this
     // multi-XCD part: 150 us per step, profiles/r04_multi_step.txt.)
