@@ -277,6 +277,11 @@ def other_config_legs(args, torch, capi, np, spl):
              means=[[6.0, 6.0], [19.0, 12.0]], sigmas=[[3.0, 3.0], [3.0, 3.0]]),
         dict(name="configs[2] fp64 twin", model="omni", K=20, dt=0.02, horizon=5.0, prec="f64", bounds=(0.0, 25.5, 0.0, 25.5),
              means=[[6.0, 6.0], [19.0, 12.0]], sigmas=[[3.0, 3.0], [3.0, 3.0]]),
+        # SURVEY.md 8(d) cfg 4's other halves: the Omni model, and a full replay-memory batch (n_mem = 100 sampled past states)
+        dict(name="configs[3] with the Omni model", model="omni", K=10, dt=0.1, horizon=20.0, prec="f64", bounds=MAP_BOUNDS,
+             means=MEANS, sigmas=SIGMAS),
+        dict(name="configs[3] with n_mem = 100", model="simple_cart", K=10, dt=0.1, horizon=20.0, prec="f64", bounds=MAP_BOUNDS,
+             means=MEANS, sigmas=SIGMAS, n_mem=100),
     ]
     res = []
     for c in cases:
@@ -298,10 +303,20 @@ def other_config_legs(args, torch, capi, np, spl):
         d_pose = torch.as_tensor(poses, dtype=tdt).cuda()
         d_ut = torch.zeros((B, T, 3), dtype=tdt, device="cuda")
         d_u0 = torch.empty((B, 3), dtype=tdt, device="cuda")
+        n_mem = c.get("n_mem", 0)
+        d_mem = d_nmem = None
+        if n_mem:
+            mem = np.stack([rng.uniform(0.5, b[1] - b[0] - 0.5, B * n_mem) + b[0],
+                            rng.uniform(0.5, b[3] - b[2] - 0.5, B * n_mem) + b[2],
+                            rng.uniform(-np.pi, np.pi, B * n_mem)], 1).reshape(B, n_mem, 3)
+            d_mem = torch.as_tensor(mem, dtype=tdt).cuda()
+            d_nmem = torch.full((B,), n_mem, dtype=torch.int32, device="cuda")
         streams = [torch.cuda.Stream(), torch.cuda.Stream()]
         half = B // 2
         calls = [eng.prepared_batch(hi - lo, d_pose[lo:hi], d_ut[lo:hi], d_u0[lo:hi], stream=st.cuda_stream,
-                                    n_steps=None if spl == 1 else spl)
+                                    n_steps=None if spl == 1 else spl,
+                                    mem_cols=None if d_mem is None else d_mem[lo:hi],
+                                    n_mem=None if d_nmem is None else d_nmem[lo:hi], mem_stride=n_mem)
                  for (lo, hi), st in zip(((0, half), (half, B)), streams)]
         torch.cuda.synchronize()
         # size the timed region from a short probe: ~0.3 s
@@ -323,7 +338,7 @@ def other_config_legs(args, torch, capi, np, spl):
         n_calls = max(2, int(0.3 / (probe * 1e-3) / spl))
         run(max(1, n_calls // 4))
         pass_ms = run(n_calls)
-        flops = 2 * K * K * T + 4 * K * K * T + (4 * K + 140) * T
+        flops = 2 * K * K * (T + n_mem) + 4 * K * K * T + (4 * K + 140) * T   # W with N = T + n_mem
         peak = VALU_F32_PEAK_TF if f32 else VALU_F64_PEAK_TF
         tfl = flops * B / (pass_ms * 1e-3) / 1e12
         # configTarget rebuild of this configuration's grid: device time per rebuild (HIP events around 50 enqueue-only rebuilds)
@@ -342,7 +357,7 @@ def other_config_legs(args, torch, capi, np, spl):
         torch.cuda.synchronize()
         nx, ny = eng.target_grid()[1:]
         res.append({"config": c["name"], "kinematics": c["model"], "num_basis": K, "horizon_steps": T, "dt": c["dt"],
-                    "dtype": c["prec"], "agents": B, "steps_per_launch": spl, "passes_timed": n_calls * spl,
+                    "dtype": c["prec"], "agents": B, "n_mem": n_mem, "steps_per_launch": spl, "passes_timed": n_calls * spl,
                     "ms_per_pass": pass_ms, "value": B / (pass_ms * 1e-3), "unit": "optimisations/s",
                     "roofline": {"bound": "valu-%s" % c["prec"], "achieved": tfl, "peak": peak, "unit": "TFLOP/s",
                                  "frac": tfl / peak, "flops_per_optimisation": flops},
