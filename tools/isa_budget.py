@@ -31,6 +31,8 @@ CASES = {
     # name: (real type, model id, K, T, kernel symbol prefix, lean, WPB, label)
     "metric": ("double", 1, 10, 200, "_ZN3eea4wave19control_wave_kernelIdLi1ELi10ELb0ELi4E", False, 4,
                "fp64, SimpleCart, K = 10, T = 200"),
+    "t192": ("double", 1, 10, 192, "_ZN3eea4wave19control_wave_kernelIdLi1ELi10ELb0ELi4E", False, 4,
+             "fp64, SimpleCart, K = 10, T = 192 (three full slots: what the 8-step tail of T = 200 adds)"),
     "k20f32": ("float", 0, 20, 250, "_ZN3eea4wave19control_wave_kernelIfLi0ELi20ELb0ELi4E", False, 4,
                "fp32, Omni, K = 20, T = 250 (BASELINE configs[2])"),
     "k20f64": ("double", 0, 20, 250, "_ZN3eea4wave19control_wave_kernelIdLi0ELi20ELb0ELi1E", False, 1,
