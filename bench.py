@@ -866,7 +866,7 @@ def main():
                             "kernel_avg_us_per_pass_profiled": per_pass_us,
                             "pass_period_us_profiled": rec["pass_period_us_from_trace"],
                             "frac_profiled": G * flops_per_opt * rec["agents_per_launch"] / (per_pass_us * 1e-6) / 1e12 / VALU_F64_PEAK_TF,
-                            "s_memtime_tick_rate_ghz_profiled": rec.get("s_memtime_tick_rate_ghz"),
+                            "effective_clock_ghz_profiled": rec.get("effective_clock_ghz"),
                             "profiled_source": "profiles/r04_bench_profile.json (rocprofv3 --kernel-trace --stats of this "
                                                "command shape, timed-region dispatches only; a separate run on another box "
                                                "of the pool)"}

@@ -34,7 +34,7 @@ def main():
     g1 = json.load(open(os.path.join(EV, "spl1_summary.json")))
     clock = None
     try:
-        m = re.search(r"(?:shader clock|s_memtime tick rate) while the wavefronts ran: ([0-9.]+) GHz", open(os.path.join(EV, "phase_timing.txt")).read())
+        m = re.search(r"shader clock while the wavefronts ran: ([0-9.]+) GHz", open(os.path.join(EV, "phase_timing.txt")).read())
         if m:
             clock = float(m.group(1))
     except OSError:
@@ -55,7 +55,7 @@ def main():
            "one_launch_per_pass": {"kernel_avg_us_profiled": g1["timed_region"]["kernel_avg_us_timed_region"],
                                    "pass_period_us_from_trace": g1["timed_region"]["pass_period_us_from_trace"],
                                    "bench_ms_per_pass_in_the_profiled_run": g1["timed_region"]["bench_ms_per_pass_same_run"]},
-           "s_memtime_tick_rate_ghz": clock,   # (NOT the shader clock: profiles/r04_ubench_rates.txt)
+           "effective_clock_ghz": clock,
            "source": "profiles/r04_spl50_summary.txt, profiles/r04_spl1_summary.txt"}
     json.dump(rec, open(os.path.join(PR, "r04_bench_profile.json"), "w"), indent=1)
     # HBM traffic per launch of the profiled shape (PMC passes of the same command: 2048 agents x 50 steps per dispatch)

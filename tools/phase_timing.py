@@ -59,7 +59,7 @@ def main():
         rt = raw[:, 10:12].astype(np.float64) * 10.0  # 100 MHz counter -> ns
         life_ns = rt[:, 1] - rt[:, 0]
         cyc = (raw[:, 9] - raw[:, 0]).astype(np.float64)
-        print("s_memtime tick rate while the wavefronts ran: %.2f GHz (mean of ticks / lifetime; not the shader clock, profiles/r04_ubench_rates.txt); launch span %.2f us, "
+        print("shader clock while the wavefronts ran: %.2f GHz (mean of cycles / lifetime); launch span %.2f us, "
               "wave lifetime %.2f us mean" % ((cyc / life_ns).mean(), (rt[:, 1].max() - rt[:, 0].min()) * 1e-3,
                                               life_ns.mean() * 1e-3))
         hw = raw[:, 12]
