@@ -136,6 +136,45 @@ int main(int argc, char** argv)
     return dt / count;
   };
 
+  // the plain passes again as ONE hipGraph of `per` passes (2 per kernel nodes on two captured streams), replayed: does a
+  // graph remove anything from the launch boundary that a stream of launches leaves?
+  auto run_graph = [&](int per, int count) {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    ok(hipEventCreateWithFlags(&fork, hipEventDisableTiming), "event");
+    ok(hipEventCreateWithFlags(&join, hipEventDisableTiming), "event");
+    ok(hipStreamBeginCapture(streams[0], hipStreamCaptureModeThreadLocal), "begin capture");
+    ok(hipEventRecord(fork, streams[0]), "fork");
+    ok(hipStreamWaitEvent(streams[1], fork, 0), "fork wait");
+    for (int i = 0; i < per; ++i) {
+      for (int g = 0; g < 2; ++g) {
+        const unsigned first = gb[g], cnt = gb[g + 1] - gb[g];
+        eea_batch_io io{};
+        io.d_pose = d_pose + 3 * first;
+        io.d_ut = d_ut + static_cast<size_t>(3) * T * first;
+        io.d_u0 = d_u0 + 3 * first;
+        ok(eea_control_batch(e, cnt, &io, streams[g]), "eea_control_batch (captured)");
+      }
+    }
+    ok(hipEventRecord(join, streams[1]), "join");
+    ok(hipStreamWaitEvent(streams[0], join, 0), "join wait");
+    ok(hipStreamEndCapture(streams[0], &graph), "end capture");
+    ok(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0), "instantiate");
+    const int launches = count / per;
+    for (int i = 0; i < 4; ++i) ok(hipGraphLaunch(exec, streams[0]), "graph launch");
+    ok(hipDeviceSynchronize(), "sync");
+    const double t0 = now();
+    for (int i = 0; i < launches; ++i) ok(hipGraphLaunch(exec, streams[0]), "graph launch");
+    ok(hipDeviceSynchronize(), "sync");
+    const double dt = (now() - t0) / (static_cast<double>(launches) * per);
+    (void)hipGraphExecDestroy(exec);
+    (void)hipGraphDestroy(graph);
+    (void)hipEventDestroy(fork);
+    (void)hipEventDestroy(join);
+    return dt;
+  };
+
   run(false, 1000, nullptr);  // clock spin-up, warm start
   double host_plain = 0.0, host_cons = 0.0;
   const double plain = run(false, passes, &host_plain);
@@ -147,6 +186,9 @@ int main(int argc, char** argv)
   for (int v : st) bad += v != 0;
   std::printf("C++ host loop, %u agents, K = 10, T = %u, fp64, two agent groups, one launch per pass and group, %d passes:\n", n, T, passes);
   std::printf("  plain passes                         %6.2f us per pass   (host inside the calls: %5.2f us per pass)\n", 1e6 * plain, 1e6 * host_plain);
+  const double graphed = run_graph(50, passes);
+  std::printf("  plain passes as a hipGraph of 50      %6.2f us per pass   (2 x 50 kernel nodes on two captured streams, replayed %d times)\n",
+              1e6 * graphed, passes / 50);
   std::printf("  consensus every pass, lag 1 (bound)  %6.2f us per pass   (host inside the calls: %5.2f us per pass)   = %.3f x plain; agents timed out: %d\n",
               1e6 * cons, 1e6 * host_cons, cons / plain, bad);
   eea_comm_destroy(c);
