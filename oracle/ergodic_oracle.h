@@ -18,6 +18,9 @@
  *     tests/golden/reference_kats.json) and against the end-to-end `control()`
  *     outputs of the reference's sources recorded at survey time
  *     (SURVEY.md section 8(c) "sanity anchors"; tests/golden/survey_anchors.json).
+ *   - every stage of control() (rollout, c_k, both gradients, co-state, update) and configTarget's phi_k of Gaussian
+ *     targets against CLOSED FORMS evaluated with mpmath at 40 digits (tests/analytic_chain.py,
+ *     tests/test_analytic_checks.py): <= 9.2e-15 -- formulas the reference's lines state, not its binary.
  *   - The reference itself is UNBUILDABLE in this image (needs Armadillo and ROS
  *     message headers, both absent; writing stand-ins is not allowed), so there
  *     is no oracle/_ref build.  Armadillo-internal summation orders (accu, gemv,
