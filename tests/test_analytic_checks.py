@@ -268,40 +268,61 @@ def test_gpu_zero_gradient_gives_zero_costate(model, K, horizon):
     ("omni", 30, 4.0, 0.1, 5, (6.0, 1.0, -1.0)),          # workgroup-per-agent kernel
     ("simple_cart", 10, 19.6, 0.1, 0, (2.0, 3.0, 2.0)),   # four steps per lane, cooperative last slot (T = 196)
 ])
-def test_gpu_every_stage_against_its_closed_form(model, K, horizon, dt, n_mem, pose):
+def test_gpu_every_stage_against_its_closed_form(model, K, horizon, dt, n_mem, pose, f32=False):
     """The HIP path's stage outputs against the closed forms of tests/analytic_chain.py -- no oracle anywhere in this
-    test: engine -> stage outputs -> mpmath.  Bars: the parity bars (1e-9 relative to the stage, c_k 1e-11)."""
+    test: engine -> stage outputs -> mpmath.  Bars: the parity bars (1e-9 relative to the stage, c_k 1e-11; the fp32
+    engine: 5e-4 / 1e-5, its inputs rounded to float before the closed forms see them)."""
     torch, capi = _gpu()
     from tests.analytic_chain import chain_errors
     _, rdiag, lim = CHAIN_MODELS[model]
     lim = np.array(lim)
     em = capi.MODEL_OMNI if model == "omni" else capi.MODEL_SIMPLE_CART
-    eng = capi.Engine(capi.make_config(em, dt, horizon, 0.1, 1.0, K, np.diag(rdiag), -lim, lim))
+    tdt = torch.float32 if f32 else torch.float64
+    eng = capi.Engine(capi.make_config(em, dt, horizon, 0.1, 1.0, K, np.diag(rdiag), -lim, lim,
+                                       precision=capi.PREC_F32 if f32 else capi.PREC_F64))
     eng.set_target_gaussians(MEANS, SIGMAS)
     eng.config_domain(BOUNDS)
     T = eng.T
     ut, shifted, mem = _chain_inputs(model, T, n_mem, 17 * K + T)
+    if f32:   # what the engine is given
+        r32 = lambda a: None if a is None else np.asarray(a, dtype=np.float32).astype(np.float64)
+        ut, shifted, mem, pose = r32(ut), r32(shifted), r32(mem), tuple(r32(np.array(pose)))
     B = 3   # three agents, the same inputs at batch positions 0 .. 2 (the middle one is checked)
-    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=torch.float64).cuda()
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a), dtype=tdt).cuda()
     d_pose = dev(np.tile(np.array(pose), (B, 1)))
     d_ut = dev(np.tile(ut.T[None], (B, 1, 1)))
-    d_u0 = torch.empty((B, 3), dtype=torch.float64, device="cuda")
-    outs = {k: torch.empty((B, T, 3), dtype=torch.float64, device="cuda") for k in ("traj", "edx", "bdx", "rhot")}
-    d_ck = torch.empty((B, K * K), dtype=torch.float64, device="cuda")
+    d_u0 = torch.empty((B, 3), dtype=tdt, device="cuda")
+    outs = {k: torch.empty((B, T, 3), dtype=tdt, device="cuda") for k in ("traj", "edx", "bdx", "rhot")}
+    d_ck = torch.empty((B, K * K), dtype=tdt, device="cuda")
     d_mem = dev(np.tile(mem.T[None], (B, 1, 1))) if n_mem else None
     d_nmem = torch.full((B,), n_mem, dtype=torch.int32, device="cuda") if n_mem else None
     eng.control_batch(B, d_pose, d_ut, d_u0, mem_cols=d_mem, n_mem=d_nmem, mem_stride=n_mem, ck=d_ck, **outs)
     torch.cuda.synchronize()
-    st = {k: v[1].cpu().numpy().T for k, v in outs.items()}
-    st["ck"] = d_ck[1].cpu().numpy()
-    st["ut"] = d_ut[1].cpu().numpy().T
+    st = {k: v[1].cpu().numpy().astype(np.float64).T for k, v in outs.items()}
+    st["ck"] = d_ck[1].cpu().numpy().astype(np.float64)
+    st["ut"] = d_ut[1].cpu().numpy().astype(np.float64).T
     errs = chain_errors(model, K, dt, 1.0, rdiag, -lim, lim, BOUNDS, pose, shifted, st, eng.phik(), mem)
     import os
     if os.environ.get("EEA_PRINT_WORST"):
-        print("closed-form chain", model, K, T, n_mem, {k: "%.1e (|stage| %.1e)" % v for k, v in errs.items()})
-    _assert_chain(errs, 1e-9, 1e-11)
-    assert np.abs(d_u0[1].cpu().numpy() - st["ut"][:, 0]).max() == 0.0   # u0 = ut.col(0) (ergodic_control.hpp:310)
+        print("closed-form chain%s" % (" (fp32 engine)" if f32 else ""), model, K, T, n_mem,
+              {k: "%.1e (|stage| %.1e)" % v for k, v in errs.items()})
+    if f32:
+        _assert_chain(errs, 5e-4, 1e-5)
+    else:
+        _assert_chain(errs, 1e-9, 1e-11)
+    assert np.abs(d_u0[1].cpu().numpy().astype(np.float64) - st["ut"][:, 0]).max() == 0.0   # u0 = ut.col(0) (ergodic_control.hpp:310)
     eng.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("model,K,horizon,dt,n_mem,pose", [
+    ("omni", 20, 5.0, 0.02, 0, (4.0, 2.0, 0.1)),           # BASELINE configs[2]'s instance: outer-product contraction, pair gradient
+    ("omni", 20, 2.58, 0.02, 33, (9.0, 3.5, -2.0)),         # T = 129: three steps per lane (the pair's second step dropped), memory
+    ("simple_cart", 10, 4.0, 0.1, 7, (8.1, 3.3, -2.6)),
+    ("omni", 16, 3.0, 0.1, 0, (2.0, 1.0, 1.0)),
+])
+def test_gpu_fp32_engine_every_stage_against_its_closed_form(model, K, horizon, dt, n_mem, pose):
+    test_gpu_every_stage_against_its_closed_form(model, K, horizon, dt, n_mem, pose, f32=True)
 
 
 @pytest.mark.gpu
