@@ -1197,12 +1197,13 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   // tools/ubench/exec_mask.hip); instead all 64 lanes take them together, 8 lanes per step (below the loop).
   constexpr bool kCoopTail = sizeof(R) == 8 && (KC == 10 || KC == 5);
   const bool coop_tail = kCoopTail && top_heavy && S == kMaxS;  // wavefront-uniform
-  // fp32, K = 20 (BASELINE configs[2]): TWO steps of the lane at a time, every operation of the pass PACKED over the pair
+  // fp32, K = 20 (BASELINE configs[2]) and K = 10: TWO steps of the lane at a time, every operation of the pass PACKED over the pair
   // (v_pk_fma_f32: (G_j(k1), G_j+1(k1)) += D(k1,k2) (cos b_k2 y_j, cos b_k2 y_j+1) with the element of D as the scalar
   // of both halves, likewise H, the four Chebyshev recurrences and the weighted sums).  Round 3's form packed pairs of x
   // MODES of one step: its recurrences and weighted sums (a third of the gradient's instructions) stayed scalar, at half
-  // the packed rate.  The second step of a pair beyond S runs on zeros and is dropped.
-  constexpr bool kPairGrad = sizeof(R) == 4 && KC == 20;
+  // the packed rate.  The second step of a pair beyond S runs on zeros and is dropped.  (K = 10: 16.05 -> 15.47 us per pass at
+  // T = 200; rows of D must start at even offsets: even K only, compile-time K only.)
+  constexpr bool kPairGrad = sizeof(R) == 4 && (KC == 20 || KC == 10);
   if constexpr (kPairGrad) {
     typedef float f2 __attribute__((ext_vector_type(2)));
     auto splat = [](float v) { return f2{ v, v }; };
