@@ -19,7 +19,7 @@ MODEL_OMNI, MODEL_SIMPLE_CART = 0, 1
 PREC_F64, PREC_F32 = 0, 1
 OK, ERR_INVALID_ARGUMENT, ERR_INVALID_TWIST, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_TARGET, ERR_TIMEOUT = range(7)
 # eea_set_option (process-wide dispatch options; the library reads no environment variable)
-OPT_CONTROL_KERNEL, OPT_WORKGROUP_THREADS, OPT_COLLISION_IMPL, OPT_MAILBOX_POLL, OPT_REBUILD_IMPL = range(5)
+OPT_CONTROL_KERNEL, OPT_WORKGROUP_THREADS, OPT_COLLISION_IMPL, OPT_MAILBOX_POLL, OPT_REBUILD_IMPL, OPT_AGENT_LANES = range(6)
 
 
 class EngineError(RuntimeError):
@@ -95,6 +95,8 @@ def lib():
         L = C.CDLL(LIB_PATH)
         L.eea_last_error.restype = C.c_char_p
         L.eea_steps.restype = C.c_uint
+        L.eea_batch_agent_lanes.restype = C.c_uint
+        L.eea_batch_agent_lanes.argtypes = [C.c_void_p, C.c_uint]
         L.eea_num_modes.restype = C.c_uint
         L.eea_real_size.restype = C.c_size_t
         L.eea_time_step.restype = C.c_double
@@ -218,6 +220,10 @@ class Engine:
         self.K2 = int(lib().eea_num_modes(self.h))
         self.real_size = int(lib().eea_real_size(self.h))
 
+    def agent_lanes(self, B):
+        """eea_batch_agent_lanes: lanes of a wavefront per agent for a plain batch of B agents (64, 8 / 16 / 32, or 0)"""
+        return int(lib().eea_batch_agent_lanes(self.h, B))
+
     def close(self):
         if self.h:
             lib().eea_destroy(self.h)
@@ -332,6 +338,10 @@ class Engine:
         io.d_rec_ready, io.d_ck_flag, io.d_status = _ptr(rec_ready), _ptr(ck_flag), _ptr(status)
         fn, h, ref, st = lib().eea_control_batch, self.h, C.byref(io), C.c_void_p(stream or 0)
         keep = (io, pose, ut, u0, mem_cols, n_mem, ck, ck_shared, ck_rec, rec_ready, ck_flag, status)
+        if (rec_ready is not None or ck_flag is not None) and n_steps is not None:
+            # (the engine's own answer for eea_control_batch_steps with the device-bound buffers, ergodic_amd.h)
+            raise EngineError(ERR_UNSUPPORTED, "n_steps cannot be combined with rec_ready / ck_flag: a step must never wait "
+                                               "for an exchange the host enqueues after the launch")
         if rec_ready is not None or ck_flag is not None:
             # device-bound exchange: the sequence numbers change from pass to pass -- call(rec_seq, ck_flag_seq)
             def call_bound(rec_seq=0, ck_flag_seq=0, _keep=keep):

@@ -91,6 +91,13 @@ bool control_wave_eligible(const ControlParams<R>& p, bool rollout_only);
 template <typename R>
 hipError_t launch_control_wave(const ControlParams<R>& p, unsigned B, int model, bool rollout_only,
                                hipStream_t stream);
+// Several agents per wavefront (control_pack_impl.hpp): groups of 8 / 16 / 32 lanes per agent, fp64, K = 5 / 10,
+// T <= 4 lanes.  control_pack_lanes: the group size for a batch of B agents (0 = one wavefront per agent); forced = the
+// value of EEA_OPT_AGENT_LANES
+bool control_pack_eligible(const ControlParams<double>& p, int lanes);
+int control_pack_lanes(const ControlParams<double>& p, unsigned B, int forced);
+hipError_t launch_control_pack(const ControlParams<double>& p, unsigned B, int model, bool rollout_only, int lanes,
+                               hipStream_t stream);
 // sum of B per-agent records (ControlParams::ck_rec): one launch, a fixed tree (groups of kSumGroup agents in agent
 // order, kSumFan group records per level-1 record, the level-1 records in order), finished by ticket inside the launch.
 // d_ws: >= ck_sum_ws_elems(B, K2) reals, d_ctr: ck_sum_tickets(B, K2) tickets (zero before the first use; they reset

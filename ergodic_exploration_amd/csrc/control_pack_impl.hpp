@@ -1,0 +1,762 @@
+// Fused receding-horizon ergodic control kernel for gfx950 (MI355X): SEVERAL AGENTS PER WAVEFRONT (short horizons).
+//
+// The wavefront-per-agent kernel (control_wave_impl.hpp) maps lane <-> horizon step: at T = 20 (BASELINE configs[1])
+// 44 of its 64 lanes idle, at T = 5 (configs[0]) 59, and a vector instruction costs the same whatever the lane mask.
+// Here an agent is a GROUP OF L = 8, 16 or 32 LANES and a wavefront carries A = 64 / L agents; a lane owns up to
+// S = ceil(T / L) <= 4 consecutive horizon steps of its agent (T <= 4 L).  Same computation, same identities -- one complete
+// `ErgodicControl<ModelT>::control` call (reference ergodic_control.hpp:224-311 minus configTarget) per agent:
+//
+//   * the six horizon scans are SEGMENTED DPP scans: row_shr 1/2/4/8 already stop at the 16-lane rows, the 8-lane groups
+//     mask the steps that would cross, the 32-lane groups add row_bcast15; a group's total comes back over ds_bpermute.
+//     Nothing an agent computes depends on a value of another agent (a NaN agent cannot reach its neighbours);
+//   * c_k on the matrix cores with BLOCK <-> AGENT: v_mfma_f64_4x4x4_4b multiplies four independent 4x4x4 blocks; the
+//     four blocks of an instruction are four different agents (L = 8), two agents x two point quads (L = 16) or four point
+//     quads of one agent (L = 32).  The 32-row tile of a half-pass is staged exactly as in the wavefront kernel (one axis
+//     per lane, the partner's cosine over v_permlane32_swap, even tile rows read by lanes 0..31 and odd rows by lanes
+//     32..63: conflict-free ds_read_b64), only the point -> tile row map differs; one accumulator set per half;
+//   * D = lambda (c - phi) per agent in LDS, agents 2 K^2 dwords apart (K = 10: 8 banks: the A row reads of a gradient
+//     step -- every lane of an agent the same address -- are conflict-free);
+//   * compiled for 3 wavefronts per SIMD (168 registers): the barrier gradient stays in registers, the LDS holds the
+//     tiles / the A agents' D and the parked headings (<= 10.8 KB per wavefront, 12 wavefronts per CU).
+//
+// What it does not take (the engine falls back to the wavefront kernel): the device-bound exchange (sum records, flags),
+// fp32, bases other than K = 5 / 10, the single-agent mailbox.  Which L a batch gets: engine.cpp (pack_lanes).
+#pragma once
+
+#include "control_wave_impl.hpp"
+
+namespace eea
+{
+namespace pack
+{
+using wave::kMaxS;
+using wave::kStageRows;
+using wave::lds_fence;
+using wave::tab_stride;
+
+__host__ __device__ constexpr int d_stride(int K) { return (K * K + 3) & ~3; }  // K = 10: 100 (200 dwords = 8 mod 64), K = 5: 28
+__host__ __device__ constexpr int region_elems(int K, int A)
+{
+  const int t = 2 * kStageRows * tab_stride(K), d = A * d_stride(K);
+  return ((t > d ? t : d) + 3) & ~3;
+}
+__host__ __device__ constexpr int park_elems() { return 2 * kMaxS * kWave; }
+__host__ __device__ constexpr int wave_lds_elems(int K, int A) { return region_elems(K, A) + park_elems(); }
+
+// row_shr:N inside the 16-lane row, lanes without a source read 0
+template <int N>
+__device__ __forceinline__ double row_shr(double v)
+{
+  return dpp_or_zero<0x110 + N, 0xf>(v);
+}
+// inclusive sum scan over the L lanes of each agent (tl = lane % L)
+template <int L>
+__device__ __forceinline__ double seg_inclusive_scan(double v, int tl)
+{
+  if constexpr (L == 8) {
+    // the shifted value of a lane whose source lies in the other agent of the row is dropped (select, not multiply: the
+    // neighbour may hold anything)
+    double t = row_shr<1>(v);
+    v += (tl >= 1) ? t : 0.0;
+    t = row_shr<2>(v);
+    v += (tl >= 2) ? t : 0.0;
+    t = row_shr<4>(v);
+    v += (tl >= 4) ? t : 0.0;
+  } else {
+    v += row_shr<1>(v);
+    v += row_shr<2>(v);
+    v += row_shr<4>(v);
+    v += row_shr<8>(v);
+    if constexpr (L == 32) v += dpp_or_zero<0x142, 0xa>(v);  // row_bcast15 into rows 1 and 3
+  }
+  return v;
+}
+// the value of the agent's last lane in every lane of the agent
+template <int L>
+__device__ __forceinline__ double seg_last(double v, int lane)
+{
+  const int src = (lane | (L - 1)) << 2;
+  const int lo = __builtin_amdgcn_ds_bpermute(src, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(src, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+
+// Point of lane r (0..31) of a half-pass -> row of the 32-row tile.  An instruction group gq (16 rows) multiplies four
+// blocks bb of four points k; its operand reads take row 16 gq + 4 bb + 2 (k & 1) + (k >> 1) (control_wave_impl.hpp: even
+// rows in lanes 0..31, odd rows in lanes 32..63).  Which (gq, bb, k) a point gets decides what a block sums:
+//   L = 8 : bb = agent of the half (4 agents x 8 points: gq = point quad)
+//   L = 16: bb = agent + 2 * (quad & 1), gq = quad >> 1   (the two quads of an agent in a group are blocks bb and bb ^ 2)
+//   L = 32: bb = quad & 3, gq = quad >> 2                 (one agent, its four quads of a group are the four blocks)
+template <int L>
+__device__ __forceinline__ int tile_row(int r)
+{
+  int gq, bb;
+  const int k = r & 3;
+  if constexpr (L == 8) {
+    gq = (r >> 2) & 1;
+    bb = r >> 3;
+  } else if constexpr (L == 16) {
+    const int q = (r >> 2) & 3;
+    gq = q >> 1;
+    bb = (r >> 4) + 2 * (q & 1);
+  } else {
+    const int q = r >> 2;
+    gq = q >> 2;
+    bb = q & 3;
+  }
+  return 16 * gq + 4 * bb + 2 * (k & 1) + (k >> 1);
+}
+// agent (index inside the wavefront) whose points block bb of half h sums
+template <int L>
+__device__ __forceinline__ int block_agent(int h, int bb)
+{
+  if constexpr (L == 8) return 4 * h + bb;
+  else if constexpr (L == 16) return 2 * h + (bb & 1);
+  else return h;
+}
+
+// MODEL, KC (5 or 10), STAGES as in control_wave_kernel; L = lanes per agent; WPB = wavefronts per workgroup
+template <int MODEL, int KC, bool STAGES, int L, int WPB>
+__global__ __launch_bounds__(WPB* kWave, 3) void control_pack_kernel(const ControlParams<double> p_arg, const unsigned B,
+                                                                     const int S_arg, const int rollout_arg)
+{
+  using R = double;
+  (void)p_arg;  // read through the kernel-argument segment below
+  static_assert(L == 8 || L == 16 || L == 32, "lanes per agent");
+  static_assert(KC == 5 || KC == 10, "block contraction: K = 5 or 10");
+  constexpr int A = kWave / L;
+  constexpr int K = KC, K2 = K * K;
+  constexpr int KS = tab_stride(KC);
+  constexpr int NB = (KC + 3) / 4;
+  constexpr int DS = d_stride(KC);
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  typedef const __attribute__((address_space(4))) ControlParams<R> KernArgParams;
+  const int wave_of_block = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int n_steps = ((KernArgParams*)__builtin_amdgcn_kernarg_segment_ptr())->n_steps;
+  // receding-horizon steps per launch (eea_control_batch_steps): as in control_wave_kernel, every step starts from the
+  // hardware lane id and re-reads the launch parameters; the controls of the step before come back from d_ut
+  for (int step = 0; step < n_steps; ++step) {
+  KernArgParams* ka = (KernArgParams*)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(ka));
+  KernArgParams& p = *ka;
+  int lane;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(lane));
+  int wv = wave_of_block;
+  asm volatile("" : "+s"(wv));
+  int S = S_arg, rollout_only = rollout_arg;
+  asm volatile("" : "+s"(S), "+s"(rollout_only));
+  const unsigned wave_base = (blockIdx.x * WPB + wv) * A;  // first agent of this wavefront
+  if (wave_base >= B) return;                              // wavefront-uniform
+  const int tl = lane & (L - 1), al = lane / L;
+  const unsigned b = wave_base + al;
+  const bool agent_in = b < B;
+  // the agent of lane ^ 32 (the partner whose other axis this lane stages)
+  const bool partner_in = (wave_base + (al ^ (A / 2))) < B;
+
+  const int T = p.T;
+  R* const sm = reinterpret_cast<R*>(smem_raw) + static_cast<size_t>(wv) * wave_lds_elems(KC, A);
+  R* const tabx = sm;  // [32 rows][KS]
+  R* const taby = tabx + kStageRows * KS;
+  R* const s_cp = sm + region_elems(KC, A);  // cos of the post-step heading, [j][lane]
+  R* const s_sp = s_cp + kMaxS * kWave;      // sin
+  R* const s_D = tabx;                       // D of agent a at a * DS (after the contraction)
+
+  // lane -> horizon steps of its agent: S consecutive steps from S * tl
+  const int i0 = S * tl;
+  const int cnt = max(0, min(S, T - i0));
+  // lanes of an agent that own a step in slot j
+  auto lanes_in_slot = [&](int j) { return min(L, max(0, (T - j + S - 1) / S)); };
+  R* const ut = p.ut + 3 * static_cast<size_t>(T) * b;
+  const R* const pose = p.pose + 3 * (static_cast<size_t>(step) * p.pose_step_stride + b);
+  // ---- controls: shift left by one column, last column zero (ergodic_control.hpp:233-234) ------------
+  R vx[kMaxS], vy[kMaxS], w[kMaxS];
+  bool bad = false;
+#pragma unroll
+  for (int j = 0; j < kMaxS; ++j) {
+    vx[j] = vy[j] = w[j] = R(0);
+    if (j < S) {
+      const int src = rollout_only ? i0 + j : i0 + j + 1;  // optTraj rolls the controls out as they are
+      if (agent_in && j < cnt && src < T) {
+        vx[j] = ut[3 * src + 0];
+        vy[j] = ut[3 * src + 1];
+        w[j] = ut[3 * src + 2];
+      }
+      // SimpleCart::operator() rejects a lateral velocity (cart.hpp:167-170)
+      if (MODEL == kModelSimpleCart && j < cnt && !(fabs(vy[j]) < R(1.0e-12))) bad = true;
+    }
+  }
+  R x0 = R(0), y0 = R(0), th0 = R(0);
+  if (agent_in) {
+    x0 = pose[0];
+    y0 = pose[1];
+    th0 = pose[2];
+  }
+  // the reference throws out of rk4_.solve: nothing of such an agent is touched (its lanes run on, their stores are off)
+  bool agent_ok = agent_in;
+  if (MODEL == kModelSimpleCart) {
+    const unsigned long long bm = __ballot(bad);
+    const unsigned long long grp = (L == 32) ? 0xffffffffull : ((1ull << L) - 1ull);
+    const bool agent_bad = ((bm >> (lane & ~(L - 1))) & grp) != 0ull;
+    agent_ok = agent_in && !agent_bad;
+    if (tl == 0 && agent_in && p.status != nullptr) {
+      if (agent_bad) p.status[b] = 2;  // EEA_ERR_INVALID_TWIST
+      else if (step == 0) p.status[b] = 0;
+    }
+  } else if (tl == 0 && agent_in && p.status != nullptr && step == 0) {
+    p.status[b] = 0;
+  }
+
+  const R dt = p.dt, dt6 = p.dt6;
+  const R inv_pi = static_cast<R>(1.0 / kPi);
+
+  // ================= forward half ========================================================================
+  // heading: theta_i = wrap(theta_{i-1} + dt/6 (w + 2w + 2w + w)) (integrator.hpp:146-148,183)
+  R thp[kMaxS];
+  {
+    R run = R(0);
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      const R d = dt6 * (((w[j] + R(2) * w[j]) + R(2) * w[j]) + w[j]);
+      run += d;
+      thp[j] = run;
+    }
+    const R incl = seg_inclusive_scan<L>(run, tl);
+    const R base = wave::wrap_pi_fast(th0) + (incl - run);  // heading before the lane's first step
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) thp[j] += base;
+  }
+  // position: x_i = x_{i-1} + dt/6 (k1 + 2 k2 + 2 k3 + k4) with k2 == k3 (integrator.hpp:176-184)
+  R px[kMaxS], py[kMaxS], incx[kMaxS], incy[kMaxS];
+  {
+    R c, s;
+    {
+      const R th_pre0 = thp[0] - dt6 * (((w[0] + R(2) * w[0]) + R(2) * w[0]) + w[0]);
+      sincospi_r(th_pre0 * inv_pi, &s, &c);
+    }
+    bool small = true;
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) small = small && (fabs(dt * (R(0.5) * w[j]) * inv_pi) <= R(0.0625));
+    const bool fast_h = __all(small);
+    R rx = R(0), ry = R(0);
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      incx[j] = incy[j] = R(0);
+      if (j < S) {
+        R sm_, cm, cpost, spost;
+        if (fast_h) {  // wavefront-uniform
+          R sd, cd;
+          sincospi_small(dt * (R(0.5) * w[j]) * inv_pi, &sd, &cd);
+          cm = c * cd - s * sd;
+          sm_ = s * cd + c * sd;
+          cpost = cm * cd - sm_ * sd;
+          spost = sm_ * cd + cm * sd;
+        } else {
+          const R th_pre = (j == 0) ? thp[0] - dt6 * (((w[0] + R(2) * w[0]) + R(2) * w[0]) + w[0]) : thp[j - 1];
+          sincospi_r((th_pre + dt * (R(0.5) * w[j])) * inv_pi, &sm_, &cm);
+          const R c2m = R(1) - R(2) * sm_ * sm_, s2m = R(2) * sm_ * cm;
+          cpost = c2m * c + s2m * s;
+          spost = s2m * c - c2m * s;
+        }
+        R k1x, k1y, k2x, k2y, k4x, k4y;
+        wave::model_xy<R, MODEL>(vx[j], vy[j], c, s, k1x, k1y);
+        wave::model_xy<R, MODEL>(vx[j], vy[j], cm, sm_, k2x, k2y);
+        wave::model_xy<R, MODEL>(vx[j], vy[j], cpost, spost, k4x, k4y);
+        incx[j] = dt6 * (((k1x + R(2) * k2x) + R(2) * k2x) + k4x);
+        incy[j] = dt6 * (((k1y + R(2) * k2y) + R(2) * k2y) + k4y);
+        rx += incx[j];
+        ry += incy[j];
+        s_cp[j * kWave + lane] = cpost;
+        s_sp[j * kWave + lane] = spost;
+        c = cpost;
+        s = spost;
+      }
+      px[j] = rx;
+      py[j] = ry;
+    }
+    const R ix = seg_inclusive_scan<L>(rx, tl), iy = seg_inclusive_scan<L>(ry, tl);
+    const R bx = x0 + (ix - rx), by = y0 + (iy - ry);
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      px[j] += bx;
+      py[j] += by;
+    }
+  }
+  if (STAGES && p.traj != nullptr && agent_ok) {
+    R* const traj = p.traj + 3 * static_cast<size_t>(T) * b;
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      if (j < cnt) {
+        traj[3 * (i0 + j) + 0] = px[j];
+        traj[3 * (i0 + j) + 1] = py[j];
+        traj[3 * (i0 + j) + 2] = wave::wrap_pi_fast(thp[j]);
+      }
+    }
+  }
+  if (STAGES && rollout_only) return;  // optTraj / path (ergodic_control.hpp:313-342): the rollout is all
+
+  // basis angles of the rollout points and the barrier gradient (:453-474), as in control_wave_kernel
+  R c1x[kMaxS], s1x[kMaxS], c1y[kMaxS], s1y[kMaxS], g0[kMaxS], g1[kMaxS];
+  bool small_b = true;
+#pragma unroll
+  for (int j = 1; j < kMaxS; ++j) {
+    small_b = small_b && (fabs(incx[j] * p.inv_lx) <= R(0.0625)) && (fabs(incy[j] * p.inv_ly) <= R(0.0625));
+  }
+  const bool fast_b = __all(small_b);
+#pragma unroll
+  for (int j = 0; j < kMaxS; ++j) {
+    c1x[j] = s1x[j] = c1y[j] = s1y[j] = g0[j] = g1[j] = R(0);
+    if (j < S) {
+      const R x = px[j] - p.map_x, y = py[j] - p.map_y;
+      if (j > 0 && fast_b) {  // wavefront-uniform
+        R sd, cd;
+        sincospi_small(incx[j] * p.inv_lx, &sd, &cd);
+        c1x[j] = c1x[j - 1] * cd - s1x[j - 1] * sd;
+        s1x[j] = s1x[j - 1] * cd + c1x[j - 1] * sd;
+        sincospi_small(incy[j] * p.inv_ly, &sd, &cd);
+        c1y[j] = c1y[j - 1] * cd - s1y[j - 1] * sd;
+        s1y[j] = s1y[j - 1] * cd + c1y[j - 1] * sd;
+      } else {
+        sincospi_r(x * p.inv_lx, &s1x[j], &c1x[j]);
+        sincospi_r(y * p.inv_ly, &s1y[j], &c1y[j]);
+      }
+      const R eps = R(0.05), weight2 = R(50);
+      g0[j] = (fmax(x - (p.lx - eps), R(0)) + fmin(x - eps, R(0))) * weight2;
+      g1[j] = (fmax(y - (p.ly - eps), R(0)) + fmin(y - eps, R(0))) * weight2;
+    }
+  }
+
+  // ---- c_k = (1/N) sum_p cos(a_k1 x_p) cos(b_k2 y_p)  (basis.cpp:109-120) on the matrix cores -----------
+  int nmem = 0;
+  if (p.mem_cols != nullptr && agent_in) {
+    nmem = (p.n_mem != nullptr) ? p.n_mem[b] : static_cast<int>(p.mem_stride);
+    nmem = nmem < 0 ? 0 : (nmem > static_cast<int>(p.mem_stride) ? static_cast<int>(p.mem_stride) : nmem);
+  }
+  R cacc[2][NB][NB];  // one accumulator set per half of the wavefront
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+#pragma unroll
+      for (int J = 0; J < NB; ++J) cacc[h][I][J] = R(0);
+    }
+  }
+  const bool lo = lane < 32;
+  const int trow = tile_row<L>(lane & 31);
+  R* const st_lower = (lo ? tabx : taby) + trow * KS;  // staging the tile of the points of lanes 0..31
+  R* const st_upper = (lo ? taby : tabx) + trow * KS;  // ... of lanes 32..63
+  struct Tab1
+  {
+    R a, b, two;  // T_k, T_{k+1}, 2 cos
+  };
+  auto tab1_init = [&](R c, bool valid) {
+    Tab1 t;
+    t.a = valid ? R(1) : R(0);
+    t.b = valid ? c : R(0);
+    t.two = c + c;
+    return t;
+  };
+  auto tab1_store = [&](const Tab1& t, R* dst, int k) { *reinterpret_cast<double2*>(dst + k) = double2{ t.a, t.b }; };
+  auto tab1_step = [&](Tab1& t) {
+    const R c = t.two * t.b - t.a, d = t.two * c - t.b;
+    t.a = c;
+    t.b = d;
+  };
+  auto stage_cos = [&](R ca, R cb, R& c_lower, R& c_upper) {
+    R from_lower, from_upper;
+    wave::half_swap(cb, from_lower, from_upper);
+    c_lower = lo ? ca : from_lower;
+    c_upper = lo ? from_upper : ca;
+  };
+  constexpr int kPairs = KS / 2;
+  const int orow = 4 * ((lane >> 2) & 3) + 2 * ((lane >> 4) & 1) + (lane >> 5), oi = lane & 3;
+  R qa[2][NB], qb[2][NB];
+  const unsigned oaddr = wave::lds_addr(tabx + orow * KS + oi);
+  auto read_operands4 = [&]() { wave::OperandReads4<KS, NB, 0, 0>::run(oaddr, qa, qb); };
+  auto operands4_ready = [&]() { wave::wait_operands4<NB>(qa, qb); };
+  auto mma4_group = [&](int h, int q) {
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+#pragma unroll
+      for (int J = 0; J < NB; ++J) cacc[h][I][J] = wave::mfma4(qa[q][I], qb[q][J], cacc[h][I][J]);
+    }
+  };
+  // the matrix instructions of one 16-row group with the staging of `dst` (kPairs stores) spread between them
+  auto mma4_group_staging = [&](int h, int q, Tab1& u, R* dst) {
+    constexpr int kEvery = (NB * NB + kPairs - 1) / kPairs;
+    int done = 0;
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+#pragma unroll
+      for (int J = 0; J < NB; ++J) {
+        cacc[h][I][J] = wave::mfma4(qa[q][I], qb[q][J], cacc[h][I][J]);
+        const int n = I * NB + J + 1;
+        if (n % kEvery == 0 && done < kPairs) {
+          tab1_store(u, dst, 2 * done);
+          tab1_step(u);
+          ++done;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+#pragma unroll
+    for (int q2 = 0; q2 < kPairs; ++q2) {
+      if (q2 >= done) {
+        tab1_store(u, dst, 2 * q2);
+        tab1_step(u);
+      }
+    }
+  };
+  {
+    // Rollout points, software-pipelined as in control_wave_kernel: the operands of a half-pass are read first, then the
+    // recurrence + stores of the NEXT half-pass run between the matrix instructions of the first 16-row group; the second
+    // group (lanes tl >= L / 2 of every agent) is skipped when no agent has a point there.
+    R cl, cu;
+    stage_cos(c1x[0], c1y[0], cl, cu);
+    {
+      Tab1 u = tab1_init(cl, (lo ? agent_in : partner_in) && 0 < cnt);
+#pragma unroll
+      for (int q = 0; q < kPairs; ++q) {
+        tab1_store(u, st_lower, 2 * q);
+        tab1_step(u);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      if (j < S) {  // wavefront-uniform
+        const bool second = lanes_in_slot(j) > L / 2;  // wavefront-uniform
+        lds_fence();
+        read_operands4();  // rows of lanes 0..31, slot j
+        lds_fence();       // operands in registers: the tile is free
+        {
+          Tab1 u = tab1_init(cu, (lo ? partner_in : agent_in) && j < cnt);
+          operands4_ready();
+          mma4_group_staging(0, 0, u, st_upper);
+          if (second) mma4_group(0, 1);
+        }
+        lds_fence();
+        read_operands4();  // rows of lanes 32..63, slot j
+        lds_fence();
+        {
+          const int jn = (j + 1 < kMaxS) ? j + 1 : j;
+          stage_cos(c1x[jn], c1y[jn], cl, cu);
+          Tab1 u = tab1_init(cl, (lo ? agent_in : partner_in) && (j + 1 < S) && (j + 1 < cnt));
+          operands4_ready();
+          mma4_group_staging(1, 0, u, st_lower);
+          if (second) mma4_group(1, 1);
+        }
+      }
+    }
+    lds_fence();
+  }
+  // sampled past states are prepended (buffer.cpp:78-108) and shifted like the rollout: rounds of L columns per agent
+  if (p.mem_cols != nullptr) {
+    const R* const mem = p.mem_cols + 3 * static_cast<size_t>(p.mem_stride) * b;
+    for (int c0 = 0; __any(c0 < nmem); c0 += L) {
+      const int q = c0 + tl;
+      const bool valid = q < nmem;  // (nmem = 0 for agents outside the batch)
+      R sa, ca = R(0), sb, cb = R(0);
+      if (valid) {
+        sincospi_r((mem[3 * q + 0] - p.map_x) * p.inv_lx, &sa, &ca);
+        sincospi_r((mem[3 * q + 1] - p.map_y) * p.inv_ly, &sb, &cb);
+      }
+      const unsigned long long vm = __ballot(valid);
+      const bool partner_valid = ((vm >> (lane ^ 32)) & 1ull) != 0ull;
+      const unsigned long long vm2 = __ballot(valid && tl >= L / 2);
+      R cl, cu;
+      stage_cos(ca, cb, cl, cu);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const unsigned half_any = static_cast<unsigned>(vm >> (32 * h)), half_second = static_cast<unsigned>(vm2 >> (32 * h));
+        if (half_any != 0u) {  // wavefront-uniform
+          {
+            // lanes of half h stage the x axis of their own point, the others the y axis of their partner's
+            const bool own = (h == 0) == lo;
+            Tab1 t = tab1_init(h ? cu : cl, own ? valid : partner_valid);
+            R* const dst = h ? st_upper : st_lower;
+#pragma unroll
+            for (int qq = 0; qq < kPairs; ++qq) {
+              tab1_store(t, dst, 2 * qq);
+              tab1_step(t);
+            }
+          }
+          lds_fence();
+          read_operands4();
+          lds_fence();
+          operands4_ready();
+          mma4_group(h, 0);
+          if (half_second != 0u) mma4_group(h, 1);
+        }
+      }
+    }
+  }
+
+  // ---- D = lambda (c - phi), fourier_diff of ergodic_control.hpp:422, per agent ---------------------------------
+  {
+    // lane l = 16 i + 4 bb + j holds, in set h, block bb's sum for c(k1 = 4 I + i, k2 = 4 J + j); the blocks of one agent
+    // are added by row rotations (L = 16: bb and bb ^ 2; L = 32: all four)
+    const int di = lane >> 4, db = (lane >> 2) & 3, dj = lane & 3;
+    R lamv[NB][NB], phiv[NB][NB];
+#pragma unroll
+    for (int I = 0; I < NB; ++I) {
+#pragma unroll
+      for (int J = 0; J < NB; ++J) {
+        const int k1 = 4 * I + di, k2 = 4 * J + dj;
+        const int idx = (k1 < K && k2 < K) ? k2 * K + k1 : 0;
+        lamv[I][J] = p.lamdak[idx];
+        phiv[I][J] = p.phik[idx];
+      }
+    }
+    const bool writer = (L == 8) || (L == 16 && db < 2) || (L == 32 && db == 0);  // one copy stores c_k
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ab = block_agent<L>(h, db);
+      const unsigned bb = wave_base + ab;
+      const bool in = bb < B;
+      int nm = 0;
+      if (p.mem_cols != nullptr && in) {
+        nm = (p.n_mem != nullptr) ? p.n_mem[bb] : static_cast<int>(p.mem_stride);
+        nm = nm < 0 ? 0 : (nm > static_cast<int>(p.mem_stride) ? static_cast<int>(p.mem_stride) : nm);
+      }
+      const R invN = R(1) / static_cast<R>(T + nm);
+#pragma unroll
+      for (int I = 0; I < NB; ++I) {
+#pragma unroll
+        for (int J = 0; J < NB; ++J) {
+          R v = cacc[h][I][J];
+          if constexpr (L == 16) v = wave::add_row_ror<8>(v);
+          if constexpr (L == 32) v = wave::add_row_ror<8>(wave::add_row_ror<4>(v));
+          const int k1 = 4 * I + di, k2 = 4 * J + dj;
+          if (k1 < K && k2 < K) {
+            const int idx = k2 * K + k1;
+            R c = invN * v;
+            if (p.ck != nullptr && in && writer) p.ck[static_cast<size_t>(bb) * K2 + idx] = c;
+            // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
+            if (p.ck_shared != nullptr) c = shared_ck_value(p, p.ck_shared, idx, K2, c);
+            s_D[ab * DS + idx] = lamv[I][J] * (c - phiv[I][J]);
+          }
+        }
+      }
+    }
+    lds_fence();
+  }
+
+  // ================= backward half =======================================================================
+  // per step: ergodic-metric gradient (:418-436, basis.cpp:91-107), one pass over the agent's D per step
+  //   edx_x = -pi/lx sin(a x) sum_k1 k1 U_{k1-1}(cos a x) G(k1),  G(k1) = sum_k2 D(k1,k2) cos(b_k2 y)
+  //   edx_y = -pi/ly sin(b y) sum_k2 k2 U_{k2-1}(cos b y) H(k2),  H(k2) = sum_k1 D(k1,k2) cos(a_k1 x)
+  R ex[STAGES ? kMaxS : 1], ey[STAGES ? kMaxS : 1];
+  const R* const Da = s_D + al * DS;
+#pragma unroll
+  for (int j = 0; j < kMaxS; ++j) {
+    if (STAGES) ex[j] = ey[j] = R(0);
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    if (j < S) {
+      R accx = R(0), accy = R(0);
+      const R twox = c1x[j] + c1x[j], twoy = c1y[j] + c1y[j];
+      R cxa[K], G[K];
+      {
+        R ta = R(1), tb = c1x[j];
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+          cxa[i] = ta;
+          const R tn = twox * tb - ta;
+          ta = tb;
+          tb = tn;
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < K; ++i) G[i] = (i == 0) ? R(0) : Da[i];  // row k2 = 0: cos(0 y) = 1, k2 sin(0) = 0
+      R um = R(0), u0 = R(1);    // U_{k2-2}, U_{k2-1} of the y angle
+      R tm = R(1), t0 = c1y[j];  // T_{k2-1}, T_{k2}
+#pragma unroll
+      for (int k2 = 1; k2 < K; ++k2) {
+        const R* const row = Da + k2 * K;
+        R h = R(0);
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+          const R d = row[i];
+          if (i > 0) G[i] += d * t0;
+          if (i == 0) h = d;  // cos(0 x) = 1
+          else h += d * cxa[i];
+        }
+        accy = wave::fma_k(u0 * h, k2, accy);
+        const R un = twoy * u0 - um;
+        um = u0;
+        u0 = un;
+        const R tn = twoy * t0 - tm;
+        tm = t0;
+        t0 = tn;
+      }
+      {
+        R ua = R(0), ub = R(1);  // U_{k-1}, U_k of the x angle
+#pragma unroll
+        for (int i = 0; i < K; ++i) {
+          if (i > 0) accx = wave::fma_k(ua * G[i], i, accx);
+          const R un = twox * ub - ua;
+          ua = ub;
+          ub = un;
+        }
+      }
+      const R exj = (-p.pi_lx * s1x[j] * accx) * p.expl_weight;
+      const R eyj = (-p.pi_ly * s1y[j] * accy) * p.expl_weight;
+      if (STAGES) {
+        ex[j] = exj;
+        ey[j] = eyj;
+      } else {
+        // g = edx + bdx (inactive steps contribute nothing to the suffix sums)
+        const bool act = j < cnt;
+        g0[j] = act ? exj + g0[j] : R(0);
+        g1[j] = act ? eyj + g1[j] : R(0);
+      }
+    }
+  }
+  if (STAGES && agent_ok) {
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      if (j < cnt) {
+        if (p.edx != nullptr) {
+          R* const o = p.edx + 3 * (static_cast<size_t>(T) * b + i0 + j);
+          o[0] = ex[j];
+          o[1] = ey[j];
+          o[2] = R(0);
+        }
+        if (p.bdx != nullptr) {
+          R* const o = p.bdx + 3 * (static_cast<size_t>(T) * b + i0 + j);
+          o[0] = g0[j];
+          o[1] = g1[j];
+          o[2] = R(0);
+        }
+      }
+    }
+  }
+
+  // co-state (suffix sums over the agent's horizon), as in control_wave_kernel; the controls again from L2
+  R vxr[kMaxS], vyr[kMaxS];
+  {
+    size_t opaque = 0;
+    asm volatile("" : "+v"(opaque));
+    const R* const ut_again = ut + opaque;
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      const int src = i0 + j + 1;
+      const bool ok = agent_in && j < cnt && src < T;
+      vxr[j] = vyr[j] = R(0);
+      if (ok) {
+        vxr[j] = ut_again[3 * src];
+        if (MODEL == kModelOmni) vyr[j] = ut_again[3 * src + 1];
+      }
+    }
+  }
+  R r0[kMaxS], r1[kMaxS];
+  R tot0, tot1, tot2;  // the agent's totals of the three co-state scans
+  {
+    R s0 = R(0), s1 = R(0);
+#pragma unroll
+    for (int j = kMaxS - 1; j >= 0; --j) {
+      if (STAGES) {
+        const bool act = j < cnt;
+        g0[j] = act ? ex[j] + g0[j] : R(0);
+        g1[j] = act ? ey[j] + g1[j] : R(0);
+      }
+      s0 += dt * g0[j];
+      s1 += dt * g1[j];
+      r0[j] = s0;
+      r1[j] = s1;
+    }
+    const R i0s = seg_inclusive_scan<L>(s0, tl), i1s = seg_inclusive_scan<L>(s1, tl);
+    tot0 = seg_last<L>(i0s, lane);
+    tot1 = seg_last<L>(i1s, lane);
+    const R o0 = tot0 - i0s, o1 = tot1 - i1s;
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      r0[j] += o0;
+      r1[j] += o1;
+    }
+  }
+  R r2[kMaxS], cth[kMaxS], sth[kMaxS];
+  {
+    R s2 = R(0);
+#pragma unroll
+    for (int j = kMaxS - 1; j >= 0; --j) {
+      cth[j] = s_cp[j * kWave + lane];
+      sth[j] = s_sp[j * kWave + lane];
+      R a02, a12;
+      if (MODEL == kModelOmni) {
+        a02 = -vxr[j] * sth[j] - vyr[j] * cth[j];
+        a12 = vxr[j] * cth[j] - vyr[j] * sth[j];
+      } else {
+        a02 = -vxr[j] * sth[j];
+        a12 = vxr[j] * cth[j];
+      }
+      const R sE = a02 * (r0[j] - dt * g0[j]) + a12 * (r1[j] - dt * g1[j]);
+      const R sG = a02 * g0[j] + a12 * g1[j];
+      const R qv = (j < S) ? dt * (sE + p.half_dt * sG) : R(0);
+      s2 += qv;
+      r2[j] = s2;
+    }
+    const R i2s = seg_inclusive_scan<L>(s2, tl);
+    tot2 = seg_last<L>(i2s, lane);
+    const R o2 = tot2 - i2s;
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) r2[j] += o2;
+  }
+
+  // ---- u_i = clamp(-Rinv B(x_i)^T rho_i)  (ergodic_control.hpp:438-451) ---------------------------------
+  // min(max()) when every total of every agent of the wavefront is finite, std::clamp's comparisons otherwise (a NaN
+  // passes std::clamp; Rinv's zeros times an infinite co-state make one)
+  const R inf = __builtin_huge_val();
+  const bool finite = __all((fabs(tot0) < inf) && (fabs(tot1) < inf) && (fabs(tot2) < inf));
+  auto update_controls = [&](auto fast_tag) {
+    constexpr bool kFast = decltype(fast_tag)::value;
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      if (j < cnt && agent_ok) {
+        const int i = i0 + j;
+        R v0, v1, v2;
+        if (MODEL == kModelOmni) {  // omni.hpp:205-212
+          v0 = cth[j] * r0[j] + sth[j] * r1[j];
+          v1 = -sth[j] * r0[j] + cth[j] * r1[j];
+          v2 = r2[j];
+        } else {  // cart.hpp:194-203
+          v0 = cth[j] * r0[j] + sth[j] * r1[j];
+          v1 = R(0);
+          v2 = r2[j];
+        }
+        const R n0 = -v0, n1 = -v1, n2 = -v2;
+        R u[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const R ur = (p.Rinv[r] * n0 + p.Rinv[r + 3] * n1) + p.Rinv[r + 6] * n2;
+          u[r] = kFast ? fmin(fmax(ur, p.umin[r]), p.umax[r]) : clamp_std(ur, p.umin[r], p.umax[r]);
+        }
+        ut[3 * i + 0] = u[0];
+        ut[3 * i + 1] = u[1];
+        ut[3 * i + 2] = u[2];
+        if (STAGES && p.rhot != nullptr) {
+          R* const o = p.rhot + 3 * (static_cast<size_t>(T) * b + i);
+          o[0] = r0[j];
+          o[1] = r1[j];
+          o[2] = r2[j];
+        }
+        if (i == 0) {
+          R* const o = p.u0 + 3 * (static_cast<size_t>(step) * p.u0_step_stride + b);
+          o[0] = u[0];
+          o[1] = u[1];
+          o[2] = u[2];
+        }
+      }
+    }
+  };
+  if (finite) update_controls(std::true_type{});  // wavefront-uniform
+  else update_controls(std::false_type{});
+  if (step + 1 < n_steps) {  // the next step reads the controls just stored (its own and its neighbour lanes') and reuses the LDS
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    lds_fence();
+  }
+  }  // step
+}
+
+}  // namespace pack
+}  // namespace eea

@@ -23,7 +23,7 @@ namespace
 using eea::fail;
 
 // process-wide dispatch options (eea_set_option); index = EEA_OPT_*
-std::atomic<int> g_options[EEA_OPT_COUNT] = { { 0 }, { 0 }, { 0 }, { 1 }, { 0 } };
+std::atomic<int> g_options[EEA_OPT_COUNT] = { { 0 }, { 0 }, { 0 }, { 1 }, { 0 }, { 0 } };
 }  // namespace
 
 namespace eea
@@ -595,6 +595,14 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
                         eea::control_wave_eligible<R>(p, rollout_only);
   p.ck_rec = rollout_only ? nullptr : static_cast<R*>(io->d_ck_rec);
   if (use_wave) {
+    // short horizons: several agents share a wavefront (control_pack_impl.hpp) when the batch still fills the chip
+    if constexpr (sizeof(R) == 8) {
+      const int lanes = eea::control_pack_lanes(p, B, eea::option(EEA_OPT_AGENT_LANES));
+      if (lanes != 0) {
+        EEA_HIP(eea::launch_control_pack(p, B, e->cfg.model, rollout_only, lanes, s));
+        return EEA_OK;
+      }
+    }
     EEA_HIP(eea::launch_control_wave<R>(p, B, e->cfg.model, rollout_only, s));
     return EEA_OK;
   }
@@ -677,6 +685,7 @@ eea_status eea_set_option(int option, int value)
     case EEA_OPT_COLLISION_IMPL: ok = value >= 0 && value <= 2; break;
     case EEA_OPT_MAILBOX_POLL: ok = value == 0 || value == 1; break;
     case EEA_OPT_REBUILD_IMPL: ok = value == 0 || value == 1; break;
+    case EEA_OPT_AGENT_LANES: ok = value == 0 || value == 8 || value == 16 || value == 32 || value == 64; break;
     default: return fail(EEA_ERR_INVALID_ARGUMENT, "unknown option");
   }
   if (!ok) return fail(EEA_ERR_INVALID_ARGUMENT, "option value out of range");
@@ -774,6 +783,20 @@ void eea_destroy(eea_engine* e)
 }
 
 unsigned eea_steps(const eea_engine* e) { return e ? static_cast<unsigned>(e->T) : 0u; }
+unsigned eea_batch_agent_lanes(const eea_engine* e, unsigned B)
+{
+  if (e == nullptr || eea::option(EEA_OPT_CONTROL_KERNEL) != 0) return 0u;
+  if (e->cfg.precision == EEA_PREC_F64) {
+    eea::ControlParams<double> p;
+    fill_params<double>(e, p);
+    if (!eea::control_wave_eligible<double>(p, false)) return 0u;
+    const int lanes = eea::control_pack_lanes(p, B, eea::option(EEA_OPT_AGENT_LANES));
+    return lanes != 0 ? static_cast<unsigned>(lanes) : 64u;
+  }
+  eea::ControlParams<float> p;
+  fill_params<float>(e, p);
+  return eea::control_wave_eligible<float>(p, false) ? 64u : 0u;
+}
 unsigned eea_num_modes(const eea_engine* e) { return e ? static_cast<unsigned>(e->K2) : 0u; }
 size_t eea_real_size(const eea_engine* e) { return e ? e->rs : 0; }
 unsigned eea_ck_record_len(const eea_engine* e) { return e ? static_cast<unsigned>(eea::ck_record_len(e->K2)) : 0u; }

@@ -89,11 +89,19 @@ enum { EEA_OPT_CONTROL_KERNEL = 0,    /* 0 = automatic (wavefront-per-agent kern
        EEA_OPT_REBUILD_IMPL = 4,      /* configTarget rebuild of a Gaussian target: 0 = automatic (per-axis factors, one
                                          launch of one workgroup), 1 = fill the grid and stream it (Target::fill +
                                          Basis::spatialCoeff as two / three launches: what explicit grids take) */
-       EEA_OPT_COUNT = 5 };
+       EEA_OPT_AGENT_LANES = 5,       /* lanes of a wavefront per agent in eea_control_batch[_steps] (short horizons share
+                                         a wavefront: T <= 4 lanes, fp64, K = 5 / 10): 0 = by batch size and horizon
+                                         (cost model), 64 = one wavefront per agent always, 8 / 16 / 32 = that group size
+                                         wherever it is eligible (tests, A/B) */
+       EEA_OPT_COUNT = 6 };
 eea_status eea_set_option(int option, int value);
 int eea_get_option(int option);
 
 unsigned eea_steps(const eea_engine* e);      /* T = steps_ (ergodic_control.hpp:199) */
+/* Lanes of a wavefront one agent of a plain eea_control_batch call of B agents occupies under the current options: 64 = one
+ * wavefront per agent, 8 / 16 / 32 = several agents per wavefront (short horizons), 0 = the workgroup-per-agent kernel.
+ * No reference counterpart (introspection for tests and capacity planning). */
+unsigned eea_batch_agent_lanes(const eea_engine* e, unsigned B);
 unsigned eea_num_modes(const eea_engine* e);  /* K^2 */
 size_t eea_real_size(const eea_engine* e);    /* 8 or 4 */
 double eea_time_step(const eea_engine* e);    /* ErgodicControl::timeStep, :350-354 */
