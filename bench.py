@@ -269,10 +269,22 @@ def other_config_legs(args, torch, capi, np, spl):
     Per leg: ms per pass, roofline fraction against the dtype's own vector peak, and the configTarget rebuild of that grid
     (config/explore_omni.yaml:49-56 for the parameter names)."""
     import time as _t
-    B = args.agents
     cases = [
+        # short horizons: several agents share a wavefront (csrc/control_pack_impl.hpp) -- at the headline's 4096 agents a
+        # pass is latency-bound (one or two wavefronts per SIMD), so each shape is also timed at the batch that fills the
+        # chip with resident wavefronts of the engine's choice of lanes per agent (3 x 1024 x 64 / lanes; K = 5: 4 x)
+        dict(name="configs[0]", model="omni", K=5, dt=0.1, horizon=0.5, prec="f64", bounds=MAP_BOUNDS,
+             means=[[2.5, 2.5]], sigmas=[[1.5, 1.5]]),
+        dict(name="configs[0], chip-filling batch", model="omni", K=5, dt=0.1, horizon=0.5, prec="f64", bounds=MAP_BOUNDS,
+             means=[[2.5, 2.5]], sigmas=[[1.5, 1.5]], agents=32768),
         dict(name="configs[1]", model="simple_cart", K=10, dt=0.1, horizon=2.0, prec="f64", bounds=MAP_BOUNDS,
              means=MEANS, sigmas=SIGMAS),
+        dict(name="configs[1], chip-filling batch", model="simple_cart", K=10, dt=0.1, horizon=2.0, prec="f64", bounds=MAP_BOUNDS,
+             means=MEANS, sigmas=SIGMAS, agents=24576),
+        dict(name="explore_omni.yaml as shipped (K = 10, T = 50)", model="omni", K=10, dt=0.1, horizon=5.0, prec="f64",
+             bounds=MAP_BOUNDS, means=MEANS, sigmas=SIGMAS),
+        dict(name="explore_omni.yaml as shipped, chip-filling batch", model="omni", K=10, dt=0.1, horizon=5.0, prec="f64",
+             bounds=MAP_BOUNDS, means=MEANS, sigmas=SIGMAS, agents=12288),
         dict(name="configs[2]", model="omni", K=20, dt=0.02, horizon=5.0, prec="f32", bounds=(0.0, 25.5, 0.0, 25.5),
              means=[[6.0, 6.0], [19.0, 12.0]], sigmas=[[3.0, 3.0], [3.0, 3.0]]),
         dict(name="configs[2] fp64 twin", model="omni", K=20, dt=0.02, horizon=5.0, prec="f64", bounds=(0.0, 25.5, 0.0, 25.5),
@@ -285,6 +297,7 @@ def other_config_legs(args, torch, capi, np, spl):
     ]
     res = []
     for c in cases:
+        B = c.get("agents", args.agents)
         f32 = c["prec"] == "f32"
         tdt = torch.float32 if f32 else torch.float64
         if c["model"] == "simple_cart":
@@ -357,15 +370,18 @@ def other_config_legs(args, torch, capi, np, spl):
         torch.cuda.synchronize()
         nx, ny = eng.target_grid()[1:]
         res.append({"config": c["name"], "kinematics": c["model"], "num_basis": K, "horizon_steps": T, "dt": c["dt"],
-                    "dtype": c["prec"], "agents": B, "n_mem": n_mem, "steps_per_launch": spl, "passes_timed": n_calls * spl,
-                    "ms_per_pass": pass_ms, "value": B / (pass_ms * 1e-3), "unit": "optimisations/s",
+                    "dtype": c["prec"], "agents": B, "lanes_per_agent": eng.agent_lanes(half), "n_mem": n_mem,
+                    "steps_per_launch": spl, "passes_timed": n_calls * spl,
+                    "ms_per_pass": pass_ms, "us_per_4096_agents": 1e3 * pass_ms * 4096 / B,
+                    "value": B / (pass_ms * 1e-3), "unit": "optimisations/s",
                     "roofline": {"bound": "valu-%s" % c["prec"], "achieved": tfl, "peak": peak, "unit": "TFLOP/s",
                                  "frac": tfl / peak, "flops_per_optimisation": flops},
                     "config_domain_rebuild": {"grid": "%dx%d" % (nx, ny), "device_us": 1e3 * evs[0].elapsed_time(evs[1]) / 50,
                                               "enqueue_only_wall_us": 1e6 * enq}})
         eng.close()
     return {"note": "the other single-GPU BASELINE configurations in the headline's launch form (two agent groups x %d steps per "
-                    "launch), 4096 agents, ~0.3 s timed each, HIP events around the launches of both streams" % spl,
+                    "launch), 4096 agents unless the case names its batch, ~0.3 s timed each, HIP events around the launches of "
+                    "both streams; lanes_per_agent < 64: several agents per wavefront (short horizons)" % spl,
             "cases": res}
 
 

@@ -40,8 +40,18 @@ __host__ __device__ constexpr int region_elems(int K, int A)
   const int t = 2 * kStageRows * tab_stride(K), d = A * d_stride(K);
   return ((t > d ? t : d) + 3) & ~3;
 }
-__host__ __device__ constexpr int park_elems() { return 2 * kMaxS * kWave; }
-__host__ __device__ constexpr int wave_lds_elems(int K, int A) { return region_elems(K, A) + park_elems(); }
+// the parked post-step headings: cos and sin, [S][64] each.  S is a launch argument: a horizon of <= 3 steps per lane leaves
+// LDS for more resident wavefronts.  Never less than what the controls' hand-over between the steps of a multi-step launch
+// takes: [3][4 L A = 256] reals from the start of the region
+__host__ __device__ constexpr int park_elems(int S) { return 2 * S * kWave; }
+__host__ __device__ constexpr int wave_lds_elems(int K, int A, int S)
+{
+  const int e = region_elems(K, A) + park_elems(S);
+  return e > 3 * kMaxS * kWave ? e : 3 * kMaxS * kWave;
+}
+// wavefronts per SIMD the kernel is compiled for: K = 5 fits 128 registers, K = 10 takes 164 (the second accumulator set,
+// the barrier gradient in registers)
+constexpr int waves_per_simd(int KC) { return KC == 5 ? 4 : 3; }
 
 // row_shr:N inside the 16-lane row, lanes without a source read 0
 template <int N>
@@ -117,7 +127,7 @@ __device__ __forceinline__ int block_agent(int h, int bb)
 
 // MODEL, KC (5 or 10), STAGES as in control_wave_kernel; L = lanes per agent; WPB = wavefronts per workgroup
 template <int MODEL, int KC, bool STAGES, int L, int WPB>
-__global__ __launch_bounds__(WPB* kWave, 3) void control_pack_kernel(const ControlParams<double> p_arg, const unsigned B,
+__global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_kernel(const ControlParams<double> p_arg, const unsigned B,
                                                                      const int S_arg, const int rollout_arg)
 {
   using R = double;
@@ -134,7 +144,9 @@ __global__ __launch_bounds__(WPB* kWave, 3) void control_pack_kernel(const Contr
   const int wave_of_block = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int n_steps = ((KernArgParams*)__builtin_amdgcn_kernarg_segment_ptr())->n_steps;
   // receding-horizon steps per launch (eea_control_batch_steps): as in control_wave_kernel, every step starts from the
-  // hardware lane id and re-reads the launch parameters; the controls of the step before come back from d_ut
+  // hardware lane id and re-reads the launch parameters.  An agent SimpleCart rejected stays out for the rest of the launch
+  // (control_wave_kernel: its wavefront returns): one bit per lane, wavefront-uniform
+  unsigned long long rejected = 0ull;
   for (int step = 0; step < n_steps; ++step) {
   KernArgParams* ka = (KernArgParams*)__builtin_amdgcn_kernarg_segment_ptr();
   asm volatile("" : "+s"(ka));
@@ -154,11 +166,11 @@ __global__ __launch_bounds__(WPB* kWave, 3) void control_pack_kernel(const Contr
   const bool partner_in = (wave_base + (al ^ (A / 2))) < B;
 
   const int T = p.T;
-  R* const sm = reinterpret_cast<R*>(smem_raw) + static_cast<size_t>(wv) * wave_lds_elems(KC, A);
+  R* const sm = reinterpret_cast<R*>(smem_raw) + static_cast<size_t>(wv) * wave_lds_elems(KC, A, S);
   R* const tabx = sm;  // [32 rows][KS]
   R* const taby = tabx + kStageRows * KS;
   R* const s_cp = sm + region_elems(KC, A);  // cos of the post-step heading, [j][lane]
-  R* const s_sp = s_cp + kMaxS * kWave;      // sin
+  R* const s_sp = s_cp + S * kWave;          // sin
   R* const s_D = tabx;                       // D of agent a at a * DS (after the contraction)
 
   // lane -> horizon steps of its agent: S consecutive steps from S * tl
@@ -171,19 +183,40 @@ __global__ __launch_bounds__(WPB* kWave, 3) void control_pack_kernel(const Contr
   // ---- controls: shift left by one column, last column zero (ergodic_control.hpp:233-234) ------------
   R vx[kMaxS], vy[kMaxS], w[kMaxS];
   bool bad = false;
+  // the controls a step leaves for the next one change hands in LDS (everything there is dead between the update and the
+  // next forward half): s_next[r][4 L al + step index], read back one column to the right (a rejected agent left nothing
+  // there: it stays rejected, below)
+  R* const s_next = sm + kMaxS * L * al;
+  if (step == 0) {  // wavefront-uniform
 #pragma unroll
-  for (int j = 0; j < kMaxS; ++j) {
-    vx[j] = vy[j] = w[j] = R(0);
-    if (j < S) {
-      const int src = rollout_only ? i0 + j : i0 + j + 1;  // optTraj rolls the controls out as they are
-      if (agent_in && j < cnt && src < T) {
-        vx[j] = ut[3 * src + 0];
-        vy[j] = ut[3 * src + 1];
-        w[j] = ut[3 * src + 2];
+    for (int j = 0; j < kMaxS; ++j) {
+      vx[j] = vy[j] = w[j] = R(0);
+      if (j < S) {
+        const int src = rollout_only ? i0 + j : i0 + j + 1;  // optTraj rolls the controls out as they are
+        if (agent_in && j < cnt && src < T) {
+          vx[j] = ut[3 * src + 0];
+          vy[j] = ut[3 * src + 1];
+          w[j] = ut[3 * src + 2];
+        }
+        // SimpleCart::operator() rejects a lateral velocity (cart.hpp:167-170)
+        if (MODEL == kModelSimpleCart && j < cnt && !(fabs(vy[j]) < R(1.0e-12))) bad = true;
       }
-      // SimpleCart::operator() rejects a lateral velocity (cart.hpp:167-170)
-      if (MODEL == kModelSimpleCart && j < cnt && !(fabs(vy[j]) < R(1.0e-12))) bad = true;
     }
+  } else {
+#pragma unroll
+    for (int j = 0; j < kMaxS; ++j) {
+      vx[j] = vy[j] = w[j] = R(0);
+      if (j < S) {
+        const int src = i0 + j + 1;
+        if (agent_in && j < cnt && src < T) {
+          vx[j] = s_next[0 * kMaxS * kWave + src];
+          vy[j] = s_next[1 * kMaxS * kWave + src];
+          w[j] = s_next[2 * kMaxS * kWave + src];
+        }
+        if (MODEL == kModelSimpleCart && j < cnt && !(fabs(vy[j]) < R(1.0e-12))) bad = true;
+      }
+    }
+    lds_fence();  // (read before the forward half writes the park and the tiles)
   }
   R x0 = R(0), y0 = R(0), th0 = R(0);
   if (agent_in) {
@@ -194,7 +227,8 @@ __global__ __launch_bounds__(WPB* kWave, 3) void control_pack_kernel(const Contr
   // the reference throws out of rk4_.solve: nothing of such an agent is touched (its lanes run on, their stores are off)
   bool agent_ok = agent_in;
   if (MODEL == kModelSimpleCart) {
-    const unsigned long long bm = __ballot(bad);
+    rejected |= __ballot(bad);
+    const unsigned long long bm = rejected;
     const unsigned long long grp = (L == 32) ? 0xffffffffull : ((1ull << L) - 1ull);
     const bool agent_bad = ((bm >> (lane & ~(L - 1))) & grp) != 0ull;
     agent_ok = agent_in && !agent_bad;
@@ -733,6 +767,11 @@ __global__ __launch_bounds__(WPB* kWave, 3) void control_pack_kernel(const Contr
         ut[3 * i + 0] = u[0];
         ut[3 * i + 1] = u[1];
         ut[3 * i + 2] = u[2];
+        if (step + 1 < n_steps) {  // wavefront-uniform: hand-over to the next step
+          s_next[0 * kMaxS * kWave + i] = u[0];
+          s_next[1 * kMaxS * kWave + i] = u[1];
+          s_next[2 * kMaxS * kWave + i] = u[2];
+        }
         if (STAGES && p.rhot != nullptr) {
           R* const o = p.rhot + 3 * (static_cast<size_t>(T) * b + i);
           o[0] = r0[j];

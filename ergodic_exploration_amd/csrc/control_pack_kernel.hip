@@ -12,7 +12,7 @@ hipError_t launch_pack_one(const ControlParams<double>& p, unsigned B, bool roll
 {
   constexpr int A = kWave / L;
   const int S = (p.T + L - 1) / L;
-  const size_t lds = static_cast<size_t>(kPackWPB) * pack::wave_lds_elems(KC, A) * sizeof(double);
+  const size_t lds = static_cast<size_t>(kPackWPB) * pack::wave_lds_elems(KC, A, S) * sizeof(double);
   const unsigned waves = (B + A - 1) / A;
   hipLaunchKernelGGL((pack::control_pack_kernel<MODEL, KC, STAGES, L, kPackWPB>), dim3((waves + kPackWPB - 1) / kPackWPB),
                      dim3(kPackWPB * kWave), lds, stream, p, B, S, rollout_only ? 1 : 0);
@@ -52,11 +52,16 @@ bool control_pack_eligible(const ControlParams<double>& p, int lanes)
 }
 
 // Lanes per agent for a batch of B agents: 0 = the wavefront-per-agent kernel.  `forced` (EEA_OPT_AGENT_LANES): 64 = never
-// pack, 8 / 16 / 32 = that group size where eligible; 0 = by the cost model:
-//   the packed kernel issues about I(S) = 440 + 450 S vector instructions per WAVEFRONT of A = 64 / L agents (S = ceil(T / L)
-//   steps per lane; control_wave_kernel: the same with A = 1, L = 64), and a SIMD with w resident wavefronts retires one fp64
-//   instruction per max(5.4, 12 / w) cycles (profiles/r04_ubench_rates.txt: 0.34 / 0.65 / 0.74 of the pipe at 1 / 2 / 4
-//   wavefronts) -- so packing pays only while the batch still fills the 1024 SIMDs with >= 2 wavefronts each.
+// pack, 8 / 16 / 32 = that group size where eligible; 0 = by the cost model below, fitted to profiles/r05_pack_sweep.txt:
+//   * a wavefront of either kernel issues I(S) = 600 + 580 S pipe slots (K = 10; 500 + 250 S at K = 5), S = ceil(T / L) steps
+//     per lane -- measured SQ_INSTS_VALU: 1071 / 1540 / 2010 at S = 1 / 2 / 3 with L = 64 and 1099 / 1568 / 2039 / 2509 with
+//     L = 8, matrix instructions counted four times -- whatever the number of agents in it;
+//   * w wavefronts per SIMD retire an instruction per max(16, 5 w) cycles each: one wavefront alone waits on its own
+//     dependency chains (T = 20, one wavefront per SIMD: 7.6 us = 16 cycles per instruction), from ~3 per SIMD on the pipe is
+//     the limit (0.75 - 0.8 busy);
+//   * the call is taken to be one of TWO concurrent agent groups (the launch form of bench.py and AgentBatch): w = 2 x its own
+//     wavefronts / 1024 SIMDs.
+// Ties go to the narrower group; a batch of fewer than 256 wavefronts is not worth packing.
 int control_pack_lanes(const ControlParams<double>& p, unsigned B, int forced)
 {
   if (forced == 64) return 0;
@@ -67,12 +72,12 @@ int control_pack_lanes(const ControlParams<double>& p, unsigned B, int forced)
     if (lanes < 64 && !control_pack_eligible(p, lanes)) continue;
     if (lanes == 64 && p.T > 4 * 64) continue;
     const int A = 64 / lanes, S = (p.T + lanes - 1) / lanes;
-    const double waves = static_cast<double>((B + A - 1) / A) / 1024.0;  // per SIMD
-    const double w_res = waves < 1.0 ? 1.0 : (waves > (lanes == 64 ? 4.0 : 3.0) ? (lanes == 64 ? 4.0 : 3.0) : waves);
-    const double cpi = 12.0 / w_res > 5.4 ? 12.0 / w_res : 5.4;
-    const double rounds = waves < 1.0 ? 1.0 : waves / w_res;  // sequential rounds of resident wavefronts
-    const double cost = (440.0 + 450.0 * S) * cpi * w_res * rounds;
-    if (best_l == 0 || cost < best * 0.97) {  // (ties go to the wider group: fewer agents share a wavefront's fate)
+    const unsigned waves = (B + A - 1) / A;
+    if (lanes < 64 && waves < 256u) continue;
+    const double w = 2.0 * static_cast<double>(waves) / 1024.0;
+    const double insts = p.K == 5 ? 500.0 + 250.0 * S : 600.0 + 580.0 * S;
+    const double cost = insts * (5.0 * w > 16.0 ? 5.0 * w : 16.0);
+    if (best_l == 0 || cost <= best) {
       best = cost;
       best_l = lanes;
     }

@@ -176,6 +176,21 @@ def test_packed_agents_do_not_leak_into_each_other(lanes, L, steps):
             assert np.array_equal(ut_a[b], ut_bad[b]) and (u0_a[b] == -7.0).all()
         else:
             assert st_a[b] == 0 and np.array_equal(ut_a[b], ut_ref[b]) and np.array_equal(u0_a[b], u0_ref[b])
+    # (a') the same in a multi-step launch: rejected in step 0, out for the rest of the launch (its wavefront neighbours carry on)
+    n_steps = 3
+    d_ut_r, d_ut_b = dev(ut0), dev(ut_bad)
+    d_u0_r = torch.full((n_steps, B, 3), -7.0, dtype=torch.float64, device="cuda")
+    d_u0_b = torch.full((n_steps, B, 3), -7.0, dtype=torch.float64, device="cuda")
+    d_st = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+    eng.control_batch(B, dev(poses), d_ut_r, d_u0_r, n_steps=n_steps, u0_step_stride=B)
+    eng.control_batch(B, dev(poses), d_ut_b, d_u0_b, n_steps=n_steps, u0_step_stride=B, status=d_st)
+    torch.cuda.synchronize()
+    ut_r, ut_m, u0_r, u0_m, st_m = (t.cpu().numpy() for t in (d_ut_r, d_ut_b, d_u0_r, d_u0_b, d_st))
+    for b in range(B):
+        if b in bad:
+            assert st_m[b] == capi.ERR_INVALID_TWIST and np.array_equal(ut_m[b], ut_bad[b]) and (u0_m[:, b] == -7.0).all()
+        else:
+            assert st_m[b] == 0 and np.array_equal(ut_m[b], ut_r[b]) and np.array_equal(u0_m[:, b], u0_r[:, b])
     # (b) non-finite poses
     p2 = poses.copy()
     p2[2, 0] = np.nan
@@ -228,13 +243,20 @@ def test_packed_consensus_ck_and_rollout(lanes, L, steps):
 
 
 def test_engine_choice_of_lanes_per_agent():
-    """automatic choice (EEA_OPT_AGENT_LANES = 0): packing only while the batch keeps >= 2 wavefronts on every SIMD;
-    ineligible shapes (fp32, other K, long horizons) keep one wavefront per agent; the forced values fall back the same way"""
+    """automatic choice (EEA_OPT_AGENT_LANES = 0, cost model of csrc/control_pack_kernel.hip): packing only while the batch
+    still fills the SIMDs; ineligible shapes (fp32, other K, long horizons) keep one wavefront per agent; the forced values
+    fall back the same way"""
     capi.set_option(capi.OPT_AGENT_LANES, 0)
     eng, _ = make_pair("simple_cart", 10, 2.0, n_oracles=0)       # BASELINE configs[1]: T = 20
-    assert eng.agent_lanes(64) == 64 and eng.agent_lanes(1024) == 64
-    assert eng.agent_lanes(4096) == 32                           # 2048 wavefronts: two per SIMD
-    assert eng.agent_lanes(32768) == 8
+    assert eng.agent_lanes(64) == 64 and eng.agent_lanes(256) == 64
+    assert eng.agent_lanes(2048) == 32 and eng.agent_lanes(4096) == 32
+    assert eng.agent_lanes(6144) == 16 and eng.agent_lanes(12288) == 8 and eng.agent_lanes(32768) == 8
+    eng.close()
+    eng, _ = make_pair("omni", 10, 5.0, n_oracles=0)              # yaml as shipped: T = 50
+    assert eng.agent_lanes(2048) == 64 and eng.agent_lanes(6144) == 16 and eng.agent_lanes(1 << 20) == 16
+    eng.close()
+    eng, _ = make_pair("omni", 5, 0.5, n_oracles=0)               # BASELINE configs[0]: T = 5
+    assert eng.agent_lanes(2048) == 8 and eng.agent_lanes(1 << 20) == 8
     eng.close()
     eng, _ = make_pair("omni", 10, 20.0, n_oracles=0)             # T = 200: never
     assert eng.agent_lanes(1 << 20) == 64
