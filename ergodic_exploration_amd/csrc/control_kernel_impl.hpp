@@ -347,7 +347,8 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
           }
           return;
         }
-        if (tid == 0 && p.status != nullptr) p.status[b] = 0;
+        // (device-bound exchange: a time-out an earlier pass left in a reused buffer stays until the caller clears it)
+        if (tid == 0 && p.status != nullptr && !(p.ck_flag != nullptr && p.status[b] == 6)) p.status[b] = 0;
       }
       EEA_STAMP(2);
 
@@ -671,11 +672,19 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
       }
     }
     bool use_shared = p.ck_shared != nullptr;
-    if (use_shared && p.ck_flag != nullptr) {  // ... consumer side: wait for the shared c_k's flag (every wavefront)
-      bool ok = wait_flag(p.ck_flag, p.ck_flag_seq);
-      if (ok && p.ck_shared_parts > 0) ok = !(load_agent(p.ck_shared + K2) < R(0));
-      if (!ok && tid == 0 && p.status != nullptr) p.status[b] = 6;  // EEA_ERR_TIMEOUT
-      use_shared = ok;  // (the same outcome in every wavefront of the agent: the flag only grows; a give-up is final)
+    if (use_shared && p.ck_flag != nullptr) {
+      // ... consumer side: wavefront 0 waits for the shared c_k's flag and hands its outcome to the others through LDS -- one
+      // polling stream per agent, and ONE outcome: near the poll bound a second poller could see the flag the first gave
+      // up on, and the agent would mix its own and the shared c_k
+      if (wave == 0) {
+        bool ok = wait_flag(p.ck_flag, p.ck_flag_seq);
+        if (ok && p.ck_shared_parts > 0) ok = !(load_agent(p.ck_shared + K2) < R(0));
+        if (!ok && tid == 0 && p.status != nullptr) p.status[b] = 6;  // EEA_ERR_TIMEOUT
+        if (tid == 0) s_sw[46] = ok ? R(1) : R(0);  // (a scratch slot no scan uses)
+      }
+      __syncthreads();
+      use_shared = s_sw[46] != R(0);
+      __syncthreads();
     }
     for (int m = tid; m < K2; m += BLK) {
       R c = s_D[m];

@@ -404,7 +404,9 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
     }
     return;
   }
-  if (lane == 0 && p.status != nullptr && step == 0) p.status[b] = 0;  // (a time-out of an earlier step of the launch stays)
+  // (a time-out of an earlier step of the launch stays; device-bound exchange: so does one an earlier PASS left in a reused
+  // buffer, until the caller clears it)
+  if (lane == 0 && p.status != nullptr && step == 0 && !(p.ck_flag != nullptr && p.status[b] == 6)) p.status[b] = 0;
   EEA_WSTAMP(1);
 
   const R dt = p.dt, dt6 = p.dt6;
@@ -697,36 +699,16 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   // lanes 32..63.  Round 3's map (row = 4 b + k: rows {0,1,4,5,...} in one lane group) put every window on half of
   // another one's banks: 2 extra LDS cycles per operand read (SQ_LDS_BANK_CONFLICT 390 per agent, profiles/r04_lds_conflicts.txt)
   // K = 20: rows 40 dwords apart, 8 consecutive rows tile the 64 banks: rows 0..7 for lanes 0..31, 8..15 for lanes 32..63.
-#ifdef EEA_OROW_R03
-  const int orow = 4 * ((lane >> 2) & 3) + (lane >> 4), oi = lane & 3;
-#else
   const int orow = (KC == 20) ? 8 * (lane >> 5) + 4 * ((lane >> 4) & 1) + ((lane >> 2) & 3)
                               : 4 * ((lane >> 2) & 3) + 2 * ((lane >> 4) & 1) + (lane >> 5);
   const int oi = lane & 3;
-#endif
   R qa[2][kBlock4 ? NB : 1], qb[2][kBlock4 ? NB : 1];
   const unsigned oaddr = lds_addr(tabx + orow * KS + oi);
   auto read_operands4 = [&]() {  // both 16-row groups of the tile: issued here, waited for by operands4_ready()
-    if constexpr (kBlock4) {
-#ifdef EEA_OPERAND_READS_COMPILER
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-#pragma unroll
-        for (int g = 0; g < NB; ++g) {
-          const int off = (16 * q + orow) * KS + 4 * g + oi;
-          qa[q][g] = tabx[off];
-          qb[q][g] = taby[off];
-        }
-      }
-#else
-      OperandReads4<KS, NB, 0, 0>::run(oaddr, qa, qb);
-#endif
-    }
+    if constexpr (kBlock4) OperandReads4<KS, NB, 0, 0>::run(oaddr, qa, qb);
   };
   auto operands4_ready = [&]() {
-#ifndef EEA_OPERAND_READS_COMPILER
     if constexpr (kBlock4) wait_operands4<NB>(qa, qb);
-#endif
   };
   auto mma4_group = [&](int q) {
 #pragma unroll
@@ -1609,9 +1591,11 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   // 2 compares + 4 selects + the moves that feed them: 125 -> ~30 vector instructions per agent -- would turn it into the
   // lower limit.  A NaN anywhere in the agent's state or gradients reaches one of the three co-state scan totals (they
   // sum every step's g and every step's A(x, u) rho terms), so ONE wavefront-uniform test picks the form: the fast one
-  // when the totals are numbers, the comparing one otherwise (signed zeros: max / min may return +0 where std::clamp
+  // when the totals are finite, the comparing one otherwise (signed zeros: max / min may return +0 where std::clamp
   // returns -0; equal as numbers).
-  const bool nan_free = __all((tot0 == tot0) && (tot1 == tot1) && (tot2 == tot2));
+  // (FINITE, not merely numbers: an infinite co-state times Rinv's zeros is a NaN the totals do not show)
+  const R inf_r = static_cast<R>(__builtin_huge_val());
+  const bool nan_free = __all((fabs(tot0) < inf_r) && (fabs(tot1) < inf_r) && (fabs(tot2) < inf_r));
   auto update_controls = [&](auto fast_tag) {
   constexpr bool kFast = decltype(fast_tag)::value;
 #pragma unroll

@@ -117,12 +117,20 @@ struct eea_engine
   {
     const void* key = nullptr;
     unsigned long last_use = 0;
+    hipStream_t last_stream = nullptr;  // the stream of the last launch that used the buffers
     DevBuf ws, ctr;
   };
   std::vector<std::unique_ptr<SumWs>> sum_ws;  // (pointers: a workspace in use must not move when the list grows)
   std::mutex sum_mutex;
   unsigned long sum_clock = 0;
-  std::vector<void*> retired;  // device buffers replaced while launches may still use them: freed with the engine
+  // device buffers replaced while launches may still use them: freed once the event recorded behind their last launch has
+  // completed (or with the engine)
+  struct Retired
+  {
+    void* p;
+    hipEvent_t done;
+  };
+  std::vector<Retired> retired;
 
   // single-agent path
   hipStream_t stream1 = nullptr;
@@ -509,10 +517,11 @@ void fill_params(const eea_engine* e, eea::ControlParams<R>& p)
 // distinct d_sum buffers); at most kMaxSumWs of them -- a caller that passes a fresh output buffer every call recycles
 // the least recently used workspace instead of growing the list.  The tickets are zeroed on the launch stream.
 constexpr size_t kMaxSumWs = 32;
+// (the caller holds e->sum_mutex, and keeps it across its launch: a second thread that misses with every workspace in use
+// must not recycle this one between the lookup and the launch)
 template <typename R>
 eea_status sum_workspace(eea_engine* e, const void* key, unsigned B, hipStream_t s, eea_engine::SumWs** out)
 {
-  std::lock_guard<std::mutex> lock(e->sum_mutex);
   eea_engine::SumWs* w = nullptr;
   for (auto& cand : e->sum_ws) {
     if (cand->key == key) w = cand.get();
@@ -536,21 +545,35 @@ eea_status sum_workspace(eea_engine* e, const void* key, unsigned B, hipStream_t
   const size_t need_ctr = sizeof(unsigned) * eea::ck_sum_tickets(B, e->K2);
   if (need_ws > w->ws.cap || need_ctr > w->ctr.cap || recycled) {
     // NO device synchronisation here (a per-pass call must not stall every stream of the device): buffers an
-    // earlier launch may still use are retired, not freed (released with the engine, or in one sweep when many have
-    // piled up); a recycled workspace gets fresh buffers for the same reason.
-    if (e->retired.size() >= 128) {  // a caller that churns output buffers: pay ONE synchronisation per 64 recycled sums
-      EEA_HIP(hipDeviceSynchronize());
-      for (void* q : e->retired) (void)hipFree(q);
-      e->retired.clear();
+    // earlier launch may still use are retired behind an event on that launch's stream and freed once it has completed
+    // (no device-wide sweep); a recycled workspace gets fresh buffers for the same reason.
+    for (size_t i = 0; i < e->retired.size();) {
+      if (hipEventQuery(e->retired[i].done) == hipSuccess) {
+        (void)hipEventDestroy(e->retired[i].done);
+        (void)hipFree(e->retired[i].p);
+        e->retired[i] = e->retired.back();
+        e->retired.pop_back();
+      } else {
+        ++i;
+      }
     }
-    if (w->ws.p != nullptr) e->retired.push_back(w->ws.p);
-    if (w->ctr.p != nullptr) e->retired.push_back(w->ctr.p);
+    (void)hipGetLastError();  // (hipErrorNotReady of the queries is not an error of this call)
+    for (void* q : { w->ws.p, w->ctr.p }) {
+      if (q == nullptr) continue;
+      hipEvent_t ev = nullptr;
+      EEA_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      EEA_HIP(hipEventRecord(ev, w->last_stream));
+      e->retired.push_back({ q, ev });
+    }
+    w->ws.p = nullptr;   // (ownership moved to the retired list)
+    w->ctr.p = nullptr;
     w->ws = DevBuf();
     w->ctr = DevBuf();
     EEA_HIP(w->ws.reserve(need_ws));
     EEA_HIP(w->ctr.reserve(need_ctr));
     EEA_HIP(hipMemsetAsync(w->ctr.p, 0, w->ctr.cap, s));  // the tickets reset themselves from here on
   }
+  w->last_stream = s;
   *out = w;
   return EEA_OK;
 }
@@ -774,7 +797,10 @@ void eea_destroy(eea_engine* e)
     w->ws.release();
     w->ctr.release();
   }
-  for (void* q : e->retired) (void)hipFree(q);
+  for (auto& r : e->retired) {
+    (void)hipEventDestroy(r.done);
+    (void)hipFree(r.p);
+  }
   if (e->ev_done) (void)hipEventDestroy(e->ev_done);
   if (e->ev_rebuild) (void)hipEventDestroy(e->ev_rebuild);
   if (e->h_mail) (void)hipHostFree(e->h_mail);
@@ -1118,6 +1144,7 @@ static eea_status records_sum_impl(eea_engine* e, unsigned B, const void* d_ck_r
   if (st != EEA_OK) return st;
   hipStream_t s = static_cast<hipStream_t>(stream);
   eea_engine::SumWs* w = nullptr;
+  std::lock_guard<std::mutex> lock(e->sum_mutex);  // across the launch: the workspace must not be recycled under it
   st = e->f32 ? sum_workspace<float>(e, d_sum, B, s, &w) : sum_workspace<double>(e, d_sum, B, s, &w);
   if (st != EEA_OK) return st;
   if (e->f32) {

@@ -240,7 +240,7 @@ unsigned eea_ck_record_len(const eea_engine* e);
  * kernel).  Concurrent calls on one engine must use distinct d_sum buffers. */
 eea_status eea_ck_records_sum(eea_engine* e, unsigned B, const void* d_ck_rec, void* d_sum, void* stream);
 /* ABI 4, device-bound form: the same sum, but the launch does not have to be ordered behind the control kernels that
- * write the records -- every unit of the sum polls the ready marks of its 32 agents (d_rec_ready[b] == seq,
+ * write the records -- every unit of the sum polls the ready marks of its 32 agents (d_rec_ready[b] - seq >= 0 mod 2^32,
  * eea_batch_io::d_rec_ready / rec_seq of the producing calls) and starts when they are there.  d_flag != NULL: *d_flag = seq
  * is published (write-through, behind the drained sum record) by the wavefront that completes the sum -- what
  * eea_batch_io::d_ck_flag of the consuming calls waits for.  Agents that never report within about a second make the
@@ -327,15 +327,17 @@ eea_status eea_comm_records_exchange_async(eea_engine* e, eea_comm* c, unsigned 
                                            void* d_sum, void* const* group_streams, unsigned n_streams, int slot);
 /* ABI 4 -- the same exchange DEVICE-BOUND, for a consensus on EVERY pass at the device's own rate (a pass of 4096 agents
  * takes ~23 us: no host wait and no stream wait fits into it).  Nothing is ordered by the host: on the communicator's
- * stream, eea_ck_records_sum_bound (polls the agents' ready marks d_rec_ready == seq: it runs while the producing control
- * kernels are still in their backward halves), with an RCCL communicator the all-reduce of the sum record over the ranks +
+ * stream, eea_ck_records_sum_bound (polls the agents' ready marks until d_rec_ready - seq >= 0 (mod 2^32): it runs while
+ * the producing control kernels are still in their backward halves), with an RCCL communicator the all-reduce of the sum record over the ranks +
  * eea_publish_record, and *d_flag = seq behind the finished d_sum.  The consuming control calls are launched WITHOUT
  * waiting, with eea_batch_io::d_ck_shared = d_sum, ck_shared_parts = 1, d_ck_flag = d_flag, ck_flag_seq = seq: they wait
  * inside the kernel, right before the first use of the shared c_k.  A consensus of lag n passes = pass i consumes seq i - n;
  * lag 1 is the previous step's c_bar (decentralised ergodic control, reference README ref. [2]).
  * The caller rotates d_ck_rec / d_sum over >= lag + 2 buffers (slot = buffer index, < EEA_COMM_SLOTS); d_rec_ready [B_local]
- * and d_flag [1] may be shared by all of them (sequence numbers only grow; zero them once).  Every launch that waits for a
- * flag must leave room for what it waits for: the producers of that flag (control kernels of other agent groups, the
+ * and d_flag [1] may be shared by all of them (sequence numbers only grow; zero them once, and start the sequence at 1:
+ * zeroed marks and flags satisfy seq 0 at once).  A per-agent EEA_ERR_TIMEOUT in a d_status buffer that is reused from pass
+ * to pass STAYS until the caller clears it (calls with d_ck_flag do not reset a status of 6; every other call rewrites
+ * d_status).  Every launch that waits for a flag must leave room for what it waits for: the producers of that flag (control kernels of other agent groups, the
  * record sum's single-wavefront workgroups, the all-reduce) have to become resident BESIDE the waiting wavefronts -- two
  * agent groups per GPU of at most half its execution slots each do (the fp64 K <= 10 instance leaves registers for the
  * sum beside a full set of control wavefronts); a waiter that cannot be served gives up after about a second
