@@ -396,6 +396,34 @@ TICK_SHAPES = [
 ]
 
 
+def cpp_host_loop_leg(agents):
+    """The consensus leg's enqueue loop from a C++ host (host/test/consensus_bench.cpp through the C ABI) instead of this
+    file's Python: (a) local exchange, lag 1; (b) with a COLLECTIVE KERNEL in the exchange -- one rank whose all-reduce is a
+    kernel of the stream-asynchronous test double tests/fake_rccl (512 threads x 96 registers x 16 KB of LDS per block: it has
+    to become resident beside the control kernels, what a real multi-GPU run's RCCL kernel has to) -- lag 2 and 3, last
+    group stream-ordered.  Own processes (their own HIP runtime, nothing shared with this one)."""
+    import subprocess
+    root = os.path.dirname(os.path.abspath(__file__))
+    exe = os.path.join(root, "ergodic_exploration_amd", "host", "build", "consensus_bench")
+    fake = os.path.join(root, "tests", "fake_rccl", "librccl.so.1")
+    if not os.path.exists(exe):
+        return {"error": "host/build/consensus_bench is not built (__graft_entry__.build())"}
+    out = {"driver": "ergodic_exploration_amd/host/test/consensus_bench.cpp", "agents": agents, "cases": []}
+    cases = [("local exchange (no collective)", "", 1)]
+    if os.path.exists(fake):
+        cases += [("collective kernel in the exchange (test double)", fake, 2), ("collective kernel in the exchange (test double)", fake, 3)]
+    for name, lib, lag in cases:
+        try:
+            r = subprocess.run([exe, "3000", str(agents), "1", lib, str(lag), "2"], capture_output=True, text=True, timeout=120)
+            line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+            res = json.loads(line[-1][len("RESULT "):]) if line else {"error": (r.stdout + r.stderr)[-300:]}
+        except Exception as exc:  # noqa: BLE001
+            res = {"error": repr(exc)}
+        res["exchange"] = name
+        out["cases"].append(res)
+    return out
+
+
 def single_robot_ticks(torch, capi, np):
     """Dependent eea_control calls of ONE agent at every BASELINE shape: wall time per call including the host round trip
     (the call returns u0 on the host, as ErgodicControl::control does)."""
@@ -609,6 +637,10 @@ def main():
 
     xcalls = {}
 
+    def collective_in_exchange():
+        """the consensus leg's exchange contains a collective kernel (an RCCL communicator, also a one-rank one)"""
+        return (not host_staged) and comm is not None and xcomm is comm
+
     def exchange_records(slot, seq):
         """the exchange of a pass in ONE C-ABI call, device-bound (eea_comm_records_exchange_bound): the record sum polls the
         agents' ready marks, the all-reduce over the ranks follows on the communicator's stream, the flag = seq behind it
@@ -726,6 +758,15 @@ def main():
                 slot = seq % NB
                 src = (seq - lag) % NB if i >= lag else None
                 for g, a in enumerate(gargs):
+                    # a COLLECTIVE KERNEL in the exchange (a real communicator): the last agent group consumes stream-ordered
+                    # -- the rule of eea_comm_records_exchange_bound: when every execution slot is held by control wavefronts
+                    # that wait for the flag, the collective kernel that produces it never becomes resident (round 5,
+                    # profiles/r05_two_ranks.txt) -- its slots drain at the end of its pass and the collective lands there
+                    if collective_in_exchange() and src is not None and G > 1 and g == G - 1:
+                        wcall = exch_calls.get(("wait", src))
+                        if wcall is None:
+                            wcall = exch_calls[("wait", src)] = xcomm.prepared_wait(src, a["stream"])
+                        wcall()
                     call = exch_calls.get((g, slot, src))
                     if call is None:
                         call = exch_calls[(g, slot, src)] = eng.prepared_batch(
@@ -1059,7 +1100,10 @@ def main():
             exchange = {"backend": exchange_backend,
                         "consumer": "eea_batch_io::d_ck_shared as a sum record, ck_shared_parts = 1 (the gradient uses c_bar)"}
             by_lag = {}
-            for lag in LAGS:
+            # with a collective kernel in the exchange the consensus lags one pass more: at lag 1 and exactly full execution
+            # slots the hybrid still stalls now and then (profiles/r05_two_ranks.txt); lag >= 2 never did
+            lags = [l for l in LAGS if l >= 2] or [2] if collective_in_exchange() else LAGS
+            for lag in lags:
                 cstate["lag"] = lag
                 e_s, p_ms, q_s = timed("consensus", args.steps, args.warmup, passes=RX)
                 torch.cuda.synchronize()
@@ -1069,9 +1113,11 @@ def main():
                     "value": world * B * RX * args.steps / e_s, "unit": "optimisations/s",
                     "host_enqueue_us_per_pass": 1e6 * q_s / (args.steps * RX),
                     "agents_timed_out": int((d_xstatus != 0).sum().item())}
-            first = by_lag[str(LAGS[0])]
+            first = by_lag[str(lags[0])]
             exchange["consensus_allreduce"] = {
-                "lag_passes": LAGS[0], "pass_ms": first["pass_ms"], "pass_ms_vs_headline": first["pass_ms_vs_headline"],
+                "lag_passes": lags[0], "consuming_groups": ("last group stream-ordered (eea_comm_wait), the others device-bound"
+                                                            if collective_in_exchange() and G > 1 else "all device-bound"),
+                "pass_ms": first["pass_ms"], "pass_ms_vs_headline": first["pass_ms_vs_headline"],
                 "pass_ms_vs_single_launch_pass": first["pass_ms_vs_single_launch_pass"],
                 "value": first["value"], "unit": "optimisations/s", "by_lag": by_lag,
                 "agent_groups": G, "bytes_per_rank_per_pass": rs * L, "host_threads": 0,
@@ -1084,6 +1130,8 @@ def main():
                         "and group (the headline runs %d steps per launch: pass_ms_vs_single_launch_pass is the like-for-"
                         "like ratio).  Every wait of this protocol is for work that was enqueued BEFORE the waiter, whatever the "
                         "stream -> hardware-queue mapping: that is why it is one step per launch" % SPL}
+            if world == 1 and rank == 0 and not f32:
+                exchange["cpp_host_loop"] = cpp_host_loop_leg(B)
             if use_dist or args.force_exchange:
                 d_all = [torch.empty((world * B, K2), dtype=tdt, device="cuda") for _ in range(2)]
                 e_s, p_ms, _ = timed("allgather", args.steps, args.warmup, passes=RX)

@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <atomic>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -35,17 +36,27 @@ struct RcclApi
   bool ok = false;
 };
 
+// eea_comm_set_library: the collective library to bind instead of the process's / the default one
+std::string g_library_path;
+std::atomic<bool> g_bound{ false };
+
 RcclApi& rccl()
 {
   static RcclApi api = [] {
     RcclApi a;
-    // an RCCL already mapped into the process (e.g. PyTorch's bundled one) is reused
-    const char* names[] = { "librccl.so", "librccl.so.1" };
-    for (const char* n : names) {
-      a.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
-      if (a.handle) break;
+    g_bound.store(true);
+    if (!g_library_path.empty()) {
+      // by path, with its own symbol scope: an RCCL of the same soname may already be mapped (PyTorch's)
+      a.handle = dlopen(g_library_path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    } else {
+      // an RCCL already mapped into the process (e.g. PyTorch's bundled one) is reused
+      const char* names[] = { "librccl.so", "librccl.so.1" };
+      for (const char* n : names) {
+        a.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        if (a.handle) break;
+      }
+      for (int i = 0; a.handle == nullptr && i < 2; ++i) a.handle = dlopen(names[1 - i], RTLD_NOW | RTLD_GLOBAL);
     }
-    for (int i = 0; a.handle == nullptr && i < 2; ++i) a.handle = dlopen(names[1 - i], RTLD_NOW | RTLD_GLOBAL);
     if (a.handle == nullptr) return a;
     a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(a.handle, "ncclGetUniqueId"));
     a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(a.handle, "ncclCommInitRank"));
@@ -154,6 +165,14 @@ eea_status sums_reserve(eea_comm* c, size_t bytes)
 }  // namespace
 
 extern "C" {
+
+eea_status eea_comm_set_library(const char* path)
+{
+  if (path == nullptr || path[0] == '\0') return fail(EEA_ERR_INVALID_ARGUMENT, "null / empty library path");
+  if (g_bound.load()) return fail(EEA_ERR_UNSUPPORTED, "the collective library of this process is already bound");
+  g_library_path = path;
+  return EEA_OK;
+}
 
 eea_status eea_comm_get_unique_id(void* id)
 {
@@ -386,6 +405,14 @@ eea_status eea_comm_records_exchange_async(eea_engine* e, eea_comm* c, unsigned 
 // batch that consumes a flag small enough that the producers it waits for can be resident beside it (two agent groups
 // per GPU are: each holds half of the execution slots) -- a consumer that cannot be served gives up after about a
 // second with EEA_ERR_TIMEOUT in d_status and its own c_k.
+// WITH A COLLECTIVE IN THE EXCHANGE (a communicator of more than one rank) "room for the producers" includes the collective
+// kernel: a block of 256-512 threads with ~100 registers and LDS of its own does not fit beside a full set of control
+// wavefronts (4 x 120 of a SIMD's 512 registers), and when every execution slot is held by control wavefronts that wait for
+// the flag it produces, nothing ever frees one (round 5: measured with two ranks on one GPU and a stream-asynchronous test
+// double of a realistic footprint, tests/fake_rccl -- every agent timed out).  The rule: AT MOST ONE of a rank's agent
+// groups consumes the flag device-bound; the other orders its consuming launch behind the exchange with
+// eea_comm_wait(c, slot, its stream) -- its half of the execution slots drains at the end of its pass and is where the
+// collective kernel lands.  The event eea_comm_wait waits for is recorded here, behind the published record.
 eea_status eea_comm_records_exchange_bound(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_rec,
                                            const unsigned* d_rec_ready, unsigned seq, void* d_sum, unsigned* d_flag, int slot)
 {
@@ -396,7 +423,10 @@ eea_status eea_comm_records_exchange_bound(eea_engine* e, eea_comm* c, unsigned 
   eea_status st = async_begin(c, nullptr, slot, false);
   if (st != EEA_OK) return st;
   if (c->comm == nullptr) {  // one rank, no collective: the sum's last wavefront publishes the flag itself
-    return eea_ck_records_sum_bound(e, B_local, d_ck_rec, d_rec_ready, seq, d_sum, d_flag, c->xstream);
+    st = eea_ck_records_sum_bound(e, B_local, d_ck_rec, d_rec_ready, seq, d_sum, d_flag, c->xstream);
+    if (st != EEA_OK) return st;
+    EEA_HIP(hipEventRecord(c->ev_done[slot], c->xstream));  // (for the groups that consume stream-ordered: eea_comm_wait)
+    return EEA_OK;
   }
   const size_t bytes = eea_real_size(e) * eea_ck_record_len(e);
   if (c->xrec_cap[slot] < bytes) {
@@ -411,7 +441,10 @@ eea_status eea_comm_records_exchange_bound(eea_engine* e, eea_comm* c, unsigned 
   if (st != EEA_OK) return st;
   st = eea_comm_allreduce_sum(e, c, c->d_xrec[slot], eea_ck_record_len(e), c->xstream);
   if (st != EEA_OK) return st;
-  return eea_publish_record(e, c->d_xrec[slot], d_sum, d_flag, seq, c->xstream);
+  st = eea_publish_record(e, c->d_xrec[slot], d_sum, d_flag, seq, c->xstream);
+  if (st != EEA_OK) return st;
+  EEA_HIP(hipEventRecord(c->ev_done[slot], c->xstream));  // (for the groups that consume stream-ordered: eea_comm_wait)
+  return EEA_OK;
 }
 
 eea_status eea_comm_wait(eea_comm* c, int slot, void* stream)

@@ -291,6 +291,11 @@ eea_status eea_rollout_batch(eea_engine* e, unsigned B, const void* d_pose, cons
  * id == NULL with nranks == 1 gives a local communicator without RCCL. */
 #define EEA_COMM_ID_BYTES 128
 typedef struct eea_comm eea_comm;
+/* Binds the collectives to the RCCL at `path` (dlopen, own symbol scope) instead of the one already mapped into the process
+ * or the default librccl.so -- for deployments that carry several RCCL builds; the one-GPU tests and bench.py point it at the
+ * test double tests/fake_rccl/librccl.so.1 to run several ranks as threads on one device.  Process-wide, before the first
+ * other eea_comm_* call (EEA_ERR_UNSUPPORTED once the library is bound). */
+eea_status eea_comm_set_library(const char* path);
 eea_status eea_comm_get_unique_id(void* id);
 eea_status eea_comm_create(int device, int nranks, int rank, const void* id, eea_comm** out);
 void eea_comm_destroy(eea_comm* c);
@@ -341,7 +346,12 @@ eea_status eea_comm_records_exchange_async(eea_engine* e, eea_comm* c, unsigned 
  * record sum's single-wavefront workgroups, the all-reduce) have to become resident BESIDE the waiting wavefronts -- two
  * agent groups per GPU of at most half its execution slots each do (the fp64 K <= 10 instance leaves registers for the
  * sum beside a full set of control wavefronts); a waiter that cannot be served gives up after about a second
- * (EEA_ERR_TIMEOUT in d_status, own c_k), it never hangs.  Host threads: none; the calling thread issues 1-3 launches. */
+ * (EEA_ERR_TIMEOUT in d_status, own c_k), it never hangs.  Host threads: none; the calling thread issues 1-3 launches.
+ * With a communicator of MORE THAN ONE RANK the producers include the collective kernel (hundreds of threads, ~100
+ * registers, LDS of its own): it does not fit beside a full set of control wavefronts, so AT MOST ONE agent group of a rank
+ * may consume the flag device-bound; the other group orders its consuming launch behind the exchange with
+ * eea_comm_wait(c, slot, its stream) (the event is recorded behind the published record) -- its execution slots drain at the
+ * end of its pass, and that is where the collective kernel lands.  All groups device-bound is safe with one rank only. */
 eea_status eea_comm_records_exchange_bound(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_rec,
                                            const unsigned* d_rec_ready, unsigned seq, void* d_sum, unsigned* d_flag, int slot);
 /* in-place ncclAllReduce(sum) of n reals: the K^2 partial sums of a grid-tiled phi_k

@@ -55,9 +55,9 @@ def test_device_backed_classes_and_anchors():
 def test_two_ranks_on_one_gpu_through_the_rccl_test_double():
     """host/test/rank_tests.cpp: eea_comm_create(nranks = 2), the all-gather's rank order, AgentBatch's stream-ordered
     consensus (equal + ragged shards), the device-bound exchange with a collective in it, and the grid-tiled occupancy
-    target -- two ranks as two threads of one process WITHOUT PyTorch, the collectives served by tests/fake_rccl
-    (RCCL itself refuses two ranks of one communicator on one device).  The harness checks that the process really
-    bound the test double."""
+    target -- two ranks as two PROCESSES without PyTorch (the binary re-executes itself once per rank), the collectives
+    served by the stream-asynchronous, kernel-shaped test double tests/fake_rccl (RCCL itself refuses two ranks of one
+    communicator on one device).  The harness checks that the processes really bound the test double."""
     _build()
     fake = os.path.join(ROOT, "tests", "fake_rccl")
     subprocess.run(["make", "-s", "-C", fake], check=True)
@@ -69,6 +69,45 @@ def test_two_ranks_on_one_gpu_through_the_rccl_test_double():
     # the binary has no link dependency on any RCCL; with the fake in front, that is what dlopen("librccl.so.1") finds
     ldd = subprocess.run(["ldd", os.path.join(BUILD, "rank_tests")], capture_output=True, text=True, env=env).stdout
     assert "rccl" not in ldd
+
+
+@pytest.mark.gpu
+def test_device_bound_exchange_beside_a_collective_kernel():
+    """the device-bound consensus exchange with a COLLECTIVE KERNEL in it, free-running from a C++ host
+    loop (host/test/consensus_bench.cpp), in the production shape -- ONE process per GPU, 4096 agents as two agent groups,
+    every execution slot of the GPU held by control wavefronts.  The all-reduce is a kernel of the stream-asynchronous test
+    double (512 threads x 96 registers x 16 KB of LDS per block; RCCL's one-rank all-reduce may launch nothing at all): it
+    has to become resident beside the control kernels.  Protocol under test (include/ergodic_amd.h,
+    eea_comm_records_exchange_bound): lag 2, the last group consumes stream-ordered (eea_comm_wait), the other device-bound.
+    No agent and no collective kernel may give up (EEA_ERR_TIMEOUT / fake_rccl_errors); the pass costs <= 1.6 x the plain
+    pass of the same loop (measured 1.36 - 1.43; the host's 24 us per pass inside the calls is the limit).  All groups
+    device-bound at lag 1 -- round 4's form -- dead-locks here: profiles/r05_two_ranks.txt.
+    Semantics: decentralised ergodic control shares c_k (reference README.md:225-227)."""
+    import json
+    _build()
+    fake = os.path.join(ROOT, "tests", "fake_rccl")
+    subprocess.run(["make", "-s", "-C", fake], check=True)
+    for lag in ("2", "3"):
+        out = subprocess.run([os.path.join(BUILD, "consensus_bench"), "1500", "4096", "1", os.path.join(fake, "librccl.so.1"), lag, "2"],
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
+        assert res["collective_kernel_in_exchange"] is True and res["consuming_groups"].startswith("one device-bound")
+        assert res["agents_timed_out"] == 0 and res["collective_kernel_timeouts"] == 0, res
+        assert res["ratio"] <= 1.6, res
+
+
+@pytest.mark.gpu
+def test_rccl_test_double_by_itself():
+    """tests/fake_rccl/selftest: 50 back-to-back in-place all-reduces, a multi-block all-gather and a large all-reduce, values
+    checked, with the ranks as threads of one process and as processes (hipIpc)"""
+    fake = os.path.join(ROOT, "tests", "fake_rccl")
+    subprocess.run(["make", "-s", "-C", fake, "librccl.so.1", "selftest"], check=True)
+    lib = os.path.join(fake, "librccl.so.1")
+    for extra in (["2", "0"], ["2", "0", "procs"], ["2", "3", "procs"], ["4", "1", "procs"]):
+        out = subprocess.run([os.path.join(fake, "selftest"), lib] + extra, capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, (extra, out.stdout + out.stderr)
+        assert "0 wrong values" in out.stdout and "gave up: 0" in out.stdout
 
 
 # parameter values of ergodic_exploration_amd/host/config/explore_{omni,cart}.yaml
