@@ -41,7 +41,14 @@ class BatchIO(C.Structure):
                 ("d_traj", C.c_void_p), ("d_ck", C.c_void_p), ("d_edx", C.c_void_p),
                 ("d_bdx", C.c_void_p), ("d_rhot", C.c_void_p), ("d_status", C.c_void_p),
                 ("d_ck_shared", C.c_void_p), ("d_ck_rec", C.c_void_p), ("ck_shared_parts", C.c_uint),
-                ("d_rec_ready", C.c_void_p), ("rec_seq", C.c_uint), ("d_ck_flag", C.c_void_p), ("ck_flag_seq", C.c_uint)]
+                ("d_rec_ready", C.c_void_p), ("rec_seq", C.c_uint), ("d_ck_flag", C.c_void_p), ("ck_flag_seq", C.c_uint),
+                ("d_skip", C.c_void_p)]
+
+
+class TickIO(C.Structure):
+    _fields_ = [("d_follow_dwa", C.c_void_p), ("d_dwa_count", C.c_void_p), ("d_u", C.c_void_p), ("d_vb", C.c_void_p),
+                ("d_grid", C.c_void_p), ("d_traj", C.c_void_p), ("d_valid", C.c_void_p), ("d_skip", C.c_void_p),
+                ("d_source", C.c_void_p), ("val_dt", C.c_double), ("val_horizon", C.c_double)]
 
 
 class CollisionCfg(C.Structure):
@@ -391,6 +398,19 @@ class Engine:
         io = BatchIO()
         io.d_pose, io.d_ut, io.d_u0, io.d_ck = _ptr(pose), _ptr(ut), _ptr(u0), _ptr(ck)
         check(lib().eea_debug_phase_timing(self.h, B, C.byref(io), C.c_void_p(stream or 0), _ptr(stamps)))
+
+    def tick_batch(self, B, pose, ut, follow, count, u, vb, grid, traj, valid, skip, coll, dwa, val_dt, val_horizon,
+                   source=None, mem_cols=None, n_mem=None, mem_stride=0, status=None, stream=None):
+        """eea_tick_batch: one iteration of Exploration::control's loop body (exploration.hpp:220-279) for B robots.
+        coll / dwa: collision_cfg(...) / dwa_cfg(...)"""
+        io = BatchIO()
+        io.d_pose, io.d_ut = _ptr(pose), _ptr(ut)
+        io.d_mem_cols, io.d_n_mem, io.mem_stride, io.d_status = _ptr(mem_cols), _ptr(n_mem), mem_stride, _ptr(status)
+        t = TickIO()
+        t.d_follow_dwa, t.d_dwa_count, t.d_u, t.d_vb, t.d_grid = _ptr(follow), _ptr(count), _ptr(u), _ptr(vb), _ptr(grid)
+        t.d_traj, t.d_valid, t.d_skip, t.d_source = _ptr(traj), _ptr(valid), _ptr(skip), _ptr(source)
+        t.val_dt, t.val_horizon = val_dt, val_horizon
+        check(lib().eea_tick_batch(self.h, B, C.byref(io), C.byref(t), C.byref(coll), C.byref(dwa), C.c_void_p(stream or 0)))
 
     def rollout_batch(self, B, pose, ut, traj, status=None, stream=None):
         check(lib().eea_rollout_batch(self.h, B, _ptr(pose), _ptr(ut), _ptr(traj), _ptr(status),

@@ -224,7 +224,18 @@ __global__ __launch_bounds__(kBlock) void validate_control_kernel(const Collisio
 // DynamicWindow::control (dynamic_window.cpp:92-286): one workgroup per robot, one lane per
 // velocity sample; lane 0 then takes the first strict minimum in the reference's loop order.
 constexpr int kDwaBlock = 128;
-template <bool MAP>
+// eea_tick_batch (FLEET): the robots of a fleet tick.  A robot whose twist validate_control accepted does nothing here
+// (its source is recorded); the others run the dynamic window in THEIR mode -- a follower towards its own twist
+// (exploration.hpp:243-251), the rest along their optTraj (:254-277) -- and lane 0 updates u, follow_dwa and i.
+struct FleetTick
+{
+  const int* valid;
+  int* follow;
+  unsigned* count;
+  double* u;
+  int* source;
+};
+template <bool MAP, bool FLEET>
 __global__ __launch_bounds__(kDwaBlock) void dwa_control_kernel(const CollisionParams c, const DwaParams d,
                                                                const HitMap m,
                                                                const int8_t* __restrict__ grid,
@@ -234,11 +245,24 @@ __global__ __launch_bounds__(kDwaBlock) void dwa_control_kernel(const CollisionP
                                                                const double* __restrict__ xt_refs,
                                                                unsigned n_ref, double dt_ref,
                                                                double* __restrict__ u_opt,
-                                                               int* __restrict__ found)
+                                                               int* __restrict__ found, const FleetTick ft)
 {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* const s_cost = reinterpret_cast<double*>(smem_raw);
   const unsigned r = blockIdx.x;
+  bool following = false;
+  if (FLEET) {
+    following = ft.follow[r] != 0;  // (after step 1 of the tick)
+    if (ft.valid[r] != 0) {         // workgroup-uniform
+      if (threadIdx.x == 0 && ft.source != nullptr) ft.source[r] = following ? 1 : 0;
+      return;
+    }
+    if (following) {
+      xt_refs = nullptr;
+      vrefs = ft.u;
+    }
+    u_opt = ft.u;
+  }
   const double* const x0 = x0s + 3 * static_cast<size_t>(r);
   const double* const vb = vbs + 3 * static_cast<size_t>(r);
   const unsigned nsamp = d.ns[0] * d.ns[1] * d.ns[2];
@@ -301,6 +325,7 @@ __global__ __launch_bounds__(kDwaBlock) void dwa_control_kernel(const CollisionP
     if (hit) {
       cost = kMax;
     } else if (xr == nullptr) {
+      // (FLEET: vrefs is the robot's own u, read here by every lane before lane 0 overwrites it behind the barrier)
       const double* const vref = vrefs + 3 * static_cast<size_t>(r);
       const double e0 = vref[0] - u0, e1 = vref[1] - u1, e2 = vref[2] - u2;
       cost = (e0 * e0 + e2 * e2) + e1 * e1;
@@ -331,8 +356,35 @@ __global__ __launch_bounds__(kDwaBlock) void dwa_control_kernel(const CollisionP
     u_opt[3 * static_cast<size_t>(r) + 0] = o0;
     u_opt[3 * static_cast<size_t>(r) + 1] = o1;
     u_opt[3 * static_cast<size_t>(r) + 2] = o2;
-    found[r] = ok ? 1 : 0;
+    if (FLEET) {
+      if (following) {  // the followed twist led into a collision: whatever the window found, control() replans next tick
+        ft.follow[r] = 0;
+        if (ft.source != nullptr) ft.source[r] = 3;
+      } else {          // follow the solution if there is one
+        ft.follow[r] = ok ? 1 : 0;
+        if (ok) ft.count[r] = 0u;
+        if (ft.source != nullptr) ft.source[r] = 2;
+      }
+    } else {
+      found[r] = ok ? 1 : 0;
+    }
   }
+}
+
+// step 1 of the fleet tick (exploration.hpp:223-228): a follower counts a step and replans after dwa_steps of them
+__global__ __launch_bounds__(256) void tick_begin_kernel(int* __restrict__ follow, unsigned* __restrict__ count,
+                                                         int* __restrict__ skip, unsigned dwa_steps, unsigned P)
+{
+  const unsigned r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= P) return;
+  int f = follow[r];
+  if (f != 0) {
+    const unsigned i = count[r] + 1u;
+    count[r] = i;
+    f = (i != dwa_steps) ? 1 : 0;
+    follow[r] = f;
+  }
+  skip[r] = f;
 }
 }  // namespace
 
@@ -560,15 +612,52 @@ hipError_t launch_dwa_control(const CollisionParams& c, const DwaParams& d, cons
     MapScratch sc;
     hipError_t e = build_hit_map(c, d_grid, sc, s);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(dwa_control_kernel<true>, dim3(P), dim3(block), lds, s, c, d, sc.map, d_grid, d_x0, d_vb,
-                         d_vref, d_xt_ref, n_ref, dt_ref, d_u_opt, d_found);
+      hipLaunchKernelGGL((dwa_control_kernel<true, false>), dim3(P), dim3(block), lds, s, c, d, sc.map, d_grid, d_x0, d_vb,
+                         d_vref, d_xt_ref, n_ref, dt_ref, d_u_opt, d_found, FleetTick{});
       e = hipGetLastError();
     }
     release_hit_map(sc, s);
     return e;
   }
-  hipLaunchKernelGGL(dwa_control_kernel<false>, dim3(P), dim3(block), lds, s, c, d, HitMap{ nullptr, 0, 0, 0, 0 }, d_grid,
-                     d_x0, d_vb, d_vref, d_xt_ref, n_ref, dt_ref, d_u_opt, d_found);
+  hipLaunchKernelGGL((dwa_control_kernel<false, false>), dim3(P), dim3(block), lds, s, c, d, HitMap{ nullptr, 0, 0, 0, 0 },
+                     d_grid, d_x0, d_vb, d_vref, d_xt_ref, n_ref, dt_ref, d_u_opt, d_found, FleetTick{});
+  return hipGetLastError();
+}
+
+hipError_t launch_tick_begin(int* d_follow, unsigned* d_count, int* d_skip, unsigned dwa_steps, unsigned P, hipStream_t s)
+{
+  if (P == 0) return hipSuccess;
+  hipLaunchKernelGGL(tick_begin_kernel, dim3((P + 255) / 256), dim3(256), 0, s, d_follow, d_count, d_skip, dwa_steps, P);
+  return hipGetLastError();
+}
+
+// the dynamic window of a fleet tick: one workgroup per robot as above; robots with a valid twist leave at once.  The cost
+// model takes every robot as one that searches (the worst case: the inflated map pays for itself at a fraction of that)
+hipError_t launch_dwa_fleet(const CollisionParams& c, const DwaParams& d, const int8_t* d_grid, const double* d_x0,
+                            const double* d_vb, const double* d_traj, unsigned n_ref, double dt_ref, const int* d_valid,
+                            int* d_follow, unsigned* d_count, double* d_u, int* d_source, unsigned P, hipStream_t s)
+{
+  if (P == 0) return hipSuccess;
+  const size_t nsamp = static_cast<size_t>(d.ns[0]) * d.ns[1] * d.ns[2];
+  const size_t lds = sizeof(double) * nsamp;
+  if (lds > 64 * 1024) return hipErrorInvalidValue;
+  const unsigned block = nsamp <= 64 ? 64 : kDwaBlock;
+  const FleetTick ft{ d_valid, d_follow, d_count, d_u, d_source };
+  if (use_hit_map(static_cast<size_t>(P) * nsamp * d.steps, d.steps, c)) {
+    MapScratch sc;
+    hipError_t e = build_hit_map(c, d_grid, sc, s);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL((dwa_control_kernel<true, true>), dim3(P), dim3(block), lds, s, c, d, sc.map, d_grid, d_x0, d_vb,
+                         static_cast<const double*>(nullptr), d_traj, n_ref, dt_ref, static_cast<double*>(nullptr),
+                         static_cast<int*>(nullptr), ft);
+      e = hipGetLastError();
+    }
+    release_hit_map(sc, s);
+    return e;
+  }
+  hipLaunchKernelGGL((dwa_control_kernel<false, true>), dim3(P), dim3(block), lds, s, c, d, HitMap{ nullptr, 0, 0, 0, 0 },
+                     d_grid, d_x0, d_vb, static_cast<const double*>(nullptr), d_traj, n_ref, dt_ref,
+                     static_cast<double*>(nullptr), static_cast<int*>(nullptr), ft);
   return hipGetLastError();
 }
 

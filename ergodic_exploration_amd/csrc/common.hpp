@@ -64,6 +64,7 @@ struct ControlParams
   R* bdx;
   R* rhot;
   int* status;
+  const int* skip;    // [B] optional (eea_batch_io::d_skip): agents with a non-zero entry are left out of the launch
   long long* dbg;     // phase stamps of the A/B library's kernels (tools/ab/); null in the product
   // single-agent path: host-visible completion word, set to done_seq (system-scope release) after
   // u0 / status of agent 0 are written; null for batches
@@ -230,6 +231,12 @@ hipError_t launch_dwa_control(const CollisionParams& c, const DwaParams& d, cons
                               const double* d_x0, const double* d_vb, const double* d_vref,
                               const double* d_xt_ref, unsigned n_ref, double dt_ref, unsigned P,
                               double* d_u_opt, int* d_found, hipStream_t s);
+// eea_tick_batch: step 1 (follow counters, skip mask) and step 4 (the dynamic window where validate_control failed, per
+// robot towards its own twist or along its optTraj, and the state update) of the fleet tick
+hipError_t launch_tick_begin(int* d_follow, unsigned* d_count, int* d_skip, unsigned dwa_steps, unsigned P, hipStream_t s);
+hipError_t launch_dwa_fleet(const CollisionParams& c, const DwaParams& d, const int8_t* d_grid, const double* d_x0,
+                            const double* d_vb, const double* d_traj, unsigned n_ref, double dt_ref, const int* d_valid,
+                            int* d_follow, unsigned* d_count, double* d_u, int* d_source, unsigned P, hipStream_t s);
 // frees the cached ring offsets and inflated-map buffers of every device
 void release_collision_caches();
 

@@ -230,6 +230,7 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
   R* const sm = reinterpret_cast<R*>(smem_raw);
 
   const int b = blockIdx.x;
+  if (p.skip != nullptr && p.skip[b] != 0) return;  // eea_batch_io::d_skip: the agent is left out (workgroup-uniform)
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(tid / kWave);

@@ -161,7 +161,8 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_k
   if (wave_base >= B) return;                              // wavefront-uniform
   const int tl = lane & (L - 1), al = lane / L;
   const unsigned b = wave_base + al;
-  const bool agent_in = b < B;
+  // (eea_batch_io::d_skip: an agent that is left out of the call is treated like one beyond the batch)
+  const bool agent_in = b < B && !(p.skip != nullptr && p.skip[b < B ? b : 0] != 0);
   // the agent of lane ^ 32 (the partner whose other axis this lane stages)
   const bool partner_in = (wave_base + (al ^ (A / 2))) < B;
 

@@ -297,6 +297,9 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   asm volatile("" : "+s"(S), "+s"(rollout_only));
   const unsigned b = blockIdx.x * WPB + wv;
   if (b >= B) return;  // wavefront-uniform
+  // eea_batch_io::d_skip (the fleet tick: a robot that follows a dynamic-window twist does not call control(),
+  // exploration.hpp:230-236): nothing of the agent is read or written
+  if (p.skip != nullptr && p.skip[b] != 0) return;
   EEA_WSTAMP_RT(10);
   EEA_WSTAMP_HWID(12);
 

@@ -607,6 +607,7 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
   p.bdx = static_cast<R*>(io->d_bdx);
   p.rhot = static_cast<R*>(io->d_rhot);
   p.status = io->d_status;
+  p.skip = io->d_skip;
   p.done = e->mail_done;
   p.done_seq = e->mail_seq;
   const int n_mem_max = rollout_only ? 0 : static_cast<int>(p.mem_stride);
@@ -685,6 +686,30 @@ eea_status occupancy_rows_impl(eea_engine* e, unsigned nx, unsigned ny_total, un
                                              static_cast<const R*>(e->d_cy.p) + static_cast<size_t>(row0) * e->K,
                                              static_cast<const R*>(e->d_lut.p), static_cast<R*>(e->d_work.p),
                                              static_cast<R*>(d_raw_out), s));
+  return EEA_OK;
+}
+
+// DynamicWindow::DynamicWindow (dynamic_window.cpp:71-90) from the C configuration
+eea_status make_dwa_params(const eea_dwa_cfg* dcfg, eea::DwaParams& d)
+{
+  if (dcfg == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null DWA configuration");
+  d.dt = dcfg->dt;
+  d.acc_dt = dcfg->acc_dt;
+  d.acc_lim[0] = dcfg->acc_lim_x;
+  d.acc_lim[1] = dcfg->acc_lim_y;
+  d.acc_lim[2] = dcfg->acc_lim_th;
+  d.vmax[0] = dcfg->max_vel_x;
+  d.vmax[1] = dcfg->max_vel_y;
+  d.vmax[2] = dcfg->max_rot_vel;
+  d.vmin[0] = dcfg->min_vel_x;
+  d.vmin[1] = dcfg->min_vel_y;
+  d.vmin[2] = dcfg->min_rot_vel;
+  // a sample count of 0 is raised to 1 (DynamicWindow::DynamicWindow, dynamic_window.cpp:71-90)
+  d.ns[0] = dcfg->vx_samples ? dcfg->vx_samples : 1;
+  d.ns[1] = dcfg->vy_samples ? dcfg->vy_samples : 1;
+  d.ns[2] = dcfg->vth_samples ? dcfg->vth_samples : 1;
+  d.steps = static_cast<unsigned>(std::abs(dcfg->horizon / dcfg->dt));
+  if (static_cast<size_t>(d.ns[0]) * d.ns[1] * d.ns[2] > 8192) return fail(EEA_ERR_UNSUPPORTED, "more than 8192 DWA samples");
   return EEA_OK;
 }
 
@@ -1537,6 +1562,59 @@ eea_status eea_validate_control_batch(int device, const eea_collision_cfg* cfg, 
 
 void eea_release_collision_caches(void) { eea::release_collision_caches(); }
 
+// One tick of Exploration<ModelT>::control's loop body for B robots (exploration.hpp:220-279): see ergodic_amd.h
+eea_status eea_tick_batch(eea_engine* e, unsigned B, const eea_batch_io* io, const eea_tick_io* tick,
+                          const eea_collision_cfg* ccfg, const eea_dwa_cfg* dcfg, void* stream)
+{
+  if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (io == nullptr || tick == nullptr || dcfg == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  if (e->f32) return fail(EEA_ERR_UNSUPPORTED, "eea_tick_batch takes fp64 engines (poses and twists are doubles)");
+  if (io->d_pose == nullptr || io->d_ut == nullptr || tick->d_follow_dwa == nullptr || tick->d_dwa_count == nullptr ||
+      tick->d_u == nullptr || tick->d_vb == nullptr || tick->d_grid == nullptr || tick->d_traj == nullptr ||
+      tick->d_valid == nullptr || tick->d_skip == nullptr) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "null tick buffer");
+  }
+  if (io->d_rec_ready != nullptr || io->d_ck_flag != nullptr) {
+    return fail(EEA_ERR_UNSUPPORTED, "eea_tick_batch does not take the device-bound exchange buffers");
+  }
+  if (B == 0) return EEA_OK;
+  eea::CollisionParams c;
+  eea_status st = make_collision_params(ccfg, c);
+  if (st != EEA_OK) return st;
+  eea::DwaParams d;
+  st = make_dwa_params(dcfg, d);
+  if (st != EEA_OK) return st;
+  if (!e->have_phik) return fail(EEA_ERR_NO_TARGET, "no target set");
+  st = use_device(e);
+  if (st != EEA_OK) return st;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  // 1. followers count a step (exploration.hpp:223-228); d_skip = who follows a DWA twist this tick
+  EEA_HIP(eea::launch_tick_begin(tick->d_follow_dwa, tick->d_dwa_count, tick->d_skip, d.steps, B, s));
+  // 2. control() of everybody else (:230-236), the twist straight into d_u; then optTraj() of the updated controls (:257)
+  eea_batch_io cio = *io;
+  cio.d_u0 = tick->d_u;
+  cio.d_skip = tick->d_skip;
+  cio.d_traj = nullptr;
+  st = control_batch_impl<double>(e, B, &cio, false, s);
+  if (st != EEA_OK) return st;
+  eea_batch_io rio{};
+  rio.d_pose = io->d_pose;
+  rio.d_ut = io->d_ut;
+  rio.d_traj = tick->d_traj;
+  rio.d_skip = tick->d_skip;
+  st = control_batch_impl<double>(e, B, &rio, true, s);
+  if (st != EEA_OK) return st;
+  // 3. validate_control (:238, numerics.hpp:312-330)
+  const unsigned val_steps = static_cast<unsigned>(std::abs(tick->val_horizon / tick->val_dt));
+  EEA_HIP(eea::launch_validate_control(c, tick->d_grid, static_cast<const double*>(io->d_pose), tick->d_u, tick->val_dt,
+                                       val_steps, B, tick->d_valid, s));
+  // 4. the dynamic window where the twist was rejected (:240-277), u / follow_dwa / i updated in place
+  EEA_HIP(eea::launch_dwa_fleet(c, d, tick->d_grid, static_cast<const double*>(io->d_pose), tick->d_vb, tick->d_traj,
+                                static_cast<unsigned>(e->T), e->cfg.dt, tick->d_valid, tick->d_follow_dwa, tick->d_dwa_count,
+                                tick->d_u, tick->d_source, B, s));
+  return EEA_OK;
+}
+
 eea_status eea_dwa_control_batch(int device, const eea_collision_cfg* ccfg, const eea_dwa_cfg* dcfg,
                                  const int8_t* d_grid, const double* d_x0, const double* d_vb,
                                  const double* d_vref, const double* d_xt_ref, unsigned n_ref,
@@ -1554,23 +1632,8 @@ eea_status eea_dwa_control_batch(int device, const eea_collision_cfg* ccfg, cons
   }
   if (d_xt_ref != nullptr && n_ref == 0) return fail(EEA_ERR_INVALID_ARGUMENT, "empty reference trajectory");
   eea::DwaParams d;
-  d.dt = dcfg->dt;
-  d.acc_dt = dcfg->acc_dt;
-  d.acc_lim[0] = dcfg->acc_lim_x;
-  d.acc_lim[1] = dcfg->acc_lim_y;
-  d.acc_lim[2] = dcfg->acc_lim_th;
-  d.vmax[0] = dcfg->max_vel_x;
-  d.vmax[1] = dcfg->max_vel_y;
-  d.vmax[2] = dcfg->max_rot_vel;
-  d.vmin[0] = dcfg->min_vel_x;
-  d.vmin[1] = dcfg->min_vel_y;
-  d.vmin[2] = dcfg->min_rot_vel;
-  // a sample count of 0 is raised to 1 (DynamicWindow::DynamicWindow, dynamic_window.cpp:71-90)
-  d.ns[0] = dcfg->vx_samples ? dcfg->vx_samples : 1;
-  d.ns[1] = dcfg->vy_samples ? dcfg->vy_samples : 1;
-  d.ns[2] = dcfg->vth_samples ? dcfg->vth_samples : 1;
-  d.steps = static_cast<unsigned>(std::abs(dcfg->horizon / dcfg->dt));
-  if (static_cast<size_t>(d.ns[0]) * d.ns[1] * d.ns[2] > 8192) return fail(EEA_ERR_UNSUPPORTED, "more than 8192 DWA samples");
+  st = make_dwa_params(dcfg, d);
+  if (st != EEA_OK) return st;
   EEA_HIP(hipSetDevice(device));
   EEA_HIP(eea::launch_dwa_control(c, d, d_grid, d_x0, d_vb, d_vref, d_xt_ref, n_ref, dt_ref, P, d_u_opt,
                                   d_found, static_cast<hipStream_t>(stream)));

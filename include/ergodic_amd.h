@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EEA_ABI_VERSION 4
+#define EEA_ABI_VERSION 5
 
 /* models usable with ErgodicControl (Cart/Mecanum cannot run under it) */
 enum { EEA_MODEL_OMNI = 0,        /* models::Omni        models/omni.hpp:164-215 */
@@ -228,6 +228,10 @@ typedef struct {
                                         c_k.  The waiting wavefronts hold their execution slots: see
                                         eea_comm_records_exchange_bound for what must fit beside them             */
   unsigned ck_flag_seq;
+  const int* d_skip;      /* [B] in, optional (ABI 5): agents with a non-zero entry are LEFT OUT of the call -- nothing of
+                                        theirs is read or written, their warm start does not advance (a robot that
+                                        follows a dynamic-window twist does not call control(), exploration.hpp:230-236;
+                                        eea_tick_batch fills it)                                                 */
 } eea_batch_io;
 
 /* length in reals of one sum record (eea_batch_io::d_ck_rec): K^2 + 1 rounded up to an even number */
@@ -431,7 +435,38 @@ eea_status eea_dwa_control_batch(int device, const eea_collision_cfg* ccfg, cons
                                  const double* d_vref, const double* d_xt_ref, unsigned n_ref,
                                  double dt_ref, unsigned P, double* d_u_opt, int* d_found, void* stream);
 
-/* The three calls above keep small device caches between calls (the ring offsets per radii, one
+/* ---- one tick of the exploration loop for a FLEET (ABI 5) ----------------------------------------------------------
+ * Exploration<ModelT>::control's loop body (exploration.hpp:220-279) for B robots on one shared occupancy grid, on the
+ * device, one stream, no host round trip:
+ *   1. a robot that follows a dynamic-window twist counts a step; after dwa_steps = (unsigned)|horizon / dt| of the DWA
+ *      configuration it replans (:223-228);
+ *   2. every robot that does not follow one: u = ErgodicControl::control(grid, pose) (:230-236) -- eea_control_batch with
+ *      d_skip for the others (their warm start stays as it is, as in the reference);
+ *   3. validate_control(collision, grid, pose, u, val_dt, val_horizon) (:238);
+ *   4. on a predicted collision: a follower re-runs the dynamic window towards its own twist and stops following
+ *      (:243-251); the others track optTraj() -- the rollout of the UPDATED controls -- and follow the result if one was
+ *      found (:254-277).  u = 0 where the dynamic window finds nothing.
+ * State carried between ticks, per robot, device memory owned by the caller, zero before the first tick: d_follow_dwa,
+ * d_dwa_count, d_u.  addStateMemory (:209) stays on the caller's side: io->d_mem_cols / d_n_mem as for eea_control_batch.
+ * io->d_u0, d_traj, d_skip are ignored (the tick supplies its own); everything else of io is passed to the control call.
+ * fp64 engines only (poses and twists are the doubles the collision / DWA kernels take). */
+typedef struct {
+  int* d_follow_dwa;      /* [B]       in/out: follow_dwa (:191)                                                 */
+  unsigned* d_dwa_count;  /* [B]       in/out: i (:194)                                                          */
+  double* d_u;            /* [B][3]    in/out: the commanded twist u (kept while a DWA twist is followed)        */
+  const double* d_vb;     /* [B][3]    in: body twists from odometry (vb_, :161-174)                             */
+  const int8_t* d_grid;   /* [ysize][xsize] in: the occupancy grid (grid_)                                       */
+  double* d_traj;         /* [B][T][3] scratch: optTraj() of the robots that ran control()                       */
+  int* d_valid;           /* [B]       scratch / out: validate_control's result (1 = collision free)            */
+  int* d_skip;            /* [B]       scratch: robots that follow a DWA twist this tick                         */
+  int* d_source;          /* [B]       out, optional: who produced u -- 0 control(), 1 a followed DWA twist,
+                                       2 DWA tracking optTraj(), 3 DWA re-run towards the followed twist        */
+  double val_dt, val_horizon;
+} eea_tick_io;
+eea_status eea_tick_batch(eea_engine* e, unsigned B, const eea_batch_io* io, const eea_tick_io* tick,
+                          const eea_collision_cfg* ccfg, const eea_dwa_cfg* dcfg, void* stream);
+
+/* The calls above keep small device caches between calls (the ring offsets per radii, one
  * inflated-map buffer per (device, stream)).  A long-running process that changes streams or map sizes
  * can drop them; synchronises the devices involved.  No reference counterpart. */
 void eea_release_collision_caches(void);

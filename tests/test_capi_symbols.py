@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 25
     missing = [s for s in syms if not hasattr(L, s)]
     assert missing == []
-    assert capi.lib().eea_abi_version() == 4
+    assert capi.lib().eea_abi_version() == 5
 
 
 def test_library_exports_only_the_documented_abi():
@@ -32,7 +32,7 @@ def test_library_exports_only_the_documented_abi():
 def test_struct_layouts_match_header():
     # sizes the C compiler gives the ABI structs (kept in sync with ergodic_amd.h by hand)
     assert C.sizeof(capi.Config) == 3 * 4 + 4 + 4 * 8 + 8 + 15 * 8  # ints, pad, doubles, K+pad, arrays
-    assert C.sizeof(capi.BatchIO) == 15 * 8 + 4 * 8  # ABI 3 (15 slots) + d_rec_ready, rec_seq, d_ck_flag, ck_flag_seq (ABI 4)
+    assert C.sizeof(capi.BatchIO) == 15 * 8 + 4 * 8 + 8  # ABI 3 (15 slots) + d_rec_ready, rec_seq, d_ck_flag, ck_flag_seq (ABI 4) + d_skip (ABI 5)
     assert C.sizeof(capi.CollisionCfg) == 3 * 8 + 2 * 4 + 4 * 8
 
 
@@ -40,7 +40,7 @@ def test_struct_layouts_against_the_c_compiler(tmp_path):
     """sizeof / offsetof of every ABI struct as gcc lays them out from include/ergodic_amd.h, against the ctypes mirrors"""
     import subprocess
     structs = {"eea_config": capi.Config, "eea_batch_io": capi.BatchIO, "eea_collision_cfg": capi.CollisionCfg,
-               "eea_dwa_cfg": capi.DwaCfg}
+               "eea_dwa_cfg": capi.DwaCfg, "eea_tick_io": capi.TickIO}
     lines = []
     for cname, cls in structs.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))

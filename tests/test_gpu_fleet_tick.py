@@ -1,0 +1,151 @@
+"""eea_tick_batch (ABI 5): one iteration of Exploration<ModelT>::control's loop body (reference
+exploration.hpp:220-279) for a FLEET of robots on one shared occupancy grid, on the device -- control() of the robots that
+do not follow a dynamic-window twist (eea_batch_io::d_skip for the others), validate_control (numerics.hpp:312-330), and the
+dynamic window (dynamic_window.cpp:92-286) per robot in ITS mode (towards the followed twist / along optTraj()), with the
+follow_dwa / i state machine in device memory.
+
+Checker: B independent `OracleExploration` loops (tests/test_host_mirror.py: the reference's loop body restated on the CPU
+oracle), tick by tick over 30 ticks of a closed loop (the robots move by integrate_twist of the commanded twist) on a map
+with obstacles that CHANGES half way (a wall appears in front of the robots that follow a DWA twist: the re-plan branch).
+Every tick: the decision (who produced the twist) and the state machine (follow_dwa, i) are identical, the validate_control
+verdicts are identical, twists <= 1e-9 where control() produced them (the oracle's warm start is re-seeded with the engine's
+every tick: never compare long closed loops) and bitwise where the dynamic window chose them from its sample grid (a
+differing choice must be a cost tie of the oracle's objective, as in test_gpu_dwa_parity.py).
+All three control kernels take the skip mask: wavefront per agent, several agents per wavefront, workgroup per agent."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import pyoracle as po
+from ergodic_exploration_amd import capi
+from tests.test_host_mirror import COLL, DWA, OracleExploration, _grid_with
+
+pytestmark = pytest.mark.gpu
+
+SOURCES = ["ergodic", "dwa-follow", "dwa-reference", "dwa-replan"]
+
+
+def _engine(model):
+    if model == "omni":
+        em, Rinv, lim = capi.MODEL_OMNI, np.diag([1.0, 1.0, 2.0]), np.array([1.0, 1.0, 2.0])
+    else:
+        em, Rinv, lim = capi.MODEL_SIMPLE_CART, np.diag([1.0, 0.0, 2.0]), np.array([1.0, 0.0, 2.0])
+    eng = capi.Engine(capi.make_config(em, 0.1, 5.0, 0.1, 1.0, 10, Rinv, -lim, lim))
+    eng.set_target_gaussians([[2.5, 2.5], [8.5, 2.5]], [[1.5, 1.5], [1.5, 1.5]])
+    return eng
+
+
+@pytest.mark.parametrize("model,kernel", [("omni", "wave"), ("simple_cart", "wave"), ("omni", "packed"), ("simple_cart", "workgroup")])
+def test_fleet_tick_against_independent_oracle_loops(model, kernel):
+    ticks, B, dt = 30, 28, 0.1
+    obstacles = [(2.4, 0.2, 3.0, 2.6), (6.0, 2.0, 6.5, 4.6), (8.8, -0.4, 9.4, 1.2)]
+    wall = (4.2, -0.6, 4.5, 4.4)   # appears at tick 12
+    grid_a, bounds = _grid_with(obstacles)
+    grid_b, _ = _grid_with(obstacles + [wall])
+    xs, ys, res = grid_a.xsize, grid_a.ysize, 0.05
+    ccfg = capi.make_collision_cfg(bounds[0], bounds[2], res, xs, ys, *COLL)
+    dcfg = capi.DwaCfg(*DWA[model])
+    try:
+        if kernel == "packed":
+            capi.set_option(capi.OPT_AGENT_LANES, 16)
+        if kernel == "workgroup":
+            capi.set_option(capi.OPT_CONTROL_KERNEL, 1)
+        eng = _engine(model)
+        eng.config_domain(bounds)
+        assert eng.agent_lanes(B) == {"wave": 64, "packed": 16, "workgroup": 0}[kernel]
+        T = eng.T
+        rng = np.random.default_rng(4)
+        # start poses in free space, most of them heading for an obstacle
+        poses = np.stack([rng.uniform(0.2, 9.5, B), rng.uniform(-0.2, 4.2, B), rng.uniform(-0.6, 0.6, B)], 1)
+        poses[:8, 0], poses[:8, 1], poses[:8, 2] = rng.uniform(1.0, 1.6, 8), rng.uniform(0.6, 2.2, 8), rng.uniform(-0.2, 0.2, 8)
+        poses[8:14, 0], poses[8:14, 1] = rng.uniform(3.3, 3.7, 6), rng.uniform(0.0, 4.0, 6)
+        for b in range(B):   # (no robot starts inside a collision)
+            while not po.validate_control(COLL, grid_b, poses[b], np.zeros(3), 0.1, 0.5):
+                poses[b, :2] = rng.uniform(0.2, 9.5), rng.uniform(-0.2, 4.2)
+        ors = [OracleExploration(model, grid_a, bounds) for _ in range(B)]
+        dev = lambda a, t=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=t).cuda()
+        d_ut = torch.zeros((B, T, 3), dtype=torch.float64, device="cuda")
+        d_follow = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        d_count = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        d_u = torch.zeros((B, 3), dtype=torch.float64, device="cuda")
+        d_traj = torch.empty((B, T, 3), dtype=torch.float64, device="cuda")
+        d_valid = torch.empty((B,), dtype=torch.int32, device="cuda")
+        d_skip = torch.empty((B,), dtype=torch.int32, device="cuda")
+        d_source = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+        d_status = torch.full((B,), -1, dtype=torch.int32, device="cuda")
+        d_grid_a, d_grid_b = dev(grid_a.data, torch.int8), dev(grid_b.data, torch.int8)
+        mem = np.zeros((B, ticks, 3))
+        vb = np.zeros((B, 3))
+        seen = set()
+        for t in range(ticks):
+            grid, d_grid = (grid_a, d_grid_a) if t < 12 else (grid_b, d_grid_b)
+            mem[:, t] = poses          # addStateMemory(pose) every tick (exploration.hpp:209); <= batch size: no sampling
+            ut_before = d_ut.cpu().numpy()
+            eng.tick_batch(B, dev(poses), d_ut, d_follow, d_count, d_u, dev(vb), d_grid, d_traj, d_valid, d_skip, ccfg, dcfg,
+                           0.1, 0.5, source=d_source, mem_cols=dev(mem[:, :t + 1]), n_mem=torch.full((B,), t + 1, dtype=torch.int32,
+                                                                                                   device="cuda"),
+                           mem_stride=t + 1, status=d_status)
+            torch.cuda.synchronize()
+            u, src, follow, count = d_u.cpu().numpy(), d_source.cpu().numpy(), d_follow.cpu().numpy(), d_count.cpu().numpy()
+            valid, ut_after = d_valid.cpu().numpy(), d_ut.cpu().numpy()
+            for b in range(B):
+                o = ors[b]
+                o.grid = grid
+                o.memory = list(mem[b, :t])           # (tick() appends the pose itself)
+                o.ec.ut = ut_before[b].T              # the oracle starts every tick from the engine's warm start
+                uo, so = o.tick(poses[b], vb[b])
+                assert SOURCES[src[b]] == so, (t, b, SOURCES[src[b]], so)
+                assert bool(follow[b]) == o.follow and (not o.follow or int(count[b]) == o.i), (t, b, follow[b], count[b], o.follow, o.i)
+                assert bool(valid[b]) == (so in ("ergodic", "dwa-follow")), (t, b, valid[b], so)   # validate_control's verdict
+                if so in ("ergodic", "dwa-follow"):
+                    assert np.abs(u[b] - uo).max() <= 1e-9, (t, b, so, u[b], uo)
+                elif not np.array_equal(u[b], uo):
+                    # the dynamic window picked another sample: it must be a tie of the oracle's own objective
+                    if so == "dwa-replan":
+                        raise AssertionError((t, b, so, u[b], uo))   # (control-error cost from identical doubles: bitwise)
+                    xt = o.ec.opt_traj()
+                    ca = po.dwa_objective_traj(DWA[model], COLL, grid, poses[b], u[b], xt, 0.1)
+                    cb = po.dwa_objective_traj(DWA[model], COLL, grid, poses[b], uo, xt, 0.1)
+                    assert abs(ca - cb) <= 1e-9 * max(1.0, abs(cb)), (t, b, u[b], uo, ca, cb)
+                if so == "dwa-follow":   # a follower's controller is left alone: its warm start did not advance
+                    assert np.array_equal(ut_after[b], ut_before[b])
+                seen.add(so)
+            assert (d_status.cpu().numpy()[src == 0] == 0).all()
+            # the robots move (numerics.hpp:273-297), odometry reports the commanded twist
+            for b in range(B):
+                poses[b] = po.integrate_twist(poses[b], u[b], dt)
+            vb = u.copy()
+        # every branch of the loop body ran (the re-plan of a followed twist needs the wall to cut a follower off within its
+        # dwa_steps: the omni scenario does, the cart's 3 x 1 x 5 window rarely finds a twist to follow at all)
+        assert seen >= {"ergodic", "dwa-follow", "dwa-reference"} and (model != "omni" or "dwa-replan" in seen), seen
+        eng.close()
+    finally:
+        capi.set_option(capi.OPT_AGENT_LANES, 0)
+        capi.set_option(capi.OPT_CONTROL_KERNEL, 0)
+
+
+def test_tick_argument_errors():
+    eng = _engine("omni")
+    eng.config_domain((-1.0, 11.0, -1.0, 5.0))
+    B, T = 4, eng.T
+    z = lambda *s, dt=torch.float64: torch.zeros(s, dtype=dt, device="cuda")
+    ccfg = capi.make_collision_cfg(-1.0, -1.0, 0.05, 240, 120, *COLL)
+    args = dict(pose=z(B, 3), ut=z(B, T, 3), follow=z(B, dt=torch.int32), count=z(B, dt=torch.int32), u=z(B, 3), vb=z(B, 3),
+                grid=z(120, 240, dt=torch.int8), traj=z(B, T, 3), valid=z(B, dt=torch.int32), skip=z(B, dt=torch.int32))
+    for missing in ("follow", "u", "grid", "traj", "skip"):
+        a = dict(args)
+        a[missing] = None
+        with pytest.raises(capi.EngineError) as ei:
+            eng.tick_batch(B, a["pose"], a["ut"], a["follow"], a["count"], a["u"], a["vb"], a["grid"], a["traj"], a["valid"], a["skip"],
+                           ccfg, capi.DwaCfg(*DWA["omni"]), 0.1, 0.5)
+        assert ei.value.status == capi.ERR_INVALID_ARGUMENT
+    eng.close()
+    e32 = capi.Engine(capi.make_config(capi.MODEL_OMNI, 0.1, 5.0, 0.1, 1.0, 10, np.eye(3), [-1] * 3, [1] * 3, precision=capi.PREC_F32))
+    e32.set_target_gaussians([[2.5, 2.5]], [[1.5, 1.5]])
+    e32.config_domain((-1.0, 11.0, -1.0, 5.0))
+    with pytest.raises(capi.EngineError) as ei:
+        e32.tick_batch(B, args["pose"], args["ut"], args["follow"], args["count"], args["u"], args["vb"], args["grid"], args["traj"],
+                       args["valid"], args["skip"], ccfg, capi.DwaCfg(*DWA["omni"]), 0.1, 0.5)
+    assert ei.value.status == capi.ERR_UNSUPPORTED
+    e32.close()
