@@ -396,6 +396,100 @@ TICK_SHAPES = [
 ]
 
 
+def tick_legs(torch, capi, np):
+    """SURVEY.md 8(f) kernels, device time from HIP events on the launch stream (not ctypes wall time):
+    (a) `tick_kernels`: Collision::collisionCheck, validate_control and DynamicWindow::control (both overloads) for P = 4096
+        and 65 536 poses on the 240 x 120 demo grid, both implementations of the lookup (ring search = up to ~200 dependent
+        byte loads per pose: latency-bound; inflated map = one dilation launch + ONE byte per pose-step: launch-bound at these
+        sizes); algorithmic bytes: one occupancy byte per ring cell visited / per pose-step, 24 B of pose in, 4 B out;
+    (b) `fleet_tick`: eea_tick_batch at B = 4096 robots (explore_omni.yaml shape: K = 10, T = 50) on that grid, robots spread
+        over the map (a part of them in front of obstacles: every branch runs), microseconds per tick over 200 ticks
+        (reference exploration.hpp:220-279: control -> validate_control -> dynamic window per robot, 10 Hz in production)."""
+    COLL = (0.7, 1.0, 0.2, 0.8)
+    DWA = (0.1, 2.0, 0.2, 2.5, 2.5, 1.0, 1.0, -1.0, 1.0, -1.0, 2.0, -2.0, 3, 8, 5)
+    xs, ys, res, x0, y0 = 240, 120, 0.05, -1.0, -1.0
+    data = np.zeros((ys, xs), dtype=np.int8)
+    cx, cy = x0 + (np.arange(xs) + 0.5) * res, y0 + (np.arange(ys) + 0.5) * res
+    for (a, b, c, d) in [(2.4, 0.2, 3.0, 2.6), (6.0, 2.0, 6.5, 4.6), (8.8, -0.4, 9.4, 1.2)]:
+        data[np.ix_((cy >= b) & (cy <= d), (cx >= a) & (cx <= c))] = 100
+    ccfg = capi.make_collision_cfg(x0, y0, res, xs, ys, *COLL)
+    dcfg = capi.DwaCfg(*DWA)
+    d_grid = torch.as_tensor(data).cuda()
+    st = torch.cuda.current_stream()
+    rng = np.random.default_rng(99)
+
+    def timed(fn, n):
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record(st)
+        for _ in range(n):
+            fn()
+        e1.record(st)
+        torch.cuda.synchronize()
+        return 1e3 * e0.elapsed_time(e1) / n   # us per call
+
+    kernels = []
+    try:
+        for impl, iname in ((1, "ring search"), (2, "inflated map")):
+            capi.set_option(capi.OPT_COLLISION_IMPL, impl)
+            for P in (4096, 65536):
+                x = torch.as_tensor(np.stack([rng.uniform(-0.5, 10.5, P), rng.uniform(-0.5, 4.5, P), rng.uniform(-3, 3, P)], 1)).cuda()
+                u = torch.as_tensor(np.stack([rng.uniform(-1, 1, P), rng.uniform(-1, 1, P), rng.uniform(-2, 2, P)], 1)).cuda()
+                hit = torch.empty((P,), dtype=torch.int32, device="cuda")
+                uo = torch.empty((P, 3), dtype=torch.float64, device="cuda")
+                xt = x[:, None, :].repeat(1, 50, 1).contiguous()
+                row = {"implementation": iname, "poses": P,
+                       "collision_check_us": timed(lambda: capi.collision_check_batch(ccfg, d_grid, x, hit), 50),
+                       "validate_control_us": timed(lambda: capi.validate_control_batch(ccfg, d_grid, x, u, 0.1, 0.5, hit), 50),
+                       "dwa_vref_us": timed(lambda: capi.dwa_control_batch(ccfg, dcfg, d_grid, x, u, uo, hit, vref=u), 10 if P > 4096 else 30),
+                       "dwa_traj_us": timed(lambda: capi.dwa_control_batch(ccfg, dcfg, d_grid, x, u, uo, hit, xt_ref=xt, dt_ref=0.1),
+                                            10 if P > 4096 else 30)}
+                row["collision_check_ns_per_pose"] = 1e3 * row["collision_check_us"] / P
+                row["dwa_vref_ns_per_rollout_step"] = 1e3 * row["dwa_vref_us"] / (P * 120 * 20)
+                kernels.append(row)
+    finally:
+        capi.set_option(capi.OPT_COLLISION_IMPL, 0)
+    # fleet tick
+    B = 4096
+    lim = np.array([1.0, 1.0, 2.0])
+    eng = capi.Engine(capi.make_config(capi.MODEL_OMNI, 0.1, 5.0, 0.1, 1.0, 10, np.diag([1.0, 1.0, 2.0]), -lim, lim))
+    eng.set_target_gaussians(MEANS, SIGMAS)
+    eng.config_domain(MAP_BOUNDS)
+    T = eng.T
+    poses = np.stack([rng.uniform(0.0, 10.0, B), rng.uniform(-0.5, 4.5, B), rng.uniform(-3, 3, B)], 1)
+    z = lambda *sh, dt=torch.float64: torch.zeros(sh, dtype=dt, device="cuda")
+    d_pose, d_ut, d_u, d_vb = torch.as_tensor(poses).cuda(), z(B, T, 3), z(B, 3), z(B, 3)
+    d_follow, d_count, d_valid, d_skip, d_src = (z(B, dt=torch.int32) for _ in range(5))
+    d_traj = z(B, T, 3)
+    tick = lambda: eng.tick_batch(B, d_pose, d_ut, d_follow, d_count, d_u, d_vb, d_grid, d_traj, d_valid, d_skip, ccfg, dcfg,
+                                  0.1, 0.5, source=d_src)
+    us = timed(tick, 200)
+    src = d_src.cpu().numpy()
+    d_follow.zero_(), d_count.zero_(), d_u.zero_(), d_ut.zero_()
+    tick_cached = lambda: eng.tick_batch(B, d_pose, d_ut, d_follow, d_count, d_u, d_vb, d_grid, d_traj, d_valid, d_skip, ccfg, dcfg,
+                                         0.1, 0.5, source=d_src, grid_epoch=7)
+    us_cached = timed(tick_cached, 200)
+    ctl = timed(lambda: eng.control_batch(B, d_pose, d_ut, d_u), 200)
+    eng.close()
+    return {"tick_kernels": {"grid": "%dx%d int8 @ %.2f m" % (xs, ys, res), "dwa_window": "3 x 8 x 5 samples x 20 steps",
+                             "note": "device microseconds per call (HIP events on the launch stream); ring search: dependent byte "
+                                     "loads (latency-bound), inflated map: one dilation launch + one byte per pose-step "
+                                     "(launch-bound at these sizes)", "cases": kernels},
+            "fleet_tick": {"robots": B, "kinematics": "omni", "num_basis": 10, "horizon_steps": T, "us_per_tick": us,
+                           "us_per_tick_unchanged_grid": us_cached,
+                           "ticks_per_s": 1e6 / us, "robot_ticks_per_s": B * 1e6 / us,
+                           "control_batch_alone_us": ctl,
+                           "sources_last_tick": {n: int((src == i).sum()) for i, n in enumerate(("control", "dwa_follow", "dwa_reference",
+                                                                                                "dwa_replan"))},
+                           "note": "eea_tick_batch: step counters -> control() of the robots that follow no DWA twist -> optTraj "
+                                   "rollout -> validate_control -> dynamic window per robot in its mode, one stream, no host round "
+                                   "trip; static poses (the robots in front of obstacles stay in the DWA branches); "
+                                   "us_per_tick_unchanged_grid: eea_tick_io::grid_epoch != 0, the inflated collision map of the "
+                                   "tick before is reused (maps update at ~1 Hz, the loop runs at 10 Hz)"}}
+
+
 def cpp_host_loop_leg(agents):
     """The consensus leg's enqueue loop from a C++ host (host/test/consensus_bench.cpp through the C ABI) instead of this
     file's Python: (a) local exchange, lag 1; (b) with a COLLECTIVE KERNEL in the exchange -- one rank whose all-reduce is a
@@ -993,6 +1087,11 @@ def main():
                     "cases": single_robot_ticks(torch, capi, np)}
             except Exception as exc:  # noqa: BLE001 -- the headline line must not die with a secondary leg
                 out["single_robot_tick"] = {"error": repr(exc)}
+        if world == 1 and not args.no_latency and not f32:
+            try:
+                out.update(tick_legs(torch, capi, np))
+            except Exception as exc:  # noqa: BLE001 -- the headline line must not die with a secondary leg
+                out["fleet_tick"] = {"error": repr(exc)}
         if world == 1 and not args.no_phik and not f32:
             try:
                 out.update(phik_legs(args, torch, capi, np))

@@ -48,7 +48,7 @@ class BatchIO(C.Structure):
 class TickIO(C.Structure):
     _fields_ = [("d_follow_dwa", C.c_void_p), ("d_dwa_count", C.c_void_p), ("d_u", C.c_void_p), ("d_vb", C.c_void_p),
                 ("d_grid", C.c_void_p), ("d_traj", C.c_void_p), ("d_valid", C.c_void_p), ("d_skip", C.c_void_p),
-                ("d_source", C.c_void_p), ("val_dt", C.c_double), ("val_horizon", C.c_double)]
+                ("d_source", C.c_void_p), ("val_dt", C.c_double), ("val_horizon", C.c_double), ("grid_epoch", C.c_ulonglong)]
 
 
 class CollisionCfg(C.Structure):
@@ -400,7 +400,7 @@ class Engine:
         check(lib().eea_debug_phase_timing(self.h, B, C.byref(io), C.c_void_p(stream or 0), _ptr(stamps)))
 
     def tick_batch(self, B, pose, ut, follow, count, u, vb, grid, traj, valid, skip, coll, dwa, val_dt, val_horizon,
-                   source=None, mem_cols=None, n_mem=None, mem_stride=0, status=None, stream=None):
+                   source=None, mem_cols=None, n_mem=None, mem_stride=0, status=None, stream=None, grid_epoch=0):
         """eea_tick_batch: one iteration of Exploration::control's loop body (exploration.hpp:220-279) for B robots.
         coll / dwa: collision_cfg(...) / dwa_cfg(...)"""
         io = BatchIO()
@@ -409,7 +409,7 @@ class Engine:
         t = TickIO()
         t.d_follow_dwa, t.d_dwa_count, t.d_u, t.d_vb, t.d_grid = _ptr(follow), _ptr(count), _ptr(u), _ptr(vb), _ptr(grid)
         t.d_traj, t.d_valid, t.d_skip, t.d_source = _ptr(traj), _ptr(valid), _ptr(skip), _ptr(source)
-        t.val_dt, t.val_horizon = val_dt, val_horizon
+        t.val_dt, t.val_horizon, t.grid_epoch = val_dt, val_horizon, grid_epoch
         check(lib().eea_tick_batch(self.h, B, C.byref(io), C.byref(t), C.byref(coll), C.byref(dwa), C.c_void_p(stream or 0)))
 
     def rollout_batch(self, B, pose, ut, traj, status=None, stream=None):

@@ -130,15 +130,28 @@ __global__ __launch_bounds__(kBlock) void inflate_kernel(const CollisionParams c
                                                          uint8_t* __restrict__ cells, int R, int w,
                                                          uint8_t stamp)
 {
+  // Occupied cells are few and the ring has hundreds of offsets: a lane that walked its own cell's ring alone made the
+  // launch as long as that walk (27 us on the 240 x 120 demo map, profiles/r05_tick_kernels.txt).  The block first lists
+  // its occupied cells, then ALL its threads walk the ring of each listed cell together.
+  __shared__ unsigned s_list[kBlock];
+  __shared__ unsigned s_n;
+  if (threadIdx.x == 0) s_n = 0u;
+  __syncthreads();
   const size_t q = static_cast<size_t>(blockIdx.x) * kBlock + threadIdx.x;
   const size_t n = static_cast<size_t>(c.xsize) * c.ysize;
-  if (q >= n) return;
-  const double cell = static_cast<double>(grid[q]) / 100.0;  // GridMap::getCell, grid.cpp:177-184
-  if (cell < c.occupied_threshold) return;                   // checkCell tests !(cell < threshold)
-  const int i = static_cast<int>(q / c.xsize), j = static_cast<int>(q - static_cast<size_t>(i) * c.xsize);
-  for (int o = 0; o < n_off; ++o) {
-    const short2 d = offsets[o];  // cell = centre + d
-    cells[static_cast<size_t>(i - d.y + R) * w + (j - d.x + R)] = stamp;  // same value from every writer
+  if (q < n) {
+    const double cell = static_cast<double>(grid[q]) / 100.0;  // GridMap::getCell, grid.cpp:177-184
+    if (!(cell < c.occupied_threshold)) s_list[atomicAdd(&s_n, 1u)] = threadIdx.x;  // checkCell tests !(cell < threshold)
+  }
+  __syncthreads();
+  const unsigned cnt = s_n;
+  for (unsigned k = 0; k < cnt; ++k) {
+    const size_t qq = static_cast<size_t>(blockIdx.x) * kBlock + s_list[k];
+    const int i = static_cast<int>(qq / c.xsize), j = static_cast<int>(qq - static_cast<size_t>(i) * c.xsize);
+    for (int o = threadIdx.x; o < n_off; o += kBlock) {
+      const short2 d = offsets[o];  // cell = centre + d
+      cells[static_cast<size_t>(i - d.y + R) * w + (j - d.x + R)] = stamp;  // same value from every writer
+    }
   }
 }
 
@@ -475,6 +488,10 @@ struct MapBuffer
   uint8_t* cells;
   size_t cap;
   unsigned stamp;
+  // what the current stamp was built from (eea_tick_io::grid_epoch != 0: a later build of the same map is skipped)
+  const int8_t* built_grid = nullptr;
+  unsigned long long built_epoch = 0;
+  CollisionParams built_params{};
 };
 std::mutex g_maps_mutex;
 std::vector<MapBuffer> g_maps;
@@ -486,7 +503,16 @@ struct MapScratch
   HitMap map{ nullptr, 0, 0, 0, 0 };
 };
 
-hipError_t build_hit_map(const CollisionParams& c, const int8_t* d_grid, MapScratch& sc, hipStream_t s)
+bool same_params(const CollisionParams& a, const CollisionParams& b)
+{
+  return a.xmin == b.xmin && a.ymin == b.ymin && a.resolution == b.resolution && a.xsize == b.xsize && a.ysize == b.ysize &&
+         a.r_bnd == b.r_bnd && a.r_col == b.r_col && a.r_max == b.r_max && a.occupied_threshold == b.occupied_threshold;
+}
+
+// epoch != 0: the caller vouches that (d_grid, epoch) names one content -- the inflated map of the last build on this
+// stream is reused when it was built from the same (grid, epoch, parameters)
+hipError_t build_hit_map(const CollisionParams& c, const int8_t* d_grid, MapScratch& sc, hipStream_t s,
+                         unsigned long long epoch = 0)
 {
   if (c.r_col < 0 || c.r_col > 8192 || c.r_max < c.r_bnd) return hipErrorInvalidValue;
   const short2* d_off = nullptr;
@@ -524,11 +550,23 @@ hipError_t build_hit_map(const CollisionParams& c, const int8_t* d_grid, MapScra
         e = hipMemsetAsync(buf->cells, 0, bytes, s);
         if (e != hipSuccess) return e;
       }
+      if (epoch != 0 && buf->stamp != 0 && buf->built_grid == d_grid && buf->built_epoch == epoch &&
+          same_params(buf->built_params, c)) {
+        sc.map.cells = buf->cells;
+        sc.map.R = R;
+        sc.map.w = w;
+        sc.map.h = h;
+        sc.map.stamp = static_cast<uint8_t>(buf->stamp);
+        return hipSuccess;
+      }
       if (++buf->stamp > 255u) {
         e = hipMemsetAsync(buf->cells, 0, buf->cap, s);
         if (e != hipSuccess) return e;
         buf->stamp = 1;
       }
+      buf->built_grid = epoch != 0 ? d_grid : nullptr;
+      buf->built_epoch = epoch;
+      buf->built_params = c;
       cells = buf->cells;
       stamp = buf->stamp;
     }
@@ -631,11 +669,15 @@ hipError_t launch_tick_begin(int* d_follow, unsigned* d_count, int* d_skip, unsi
   return hipGetLastError();
 }
 
-// the dynamic window of a fleet tick: one workgroup per robot as above; robots with a valid twist leave at once.  The cost
-// model takes every robot as one that searches (the worst case: the inflated map pays for itself at a fraction of that)
-hipError_t launch_dwa_fleet(const CollisionParams& c, const DwaParams& d, const int8_t* d_grid, const double* d_x0,
-                            const double* d_vb, const double* d_traj, unsigned n_ref, double dt_ref, const int* d_valid,
-                            int* d_follow, unsigned* d_count, double* d_u, int* d_source, unsigned P, hipStream_t s)
+// Steps 3 and 4 of a fleet tick: validate_control of every robot's twist, then the dynamic window of the robots whose twist
+// was rejected (one workgroup per robot as above; robots with a valid twist leave at once).  ONE inflated map serves both
+// launches (and, with grid_epoch != 0, the ticks that follow on an unchanged grid).  The cost model takes every robot as
+// one that searches (the worst case: the inflated map pays for itself at a fraction of that).
+hipError_t launch_validate_and_dwa_fleet(const CollisionParams& c, const DwaParams& d, const int8_t* d_grid,
+                                         unsigned long long grid_epoch, const double* d_x0, const double* d_vb,
+                                         const double* d_traj, unsigned n_ref, double dt_ref, double val_dt, unsigned val_steps,
+                                         int* d_valid, int* d_follow, unsigned* d_count, double* d_u, int* d_source, unsigned P,
+                                         hipStream_t s)
 {
   if (P == 0) return hipSuccess;
   const size_t nsamp = static_cast<size_t>(d.ns[0]) * d.ns[1] * d.ns[2];
@@ -643,10 +685,13 @@ hipError_t launch_dwa_fleet(const CollisionParams& c, const DwaParams& d, const 
   if (lds > 64 * 1024) return hipErrorInvalidValue;
   const unsigned block = nsamp <= 64 ? 64 : kDwaBlock;
   const FleetTick ft{ d_valid, d_follow, d_count, d_u, d_source };
-  if (use_hit_map(static_cast<size_t>(P) * nsamp * d.steps, d.steps, c)) {
+  const dim3 vgrid((P + kBlock - 1) / kBlock);
+  if (use_hit_map(static_cast<size_t>(P) * (val_steps + nsamp * d.steps), d.steps, c)) {
     MapScratch sc;
-    hipError_t e = build_hit_map(c, d_grid, sc, s);
+    hipError_t e = build_hit_map(c, d_grid, sc, s, grid_epoch);
     if (e == hipSuccess) {
+      hipLaunchKernelGGL(validate_control_kernel<true>, vgrid, dim3(kBlock), 0, s, c, sc.map, d_grid, d_x0, d_u, val_dt,
+                         val_steps, P, d_valid);
       hipLaunchKernelGGL((dwa_control_kernel<true, true>), dim3(P), dim3(block), lds, s, c, d, sc.map, d_grid, d_x0, d_vb,
                          static_cast<const double*>(nullptr), d_traj, n_ref, dt_ref, static_cast<double*>(nullptr),
                          static_cast<int*>(nullptr), ft);
@@ -655,6 +700,8 @@ hipError_t launch_dwa_fleet(const CollisionParams& c, const DwaParams& d, const 
     release_hit_map(sc, s);
     return e;
   }
+  hipLaunchKernelGGL(validate_control_kernel<false>, vgrid, dim3(kBlock), 0, s, c, HitMap{ nullptr, 0, 0, 0, 0 }, d_grid, d_x0,
+                     d_u, val_dt, val_steps, P, d_valid);
   hipLaunchKernelGGL((dwa_control_kernel<false, true>), dim3(P), dim3(block), lds, s, c, d, HitMap{ nullptr, 0, 0, 0, 0 },
                      d_grid, d_x0, d_vb, static_cast<const double*>(nullptr), d_traj, n_ref, dt_ref,
                      static_cast<double*>(nullptr), static_cast<int*>(nullptr), ft);

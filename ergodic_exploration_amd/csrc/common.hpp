@@ -231,12 +231,14 @@ hipError_t launch_dwa_control(const CollisionParams& c, const DwaParams& d, cons
                               const double* d_x0, const double* d_vb, const double* d_vref,
                               const double* d_xt_ref, unsigned n_ref, double dt_ref, unsigned P,
                               double* d_u_opt, int* d_found, hipStream_t s);
-// eea_tick_batch: step 1 (follow counters, skip mask) and step 4 (the dynamic window where validate_control failed, per
-// robot towards its own twist or along its optTraj, and the state update) of the fleet tick
+// eea_tick_batch: step 1 (follow counters, skip mask) and steps 3 + 4 (validate_control; the dynamic window where it failed,
+// per robot towards its own twist or along its optTraj, and the state update) of the fleet tick
 hipError_t launch_tick_begin(int* d_follow, unsigned* d_count, int* d_skip, unsigned dwa_steps, unsigned P, hipStream_t s);
-hipError_t launch_dwa_fleet(const CollisionParams& c, const DwaParams& d, const int8_t* d_grid, const double* d_x0,
-                            const double* d_vb, const double* d_traj, unsigned n_ref, double dt_ref, const int* d_valid,
-                            int* d_follow, unsigned* d_count, double* d_u, int* d_source, unsigned P, hipStream_t s);
+hipError_t launch_validate_and_dwa_fleet(const CollisionParams& c, const DwaParams& d, const int8_t* d_grid,
+                                         unsigned long long grid_epoch, const double* d_x0, const double* d_vb,
+                                         const double* d_traj, unsigned n_ref, double dt_ref, double val_dt, unsigned val_steps,
+                                         int* d_valid, int* d_follow, unsigned* d_count, double* d_u, int* d_source, unsigned P,
+                                         hipStream_t s);
 // frees the cached ring offsets and inflated-map buffers of every device
 void release_collision_caches();
 

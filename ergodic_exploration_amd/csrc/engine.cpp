@@ -1604,14 +1604,13 @@ eea_status eea_tick_batch(eea_engine* e, unsigned B, const eea_batch_io* io, con
   rio.d_skip = tick->d_skip;
   st = control_batch_impl<double>(e, B, &rio, true, s);
   if (st != EEA_OK) return st;
-  // 3. validate_control (:238, numerics.hpp:312-330)
+  // 3. validate_control (:238, numerics.hpp:312-330); 4. the dynamic window where the twist was rejected (:240-277), u /
+  // follow_dwa / i updated in place.  One inflated map for both
   const unsigned val_steps = static_cast<unsigned>(std::abs(tick->val_horizon / tick->val_dt));
-  EEA_HIP(eea::launch_validate_control(c, tick->d_grid, static_cast<const double*>(io->d_pose), tick->d_u, tick->val_dt,
-                                       val_steps, B, tick->d_valid, s));
-  // 4. the dynamic window where the twist was rejected (:240-277), u / follow_dwa / i updated in place
-  EEA_HIP(eea::launch_dwa_fleet(c, d, tick->d_grid, static_cast<const double*>(io->d_pose), tick->d_vb, tick->d_traj,
-                                static_cast<unsigned>(e->T), e->cfg.dt, tick->d_valid, tick->d_follow_dwa, tick->d_dwa_count,
-                                tick->d_u, tick->d_source, B, s));
+  EEA_HIP(eea::launch_validate_and_dwa_fleet(c, d, tick->d_grid, tick->grid_epoch, static_cast<const double*>(io->d_pose),
+                                             tick->d_vb, tick->d_traj, static_cast<unsigned>(e->T), e->cfg.dt, tick->val_dt,
+                                             val_steps, tick->d_valid, tick->d_follow_dwa, tick->d_dwa_count, tick->d_u,
+                                             tick->d_source, B, s));
   return EEA_OK;
 }
 

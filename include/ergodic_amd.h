@@ -462,6 +462,10 @@ typedef struct {
   int* d_source;          /* [B]       out, optional: who produced u -- 0 control(), 1 a followed DWA twist,
                                        2 DWA tracking optTraj(), 3 DWA re-run towards the followed twist        */
   double val_dt, val_horizon;
+  unsigned long long grid_epoch; /* 0: the grid's content may have changed since the last tick.  Otherwise the caller vouches
+                                       that (d_grid, grid_epoch) names ONE content (bump it with every map update, ~1 Hz
+                                       against the loop's 10 Hz): the inflated collision map of the last tick on this stream
+                                       is reused instead of rebuilt                                                */
 } eea_tick_io;
 eea_status eea_tick_batch(eea_engine* e, unsigned B, const eea_batch_io* io, const eea_tick_io* tick,
                           const eea_collision_cfg* ccfg, const eea_dwa_cfg* dcfg, void* stream);

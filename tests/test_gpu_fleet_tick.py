@@ -85,7 +85,10 @@ def test_fleet_tick_against_independent_oracle_loops(model, kernel):
             eng.tick_batch(B, dev(poses), d_ut, d_follow, d_count, d_u, dev(vb), d_grid, d_traj, d_valid, d_skip, ccfg, dcfg,
                            0.1, 0.5, source=d_source, mem_cols=dev(mem[:, :t + 1]), n_mem=torch.full((B,), t + 1, dtype=torch.int32,
                                                                                                    device="cuda"),
-                           mem_stride=t + 1, status=d_status)
+                           mem_stride=t + 1, status=d_status,
+                           # (the inflated collision map is rebuilt every tick, or kept while the caller's epoch says the
+                           # grid has not changed: 1 before the wall appears, 2 after)
+                           grid_epoch=0 if kernel != "wave" else (1 if t < 12 else 2))
             torch.cuda.synchronize()
             u, src, follow, count = d_u.cpu().numpy(), d_source.cpu().numpy(), d_follow.cpu().numpy(), d_count.cpu().numpy()
             valid, ut_after = d_valid.cpu().numpy(), d_ut.cpu().numpy()
