@@ -539,10 +539,39 @@ def single_robot_ticks(torch, capi, np):
         for _ in range(n):
             eng.control(MAP_BOUNDS, x)
         lat = (time.perf_counter() - t0) / n
+        # the same calls served by the RESIDENT workgroup (EEA_OPT_RESIDENT_CONTROL: a host-mapped mailbox, no launch per call)
+        lat_res = None
+        try:
+            capi.set_option(capi.OPT_RESIDENT_CONTROL, 1)
+            for _ in range(20):
+                eng.control(MAP_BOUNDS, x)
+            t0 = time.perf_counter()
+            for _ in range(n):
+                eng.control(MAP_BOUNDS, x)
+            lat_res = (time.perf_counter() - t0) / n
+        finally:
+            capi.set_option(capi.OPT_RESIDENT_CONTROL, 0)
         res.append({"config": c["name"], "kinematics": c["model"], "num_basis": c["K"], "horizon_steps": eng.T,
-                    "dtype": c["prec"], "gpu_us_per_call": 1e6 * lat})
+                    "dtype": c["prec"], "gpu_us_per_call": 1e6 * lat,
+                    "gpu_us_per_call_resident": None if lat_res is None else 1e6 * lat_res})
         eng.close()
     return res
+
+
+def cpp_tick_latency():
+    """host/test/tick_latency.cpp: the same dependent eea_control calls from a C++ host (what a maintainer's binding costs,
+    without this file's Python around every call)"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ergodic_exploration_amd", "host", "build", "tick_latency")
+    if not os.path.exists(exe):
+        return {"error": "host/build/tick_latency is not built (__graft_entry__.build())"}
+    try:
+        r = subprocess.run([exe, "2000"], capture_output=True, text=True, timeout=120)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+        return {"driver": "ergodic_exploration_amd/host/test/tick_latency.cpp",
+                "cases": json.loads(line[-1][len("RESULT "):])} if line else {"error": (r.stdout + r.stderr)[-300:]}
+    except Exception as exc:  # noqa: BLE001
+        return {"error": repr(exc)}
 
 
 def cpu_ticks(seconds_each=0.3):
@@ -1083,8 +1112,11 @@ def main():
                 out["single_robot_tick"] = {
                     "note": "the reference's own use: ONE robot, one control() per tick (exploration.hpp:232) -- dependent "
                             "eea_control calls at every BASELINE shape, wall time per call incl. the host round trip; "
+                            "gpu_us_per_call_resident: served by the resident workgroup (EEA_OPT_RESIDENT_CONTROL: a host-mapped "
+                            "mailbox instead of a launch per call); cpp_host: the same calls from a C++ loop; "
                             "cpu_port_us_per_call = the oracle's control() at the same shape, 1 thread, this host",
-                    "cases": single_robot_ticks(torch, capi, np)}
+                    "cases": single_robot_ticks(torch, capi, np),
+                    "cpp_host": cpp_tick_latency()}
             except Exception as exc:  # noqa: BLE001 -- the headline line must not die with a secondary leg
                 out["single_robot_tick"] = {"error": repr(exc)}
         if world == 1 and not args.no_latency and not f32:

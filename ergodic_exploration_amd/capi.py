@@ -19,7 +19,7 @@ MODEL_OMNI, MODEL_SIMPLE_CART = 0, 1
 PREC_F64, PREC_F32 = 0, 1
 OK, ERR_INVALID_ARGUMENT, ERR_INVALID_TWIST, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_TARGET, ERR_TIMEOUT = range(7)
 # eea_set_option (process-wide dispatch options; the library reads no environment variable)
-OPT_CONTROL_KERNEL, OPT_WORKGROUP_THREADS, OPT_COLLISION_IMPL, OPT_MAILBOX_POLL, OPT_REBUILD_IMPL, OPT_AGENT_LANES = range(6)
+OPT_CONTROL_KERNEL, OPT_WORKGROUP_THREADS, OPT_COLLISION_IMPL, OPT_MAILBOX_POLL, OPT_REBUILD_IMPL, OPT_AGENT_LANES, OPT_RESIDENT_CONTROL = range(7)
 
 
 class EngineError(RuntimeError):

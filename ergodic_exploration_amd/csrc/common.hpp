@@ -85,6 +85,40 @@ template <typename R>
 hipError_t launch_control(const ControlParams<R>& p, unsigned B, int model, int n_mem_max,
                           bool rollout_only, hipStream_t stream);
 
+// The resident single-robot workgroup (control_kernel_impl.hpp control_resident_kernel; EEA_OPT_RESIDENT_CONTROL): one launch
+// serves one robot's control() calls from a host-mapped mailbox until it has been idle for idle_ticks (100 MHz) or is told to
+// leave.  The mailbox layout (host side: engine.cpp) is ResidentMailF64 / F32 below.
+constexpr int kResidentMemCols = 128;  // capacity of the mapped replay-memory buffer (the shipped batch_size is 100)
+template <typename R>
+struct ResidentMail
+{
+  // host -> device: ONE 64-byte line, the request number written last -- the workgroup's poll fetches the whole line (16
+  // lanes, one dword each: one PCIe read), so a new request number arrives together with its data
+  alignas(64) R pose[3];
+  R map_x, map_y;      // map_pos_ is refreshed on every call (ergodic_control.hpp:366-367)
+  int n_mem;           // valid columns of the mapped replay-memory buffer
+  int cmd;             // 1 = leave
+  unsigned req;        // request number (only grows)
+  // device -> host
+  alignas(64) R u0[3];
+  int status;
+  int done;            // = the request's number once u0 / status are visible
+  int alive;           // 0 once the workgroup has left
+};
+static_assert(offsetof(ResidentMail<double>, req) + sizeof(unsigned) <= 64 && offsetof(ResidentMail<double>, u0) == 64,
+              "the request is one cache line");
+// what the body reads instead of the mailbox: device memory, filled by the workgroup from the fetched line
+template <typename R>
+struct ResidentStage
+{
+  R pose[3];
+  int n_mem;
+};
+
+template <typename R>
+hipError_t launch_control_resident(const ControlParams<R>& p, int model, int n_mem_max, void* d_mail, void* d_stage,
+                                   unsigned first_seen, long long idle_ticks, hipStream_t stream);
+
 // Wavefront-per-agent control kernel (control_wave_impl.hpp): horizons of at most 256 steps, K <= 16 or K = 20.
 // launch_control_wave needs control_wave_eligible.
 template <typename R>

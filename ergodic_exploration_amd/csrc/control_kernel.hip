@@ -47,7 +47,52 @@ hipError_t launch_block(const ControlParams<R>& p, unsigned B, int Nmax, bool ro
       return launch_model<R, MODEL, 256>(p, B, Nmax, rollout_only, lds, stream);
   }
 }
+template <typename R, int MODEL, int BLK>
+hipError_t resident_model(const ControlParams<R>& p, int Nmax, size_t lds, void* mail, void* stage, unsigned first_seen,
+                          long long idle_ticks, hipStream_t stream)
+{
+  switch (p.K) {
+    case 5:
+      return launch_resident_one<R, MODEL, 5, BLK>(p, Nmax, lds, mail, stage, first_seen, idle_ticks, stream);
+    case 10:
+      return launch_resident_one<R, MODEL, 10, BLK>(p, Nmax, lds, mail, stage, first_seen, idle_ticks, stream);
+    case 20:
+      return launch_resident_one<R, MODEL, 20, BLK>(p, Nmax, lds, mail, stage, first_seen, idle_ticks, stream);
+    case 30:
+      return launch_resident_one<R, MODEL, 30, BLK>(p, Nmax, lds, mail, stage, first_seen, idle_ticks, stream);
+    default:
+      return launch_resident_one<R, MODEL, 0, BLK>(p, Nmax, lds, mail, stage, first_seen, idle_ticks, stream);
+  }
+}
+template <typename R, int MODEL>
+hipError_t resident_block(const ControlParams<R>& p, int Nmax, size_t lds, void* mail, void* stage, unsigned first_seen,
+                          long long idle_ticks, hipStream_t stream)
+{
+  switch (control_threads(p.T)) {
+    case 64:
+      return resident_model<R, MODEL, 64>(p, Nmax, lds, mail, stage, first_seen, idle_ticks, stream);
+    case 128:
+      return resident_model<R, MODEL, 128>(p, Nmax, lds, mail, stage, first_seen, idle_ticks, stream);
+    default:
+      return resident_model<R, MODEL, 256>(p, Nmax, lds, mail, stage, first_seen, idle_ticks, stream);
+  }
+}
 }  // namespace
+
+// the resident single-robot workgroup (control_resident_kernel): p.pose / u0 / status / done / n_mem / mem_cols point into
+// the host-mapped mailbox and replay-memory buffer; n_mem_max = the buffer's capacity in columns
+template <typename R>
+hipError_t launch_control_resident(const ControlParams<R>& p, int model, int n_mem_max, void* d_mail, void* d_stage,
+                                   unsigned first_seen, long long idle_ticks, hipStream_t stream)
+{
+  const int Nmax = p.T + n_mem_max;
+  const size_t lds = control_lds_bytes<R>(p.T, p.K, n_mem_max, p.chunk);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  if (model == kModelOmni) return resident_block<R, kModelOmni>(p, Nmax, lds, d_mail, d_stage, first_seen, idle_ticks, stream);
+  return resident_block<R, kModelSimpleCart>(p, Nmax, lds, d_mail, d_stage, first_seen, idle_ticks, stream);
+}
+template hipError_t launch_control_resident<double>(const ControlParams<double>&, int, int, void*, void*, unsigned, long long, hipStream_t);
+template hipError_t launch_control_resident<float>(const ControlParams<float>&, int, int, void*, void*, unsigned, long long, hipStream_t);
 
 template <typename R>
 size_t control_lds_bytes(int T, int K, int n_mem_max, int /*chunk*/)

@@ -221,15 +221,15 @@ __device__ __forceinline__ R wrap_pi_fast(R rad)
   return rad - pi;
 }
 
-// BLK: threads per agent (64, 128 or 256): short horizons take fewer wavefronts per agent
+// BLK: threads per agent (64, 128 or 256): short horizons take fewer wavefronts per agent.
+// The body of one agent's control() call as a device function: control_kernel (one launch per call) and
+// control_resident_kernel (a workgroup that stays and serves one robot's calls from a host mailbox) share it.
 template <typename R, int MODEL, int KC, int BLK>
-__global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
-    const ControlParams<R> p, const int Nmax, const int rollout_only)
+__device__ __forceinline__ void control_agent(const ControlParams<R>& p, const int Nmax, const int rollout_only, const int b)
 {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   R* const sm = reinterpret_cast<R*>(smem_raw);
 
-  const int b = blockIdx.x;
   if (p.skip != nullptr && p.skip[b] != 0) return;  // eea_batch_io::d_skip: the agent is left out (workgroup-uniform)
   const int tid = threadIdx.x;
   const int lane = tid & (kWave - 1);
@@ -896,6 +896,118 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
     }
   }
   EEA_STAMP(11);
+}
+
+template <typename R, int MODEL, int KC, int BLK>
+__global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_kernel(
+    const ControlParams<R> p, const int Nmax, const int rollout_only)
+{
+  control_agent<R, MODEL, KC, BLK>(p, Nmax, rollout_only, static_cast<int>(blockIdx.x));
+}
+
+// ---- one robot, one control() per tick, WITHOUT a launch per call (round 5) ------------------------------------------------
+// The reference's real use is one robot at 10 Hz (exploration.hpp:232); a launch per call costs the host -> device -> host
+// round trip of a dispatch (18-22 us whatever the shape; the reference's smallest shipped shape takes 6 us on one CPU thread).
+// This workgroup STAYS: it polls a host-mapped mailbox (pose + request number in one cache line, written by eea_control),
+// runs the same control_agent body, and answers through the mailbox (u0, status, done = request number: system-scope
+// release, as the one-launch path).  Bounded in every direction: it leaves by itself after `idle_ticks` of the constant 100
+// MHz clock without a request (alive = 0 tells the host, which launches it again on the next call), on an exit command, and
+// the body has no unbounded wait.  Opt-in: EEA_OPT_RESIDENT_CONTROL.
+template <typename R, int MODEL, int KC, int BLK>
+__global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_resident_kernel(
+    const ControlParams<R> p0, const int Nmax, ResidentMail<R>* const mail, ResidentStage<R>* const stage,
+    const unsigned first_seen, const long long idle_ticks)
+{
+  __shared__ unsigned s_line[16];
+  constexpr int kReq = offsetof(ResidentMail<R>, req) / 4, kCmd = offsetof(ResidentMail<R>, cmd) / 4;
+  constexpr int kNmem = offsetof(ResidentMail<R>, n_mem) / 4, kMapX = offsetof(ResidentMail<R>, map_x) / 4;
+  unsigned last = first_seen;
+  for (;;) {
+    if (threadIdx.x < kWave) {  // wavefront 0 polls: lanes 0..15 fetch the request line, one dword each
+      const unsigned* const line = reinterpret_cast<const unsigned*>(mail);
+      const int l = threadIdx.x & 15;
+      const long long t0 = wall_clock64();
+      unsigned v, r;
+      bool idle = false;
+      for (;;) {
+        v = __hip_atomic_load(line + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        r = __builtin_amdgcn_readlane(v, kReq);
+        if (r != last) break;
+        if (wall_clock64() - t0 > idle_ticks) {
+          idle = true;
+          break;
+        }
+        __builtin_amdgcn_s_sleep(2);
+      }
+      if (idle) {
+        // idle for too long: say so FIRST, then look once more -- a request posted before the host can have seen alive = 0 is
+        // still served, one posted later finds alive = 0 and launches a new workgroup (eea_control)
+        if (threadIdx.x == 0) __hip_atomic_store(&mail->alive, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        __builtin_amdgcn_s_sleep(64);
+        v = __hip_atomic_load(line + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      if (threadIdx.x < 16) s_line[threadIdx.x] = v;
+    }
+    __syncthreads();
+    const unsigned r = s_line[kReq];
+    if (r == last) return;  // (alive is 0)
+    last = r;
+    if (s_line[kCmd] != 0u) {
+      if (threadIdx.x == 0) {
+        __hip_atomic_store(&mail->alive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mail->done, static_cast<int>(r), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+    }
+    // the body reads the pose and the column count from DEVICE memory (one more trip over PCIe per field otherwise)
+    ControlParams<R> p = p0;
+    {
+      constexpr int kPoseDwords = 3 * sizeof(R) / 4;
+      unsigned* const st = reinterpret_cast<unsigned*>(stage);
+      if (threadIdx.x < kPoseDwords) st[threadIdx.x] = s_line[threadIdx.x];
+      if (threadIdx.x == kPoseDwords) st[offsetof(ResidentStage<R>, n_mem) / 4] = s_line[kNmem];
+      R mx, my;
+      if (sizeof(R) == 8) {
+        mx = static_cast<R>(__hiloint2double(static_cast<int>(s_line[kMapX + 1]), static_cast<int>(s_line[kMapX])));
+        my = static_cast<R>(__hiloint2double(static_cast<int>(s_line[kMapX + 3]), static_cast<int>(s_line[kMapX + 2])));
+      } else {
+        mx = static_cast<R>(__int_as_float(static_cast<int>(s_line[kMapX])));
+        my = static_cast<R>(__int_as_float(static_cast<int>(s_line[kMapX + 1])));
+      }
+      p.map_x = mx;
+      p.map_y = my;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // whatever other kernels (or the host: eea_set_ut) wrote since the last request, and the stage just written, are behind
+    // this workgroup's L1
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    p.pose = stage->pose;
+    p.n_mem = &stage->n_mem;
+    // the answer is announced HERE, behind every store of the request (the one-launch path announces it as soon as u0 is out:
+    // there the stream orders whatever follows behind the kernel; here nothing does)
+    p.done = nullptr;
+    control_agent<R, MODEL, KC, BLK>(p, Nmax, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(&mail->done, static_cast<int>(r), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+template <typename R, int MODEL, int KC, int BLK>
+hipError_t launch_resident_one(const ControlParams<R>& p, int Nmax, size_t lds, void* mail, void* stage, unsigned first_seen,
+                               long long idle_ticks, hipStream_t stream)
+{
+  auto kern = control_resident_kernel<R, MODEL, KC, BLK>;
+  if (lds > 64 * 1024) {
+    const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize,
+                                             static_cast<int>(lds));
+    if (e != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(kern, dim3(1), dim3(BLK), lds, stream, p, Nmax, static_cast<ResidentMail<R>*>(mail),
+                     static_cast<ResidentStage<R>*>(stage), first_seen, idle_ticks);
+  return hipGetLastError();
 }
 
 template <typename R, int MODEL, int KC, int BLK>

@@ -23,7 +23,7 @@ namespace
 using eea::fail;
 
 // process-wide dispatch options (eea_set_option); index = EEA_OPT_*
-std::atomic<int> g_options[EEA_OPT_COUNT] = { { 0 }, { 0 }, { 0 }, { 1 }, { 0 }, { 0 } };
+std::atomic<int> g_options[EEA_OPT_COUNT] = { { 0 }, { 0 }, { 0 }, { 1 }, { 0 }, { 0 }, { 0 } };
 }  // namespace
 
 namespace eea
@@ -142,6 +142,18 @@ struct eea_engine
   double last_pose[3] = { 0, 0, 0 };
   int mail_seq = 0;          // sequence number of the last single-agent launch
   int* mail_done = nullptr;  // set while eea_control fills the launch parameters
+  unsigned long phik_gen = 0;  // bumped whenever phi_k / the domain changes
+
+  // resident single-robot workgroup (EEA_OPT_RESIDENT_CONTROL): host-mapped mailbox + replay-memory buffer, its own stream
+  void* h_rmail = nullptr;
+  void* d_rmail = nullptr;
+  void* h_rmem = nullptr;
+  void* d_rmem = nullptr;
+  DevBuf d_rstage;             // ResidentStage: the request's pose / column count in device memory
+  hipStream_t stream_res = nullptr;
+  bool res_launched = false;   // a workgroup was launched and has not been seen to leave
+  unsigned res_seq = 0;        // last request number
+  unsigned long res_gen = 0;   // phik_gen it was launched with
 };
 
 namespace
@@ -357,6 +369,7 @@ eea_status rebuild_phik(eea_engine* e, hipStream_t s, bool wait)
       e->rebuild_pending = true;
     }
     e->have_phik = true;
+  ++e->phik_gen;  // (the resident single-robot workgroup restarts on the next call)
     e->have_fill_grid = true;
     e->phi_is_raw = true;
     e->fill_deferred = true;
@@ -424,6 +437,7 @@ eea_status rebuild_phik(eea_engine* e, hipStream_t s, bool wait)
     e->rebuild_pending = true;
   }
   e->have_phik = true;
+  ++e->phik_gen;  // (the resident single-robot workgroup restarts on the next call)
   e->have_fill_grid = true;
   e->phi_is_raw = true;
   return EEA_OK;
@@ -480,6 +494,7 @@ eea_status set_target_grid_impl(eea_engine* e, unsigned nx, unsigned ny, const v
                                        static_cast<R*>(e->d_phik.p), s));
   EEA_HIP(hipStreamSynchronize(s));
   e->have_phik = true;
+  ++e->phik_gen;  // (the resident single-robot workgroup restarts on the next call)
   return EEA_OK;
 }
 
@@ -713,6 +728,119 @@ eea_status make_dwa_params(const eea_dwa_cfg* dcfg, eea::DwaParams& d)
   return EEA_OK;
 }
 
+// ---- resident single-robot workgroup (control_kernel_impl.hpp control_resident_kernel) --------------------------------------
+constexpr long long kResidentIdleTicks = 25000000LL;  // 250 ms of the 100 MHz clock: a 10 Hz loop keeps it alive
+
+// tells the workgroup to leave and waits until it has (no-op when none was launched)
+eea_status resident_stop(eea_engine* e)
+{
+  if (!e->res_launched) return EEA_OK;
+  // (the two mailbox layouts differ only in the width of the reals in front of cmd / req: go through the right one)
+  if (e->f32) {
+    auto* m = static_cast<eea::ResidentMail<float>*>(e->h_rmail);
+    __atomic_store_n(&m->cmd, 1, __ATOMIC_RELAXED);
+    __atomic_store_n(&m->req, ++e->res_seq, __ATOMIC_RELEASE);
+  } else {
+    auto* m = static_cast<eea::ResidentMail<double>*>(e->h_rmail);
+    __atomic_store_n(&m->cmd, 1, __ATOMIC_RELAXED);
+    __atomic_store_n(&m->req, ++e->res_seq, __ATOMIC_RELEASE);
+  }
+  EEA_HIP(hipStreamSynchronize(e->stream_res));  // it leaves within microseconds (or has left already: idle)
+  if (e->f32) static_cast<eea::ResidentMail<float>*>(e->h_rmail)->cmd = 0;
+  else static_cast<eea::ResidentMail<double>*>(e->h_rmail)->cmd = 0;
+  e->res_launched = false;
+  return EEA_OK;
+}
+
+template <typename R>
+eea_status resident_start(eea_engine* e)
+{
+  using Mail = eea::ResidentMail<R>;
+  if (e->h_rmail == nullptr) {
+    EEA_HIP(hipHostMalloc(&e->h_rmail, sizeof(Mail), hipHostMallocMapped));
+    std::memset(e->h_rmail, 0, sizeof(Mail));
+    EEA_HIP(hipHostGetDevicePointer(&e->d_rmail, e->h_rmail, 0));
+    EEA_HIP(hipHostMalloc(&e->h_rmem, sizeof(R) * 3 * eea::kResidentMemCols, hipHostMallocMapped));
+    std::memset(e->h_rmem, 0, sizeof(R) * 3 * eea::kResidentMemCols);
+    EEA_HIP(hipHostGetDevicePointer(&e->d_rmem, e->h_rmem, 0));
+    EEA_HIP(hipStreamCreateWithFlags(&e->stream_res, hipStreamNonBlocking));
+    EEA_HIP(e->d_rstage.reserve(sizeof(eea::ResidentStage<R>)));
+  }
+  EEA_HIP(hipStreamSynchronize(e->stream_res));  // (an earlier workgroup that left by itself has completed)
+  eea_status st = finish_rebuild(e);             // phi_k of an enqueued rebuild is complete before the workgroup reads it
+  if (st != EEA_OK) return st;
+  EEA_HIP(hipStreamSynchronize(e->stream1));     // ... and so is everything else the launch path left behind (d_ut1)
+  Mail* const hm = static_cast<Mail*>(e->h_rmail);
+  Mail* const dm = static_cast<Mail*>(e->d_rmail);
+  eea::ControlParams<R> p;
+  fill_params<R>(e, p);
+  p.pose = dm->pose;   // (the workgroup points these two at its device-memory stage per request)
+  p.n_mem = &dm->n_mem;
+  p.ut = static_cast<R*>(e->d_ut1.p);
+  p.u0 = dm->u0;
+  p.status = &dm->status;
+  p.mem_cols = static_cast<const R*>(e->d_rmem);
+  p.mem_stride = static_cast<unsigned>(eea::kResidentMemCols);
+  p.rec_len = eea::ck_record_len(e->K2);
+  const size_t lds = eea::control_lds_bytes<R>(p.T, p.K, eea::kResidentMemCols, p.chunk);
+  if (lds > 160 * 1024) return EEA_ERR_UNSUPPORTED;  // (no message: the caller takes the launch path)
+  hm->alive = 1;
+  hm->cmd = 0;
+  __atomic_thread_fence(__ATOMIC_SEQ_CST);
+  EEA_HIP(eea::launch_control_resident<R>(p, e->cfg.model, eea::kResidentMemCols, e->d_rmail, e->d_rstage.p, e->res_seq,
+                                          kResidentIdleTicks, e->stream_res));
+  e->res_launched = true;
+  e->res_gen = e->phik_gen;
+  return EEA_OK;
+}
+
+// eea_control through the resident workgroup: post the request in the mailbox, poll the answer
+template <typename R>
+eea_status control_resident(eea_engine* e, const double x[3], const double* h_mem_cols, unsigned n_mem, double u_out[3])
+{
+  using Mail = eea::ResidentMail<R>;
+  eea_status st = EEA_OK;
+  if (e->res_launched && e->res_gen != e->phik_gen) {  // the domain / phi_k changed: the launch parameters are stale
+    st = resident_stop(e);
+    if (st != EEA_OK) return st;
+  }
+  Mail* hm = static_cast<Mail*>(e->h_rmail);
+  if (!e->res_launched || __atomic_load_n(&hm->alive, __ATOMIC_ACQUIRE) == 0) {
+    e->res_launched = false;
+    st = resident_start<R>(e);
+    if (st != EEA_OK) return st;
+    hm = static_cast<Mail*>(e->h_rmail);
+  }
+  to_real<R>(x, hm->pose, 3);
+  hm->map_x = static_cast<R>(e->map_x);
+  hm->map_y = static_cast<R>(e->map_y);
+  hm->n_mem = static_cast<int>(n_mem);
+  if (n_mem > 0) to_real<R>(h_mem_cols, static_cast<R*>(e->h_rmem), 3 * static_cast<size_t>(n_mem));
+  hm->status = 0;
+  const unsigned seq = ++e->res_seq;
+  __atomic_store_n(&hm->req, seq, __ATOMIC_RELEASE);
+  // the answer (bounded: ~2 s of polling), or the news that the workgroup left before it saw the request
+  bool relaunched = false;
+  for (long spin = 0;; ++spin) {
+    if (__atomic_load_n(&hm->done, __ATOMIC_ACQUIRE) == static_cast<int>(seq)) break;
+    if (__atomic_load_n(&hm->alive, __ATOMIC_ACQUIRE) == 0 &&
+        __atomic_load_n(&hm->done, __ATOMIC_ACQUIRE) != static_cast<int>(seq)) {
+      if (relaunched) return fail(EEA_ERR_HIP, "the resident control workgroup left twice without answering");
+      // it went idle just before the request: a new one starts from the request before this one and sees it at once
+      e->res_launched = false;
+      --e->res_seq;
+      st = resident_start<R>(e);
+      ++e->res_seq;
+      if (st != EEA_OK) return st;
+      relaunched = true;
+    }
+    if (spin > 400000000L) return fail(EEA_ERR_TIMEOUT, "the resident control workgroup does not answer");
+  }
+  if (hm->status == EEA_ERR_INVALID_TWIST) return fail(EEA_ERR_INVALID_TWIST, "Invalid twist y-velocity must be 0.");
+  for (int i = 0; i < 3; ++i) u_out[i] = static_cast<double>(hm->u0[i]);
+  return EEA_OK;
+}
+
 eea_status check_engine(const eea_engine* e)
 {
   if (e == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null engine");
@@ -734,6 +862,7 @@ eea_status eea_set_option(int option, int value)
     case EEA_OPT_MAILBOX_POLL: ok = value == 0 || value == 1; break;
     case EEA_OPT_REBUILD_IMPL: ok = value == 0 || value == 1; break;
     case EEA_OPT_AGENT_LANES: ok = value == 0 || value == 8 || value == 16 || value == 32 || value == 64; break;
+    case EEA_OPT_RESIDENT_CONTROL: ok = value == 0 || value == 1; break;
     default: return fail(EEA_ERR_INVALID_ARGUMENT, "unknown option");
   }
   if (!ok) return fail(EEA_ERR_INVALID_ARGUMENT, "option value out of range");
@@ -809,13 +938,14 @@ void eea_destroy(eea_engine* e)
 {
   if (e == nullptr) return;
   (void)hipSetDevice(e->cfg.device);
+  (void)resident_stop(e);  // the resident single-robot workgroup leaves before anything it reads is freed
   (void)finish_rebuild(e);
   if (e->stream1) {
     (void)hipStreamSynchronize(e->stream1);
     (void)hipStreamDestroy(e->stream1);
   }
   DevBuf* bufs[] = { &e->d_phik, &e->d_lamdak, &e->d_phi, &e->d_axis, &e->d_cx, &e->d_cy,
-                     &e->d_work, &e->d_gauss, &e->d_sum, &e->d_ut1, &e->d_traj1, &e->d_mem1,
+                     &e->d_work, &e->d_gauss, &e->d_sum, &e->d_ut1, &e->d_traj1, &e->d_mem1, &e->d_rstage,
                      &e->d_lut, &e->d_raw, &e->d_occ };
   for (DevBuf* b : bufs) b->release();
   for (auto& w : e->sum_ws) {
@@ -830,6 +960,9 @@ void eea_destroy(eea_engine* e)
   if (e->ev_rebuild) (void)hipEventDestroy(e->ev_rebuild);
   if (e->h_mail) (void)hipHostFree(e->h_mail);
   if (e->h_stage) (void)hipHostFree(e->h_stage);
+  if (e->h_rmail) (void)hipHostFree(e->h_rmail);
+  if (e->h_rmem) (void)hipHostFree(e->h_rmem);
+  if (e->stream_res) (void)hipStreamDestroy(e->stream_res);
   delete e;
 }
 
@@ -953,6 +1086,7 @@ eea_status eea_set_target_occupancy(eea_engine* e, unsigned nx, unsigned ny, con
   }
   EEA_HIP(hipStreamSynchronize(s));
   e->have_phik = true;
+  ++e->phik_gen;  // (the resident single-robot workgroup restarts on the next call)
   return EEA_OK;
 }
 
@@ -990,6 +1124,7 @@ eea_status eea_set_phik(eea_engine* e, const void* phik, int on_device, double l
   e->lx = lx;
   e->ly = ly;
   e->have_phik = true;
+  ++e->phik_gen;  // (the resident single-robot workgroup restarts on the next call)
   return EEA_OK;
 }
 
@@ -1011,6 +1146,7 @@ eea_status eea_set_phik_from_sums(eea_engine* e, const void* d_sums, double lx, 
   e->lx = lx;
   e->ly = ly;
   e->have_phik = true;
+  ++e->phik_gen;  // (the resident single-robot workgroup restarts on the next call)
   return EEA_OK;
 }
 
@@ -1242,6 +1378,15 @@ eea_status eea_control(eea_engine* e, double xmin, double xmax, double ymin, dou
   if (st != EEA_OK) return st;
   if (!e->have_phik) return fail(EEA_ERR_NO_TARGET, "no target set");
   for (int i = 0; i < 3; ++i) e->last_pose[i] = x[i];
+  // one robot, one control() per tick without a launch per call (EEA_OPT_RESIDENT_CONTROL); a replay-memory sample beyond
+  // the mapped buffer takes the launch path
+  if (eea::option(EEA_OPT_RESIDENT_CONTROL) != 0 && n_mem <= static_cast<unsigned>(eea::kResidentMemCols)) {
+    st = e->f32 ? control_resident<float>(e, x, h_mem_cols, n_mem, u_out) : control_resident<double>(e, x, h_mem_cols, n_mem, u_out);
+    if (st != EEA_ERR_UNSUPPORTED) return st;  // (UNSUPPORTED: the shape does not fit a resident workgroup -- launch path)
+  } else {
+    st = resident_stop(e);  // (the option was switched off, or this call does not fit: the launch path owns d_ut1 now)
+    if (st != EEA_OK) return st;
+  }
 
   eea_batch_io io;
   std::memset(&io, 0, sizeof(io));

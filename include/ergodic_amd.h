@@ -93,7 +93,12 @@ enum { EEA_OPT_CONTROL_KERNEL = 0,    /* 0 = automatic (wavefront-per-agent kern
                                          a wavefront: T <= 4 lanes, fp64, K = 5 / 10): 0 = by batch size and horizon
                                          (cost model), 64 = one wavefront per agent always, 8 / 16 / 32 = that group size
                                          wherever it is eligible (tests, A/B) */
-       EEA_OPT_COUNT = 6 };
+       EEA_OPT_RESIDENT_CONTROL = 6,  /* eea_control (one robot, one control() per tick): 1 = a RESIDENT workgroup serves the calls
+                                         from a host-mapped mailbox instead of one launch per call (the launch round trip is
+                                         18-22 us whatever the shape).  It leaves by itself after 250 ms without a call and
+                                         on eea_destroy; while it is there, device-wide waits (hipDeviceSynchronize, hipFree)
+                                         of the process take up to that long.  0 (default) = one launch per call */
+       EEA_OPT_COUNT = 7 };
 eea_status eea_set_option(int option, int value);
 int eea_get_option(int option);
 
