@@ -202,12 +202,13 @@ def phik_legs(args, torch, capi, np):
     gbs = nbytes / (ms * 1e-3) / 1e9
     traffic, traffic_source = None, "profiles/ (rocprofv3 --pmc passes, not collected in-run)"
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_phik_pmc.json")) as f:
+        pname = "r05_phik_pmc.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_phik_pmc.json")) else "r03_phik_pmc.json"
+        with open(os.path.join(ROOT, "profiles", pname)) as f:
             rec = json.load(f)
         if rec.get("grid") == n and rec.get("K") == K and rec.get("precision") == "f64":
             traffic = rec["hbm_read_bytes_x2_corrected"]
-            traffic_source = ("profiles/r03_phik_pmc.json (separate rocprofv3 --pmc FETCH_SIZE pass of this workload, x2 "
-                              "gfx950 correction; NOT measured in this run)")
+            traffic_source = ("profiles/%s (separate rocprofv3 --pmc FETCH_SIZE pass of this workload, x2 "
+                              "gfx950 correction; NOT measured in this run)" % pname)
     except Exception:
         pass
     out["roofline_phik"] = {"bound": "hbm", "kernel": "spatial_stream_kernel (+ sum_partials_kernel)",
@@ -215,7 +216,11 @@ def phik_legs(args, torch, capi, np):
                             "traffic": traffic, "traffic_source": traffic_source,
                             "bytes_per_launch": nbytes, "launch_ms": ms,
                             "workload": "Basis::spatialCoeff, %dx%d fp64 target grid (%.2f GB) resident in HBM, K=%d"
-                                        % (n, n, nbytes / 1e9, K)}
+                                        % (n, n, nbytes / 1e9, K),
+                            "note": "a SYNTHETIC grid sized to expose the HBM roofline of the streaming kernel.  The grids BASELINE "
+                                    "names (121x61, 256x256, 1024x1024: 59 KB - 8 MB) are launch-latency bound -- one workgroup from "
+                                    "the per-axis factors, 7 - 17 us of device time whatever the bytes (config_domain_rebuild below: "
+                                    "the 1024x1024 rebuild moves 1 MB in ~17 us = 0.8 %% of HBM)"}
     eng.close()
     del phi, part
     torch.cuda.empty_cache()
@@ -1017,7 +1022,7 @@ def main():
         hbm_gbs = G * bytes_per_opt * Bl / launch_s / 1e9
         tflops = G * flops_per_opt * Bl / launch_s / 1e12
         traffic, traffic_source = None, None
-        for name in ("r04_control_pmc.json", "r04_control_pmc_spl1.json"):
+        for name in ("r05_control_pmc.json", "r05_control_pmc_spl1.json", "r04_control_pmc.json", "r04_control_pmc_spl1.json"):
             pmc = os.path.join(ROOT, "profiles", name)
             if not os.path.exists(pmc):
                 continue
@@ -1036,7 +1041,9 @@ def main():
         # tools/summarize_prof.py from a separate profiled run: NOT measured in this run)
         profiled = {}
         try:
-            with open(os.path.join(ROOT, "profiles", "r04_bench_profile.json")) as f:
+            prof_name = "r05_bench_profile.json" if os.path.exists(os.path.join(ROOT, "profiles", "r05_bench_profile.json")) \
+                else "r04_bench_profile.json"
+            with open(os.path.join(ROOT, "profiles", prof_name)) as f:
                 rec = json.load(f)
             if (rec.get("agents") == B and rec.get("T") == T and rec.get("K") == K and rec.get("precision") == args.precision
                     and rec.get("concurrent_launches") == G and rec.get("steps_per_launch", 1) == SPL
@@ -1047,12 +1054,40 @@ def main():
                             "pass_period_us_profiled": rec["pass_period_us_from_trace"],
                             "frac_profiled": G * flops_per_opt * rec["agents_per_launch"] / (per_pass_us * 1e-6) / 1e12 / VALU_F64_PEAK_TF,
                             "effective_clock_ghz_profiled": rec.get("effective_clock_ghz"),
-                            "profiled_source": "profiles/r04_bench_profile.json (rocprofv3 --kernel-trace --stats of this "
+                            "profiled_source": "profiles/%s (rocprofv3 --kernel-trace --stats of this "
                                                "command shape, timed-region dispatches only; a separate run on another box "
-                                               "of the pool)"}
+                                               "of the pool)" % prof_name}
         except Exception:
             pass
         vpeak = VALU_F32_PEAK_TF if f32 else VALU_F64_PEAK_TF
+        # What the kernel's OWN instruction stream allows: a vector instruction holds a SIMD's pipe for 4
+        # cycles, a 4x4x4 fp64 matrix instruction for 16, and they share it (profiles/r02_ubench_coissue.txt): with w resident
+        # wavefronts per SIMD a pass cannot take less than w x (4 VALU + 16 MFMA) / clock.  Instruction counts per wavefront
+        # from the SQ counters of this kernel (profiles/r05_isa_counts.json, rocprofv3 --pmc), the static budget of round 4
+        # (profiles/r04_isa_budget.txt: 2 077 + 117) if that file is missing; clock = the measured shader clock under this
+        # load.  frac_of_issue_bound = issue_bound_us / pass time: how much of the pass the pipe is busy; what is left is
+        # dependency stalls and waits (SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES, the counter file).
+        issue = {}
+        try:
+            valu, mfma, src = 2077.0 + 117.0, 117.0, "profiles/r04_isa_budget.txt (static budget of the metric point)"
+            cpath = os.path.join(ROOT, "profiles", "r05_isa_counts.json")
+            if os.path.exists(cpath):
+                with open(cpath) as f:
+                    ic = json.load(f)
+                if ic.get("T") == T and ic.get("K") == K and ic.get("precision") == args.precision and ic.get("matrix_insts_per_wave"):
+                    valu, mfma, src = ic["valu_insts_per_wave_incl_matrix"], ic["matrix_insts_per_wave"], "profiles/r05_isa_counts.json (SQ counters)"
+                    issue["wait_inst_any_over_wave_cycles"] = ic.get("wait_inst_any_over_wave_cycles")
+            if T == 200 and K == 10 and not f32 and args.model == "simple_cart" and not args.n_mem:
+                clock = profiled.get("effective_clock_ghz_profiled") or 2.33
+                waves_per_simd = B / 1024.0
+                bound_us = waves_per_simd * (4.0 * (valu - mfma) + 16.0 * mfma) / (clock * 1e3)
+                issue.update({"issue_bound_us": bound_us, "frac_of_issue_bound": bound_us / (pass_ms * 1e3),
+                              "vector_insts_per_agent": valu - mfma, "matrix_insts_per_agent": mfma,
+                              "pipe_cycles_per_agent": 4.0 * (valu - mfma) + 16.0 * mfma, "shader_clock_ghz": clock,
+                              "wavefronts_per_simd": waves_per_simd, "issue_bound_source": src,
+                              "reference_formulation_cycles_per_agent": 4.0 * flops_per_opt / 2.0 / 64.0})
+        except Exception:
+            pass
         out = {
             "metric": "receding-horizon optimisations/sec at K=10x10, T=200; 1/2/4/8-GPU agent-batch",
             "value": value, "unit": "optimisations/s", "n_gpus": world, "steps": args.steps,
@@ -1082,15 +1117,23 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_source,
                          "flops_per_launch": flops_per_opt * Bl * SPL, "launch_ms": pass_ms * SPL,
                          "passes_per_launch": SPL, "agents_per_launch": Bl,
-                         "concurrent_launches": G, "achieved_per_launch": tflops / G, **profiled,
+                         "concurrent_launches": G, "achieved_per_launch": tflops / G, **profiled, **issue,
                          "note": "the control kernel is vector-ALU / transcendental bound, not HBM bound (SURVEY.md "
-                                 "8(d)); W = 2K^2N + 4K^2T + (4K+140)T flop per optimisation (reference formulation)"},
-            "roofline_hbm": {"bound": "hbm", "kernel": "control kernel", "achieved": hbm_gbs, "peak": HBM_PEAK_GBS,
-                             "unit": "GB/s", "frac": hbm_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                             "traffic_source": traffic_source, "bytes_per_launch": bytes_per_opt * Bl * SPL,
+                                 "8(d)); W = 2K^2N + 4K^2T + (4K+140)T flop per optimisation (reference formulation); frac = "
+                                 "achieved / the NOMINAL fp64 vector peak; frac_of_issue_bound = how busy the SIMD pipes are with "
+                                 "the instructions the kernel actually issues"},
+            "roofline_hbm": {"bound": "hbm", "kernel": "control kernel",
+                             "algorithmic_rate": hbm_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "algorithmic_frac": hbm_gbs / HBM_PEAK_GBS,
+                             "counter_rate": None if traffic is None else G * traffic / (launch_s * SPL) / 1e9,
+                             "traffic": traffic, "traffic_source": traffic_source, "bytes_per_launch": bytes_per_opt * Bl * SPL,
                              "launch_ms": pass_ms * SPL, "passes_per_launch": SPL, "agents_per_launch": Bl,
                              "concurrent_launches": G,
-                             "achieved_per_launch": hbm_gbs / G},
+                             "note": "algorithmic_rate = the bytes the reference formulation moves per optimisation (pose, controls in "
+                                     "and out) / time -- NOT bytes the device moved: with several steps per launch the controls stay in "
+                                     "L2 / LDS between steps and counter_rate (FETCH_SIZE x 2 + WRITE_SIZE of the profiled run) is what "
+                                     "HBM actually saw.  Either way the kernel is nowhere near the HBM roofline: north_star asks for the "
+                                     "figure"},
         }
         if world == 1 and not args.no_other_configs and not args.n_mem:
             try:
