@@ -420,10 +420,12 @@ def tick_legs(torch, capi, np):
     ccfg = capi.make_collision_cfg(x0, y0, res, xs, ys, *COLL)
     dcfg = capi.DwaCfg(*DWA)
     d_grid = torch.as_tensor(data).cuda()
-    st = torch.cuda.current_stream()
+    st = torch.cuda.Stream()      # every call below is enqueued on THIS stream, and so are the events around them
+    sp = st.cuda_stream
     rng = np.random.default_rng(99)
 
     def timed(fn, n):
+        torch.cuda.synchronize()   # (the inputs were produced on torch's own stream)
         for _ in range(3):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -433,7 +435,7 @@ def tick_legs(torch, capi, np):
             fn()
         e1.record(st)
         torch.cuda.synchronize()
-        return 1e3 * e0.elapsed_time(e1) / n   # us per call
+        return 1e3 * e0.elapsed_time(e1) / n   # us per call (device time on the launch stream)
 
     kernels = []
     try:
@@ -446,11 +448,12 @@ def tick_legs(torch, capi, np):
                 uo = torch.empty((P, 3), dtype=torch.float64, device="cuda")
                 xt = x[:, None, :].repeat(1, 50, 1).contiguous()
                 row = {"implementation": iname, "poses": P,
-                       "collision_check_us": timed(lambda: capi.collision_check_batch(ccfg, d_grid, x, hit), 50),
-                       "validate_control_us": timed(lambda: capi.validate_control_batch(ccfg, d_grid, x, u, 0.1, 0.5, hit), 50),
-                       "dwa_vref_us": timed(lambda: capi.dwa_control_batch(ccfg, dcfg, d_grid, x, u, uo, hit, vref=u), 10 if P > 4096 else 30),
-                       "dwa_traj_us": timed(lambda: capi.dwa_control_batch(ccfg, dcfg, d_grid, x, u, uo, hit, xt_ref=xt, dt_ref=0.1),
-                                            10 if P > 4096 else 30)}
+                       "collision_check_us": timed(lambda: capi.collision_check_batch(ccfg, d_grid, x, hit, stream=sp), 50),
+                       "validate_control_us": timed(lambda: capi.validate_control_batch(ccfg, d_grid, x, u, 0.1, 0.5, hit, stream=sp), 50),
+                       "dwa_vref_us": timed(lambda: capi.dwa_control_batch(ccfg, dcfg, d_grid, x, u, uo, hit, vref=u, stream=sp),
+                                            10 if P > 4096 else 30),
+                       "dwa_traj_us": timed(lambda: capi.dwa_control_batch(ccfg, dcfg, d_grid, x, u, uo, hit, xt_ref=xt, dt_ref=0.1,
+                                                                           stream=sp), 10 if P > 4096 else 30)}
                 row["collision_check_ns_per_pose"] = 1e3 * row["collision_check_us"] / P
                 row["dwa_vref_ns_per_rollout_step"] = 1e3 * row["dwa_vref_us"] / (P * 120 * 20)
                 kernels.append(row)
@@ -469,14 +472,14 @@ def tick_legs(torch, capi, np):
     d_follow, d_count, d_valid, d_skip, d_src = (z(B, dt=torch.int32) for _ in range(5))
     d_traj = z(B, T, 3)
     tick = lambda: eng.tick_batch(B, d_pose, d_ut, d_follow, d_count, d_u, d_vb, d_grid, d_traj, d_valid, d_skip, ccfg, dcfg,
-                                  0.1, 0.5, source=d_src)
+                                  0.1, 0.5, source=d_src, stream=sp)
     us = timed(tick, 200)
     src = d_src.cpu().numpy()
     d_follow.zero_(), d_count.zero_(), d_u.zero_(), d_ut.zero_()
     tick_cached = lambda: eng.tick_batch(B, d_pose, d_ut, d_follow, d_count, d_u, d_vb, d_grid, d_traj, d_valid, d_skip, ccfg, dcfg,
-                                         0.1, 0.5, source=d_src, grid_epoch=7)
+                                         0.1, 0.5, source=d_src, grid_epoch=7, stream=sp)
     us_cached = timed(tick_cached, 200)
-    ctl = timed(lambda: eng.control_batch(B, d_pose, d_ut, d_u), 200)
+    ctl = timed(lambda: eng.control_batch(B, d_pose, d_ut, d_u, stream=sp), 200)
     eng.close()
     return {"tick_kernels": {"grid": "%dx%d int8 @ %.2f m" % (xs, ys, res), "dwa_window": "3 x 8 x 5 samples x 20 steps",
                              "note": "device microseconds per call (HIP events on the launch stream); ring search: dependent byte "
