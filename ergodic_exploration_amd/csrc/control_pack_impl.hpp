@@ -51,7 +51,10 @@ __host__ __device__ constexpr int wave_lds_elems(int K, int A, int S)
 }
 // wavefronts per SIMD the kernel is compiled for: K = 5 fits 128 registers, K = 10 takes 164 (the second accumulator set,
 // the barrier gradient in registers)
-constexpr int waves_per_simd(int KC) { return KC == 5 ? 4 : 3; }
+#ifndef EEA_PACK_WAVES_K10
+#define EEA_PACK_WAVES_K10 3
+#endif
+constexpr int waves_per_simd(int KC) { return KC == 5 ? 4 : EEA_PACK_WAVES_K10; }
 
 // row_shr:N inside the 16-lane row, lanes without a source read 0
 template <int N>

@@ -13,6 +13,7 @@
 #include <stdexcept>
 #include <vector>
 
+#include <ergodic_exploration/dynamic_window.hpp>
 #include <ergodic_exploration/ergodic_control.hpp>
 
 namespace ergodic_exploration
@@ -177,6 +178,63 @@ public:
     hip_check(hipMemcpy(ck.memptr(), all.get(), sizeof(double) * modes_ * n_ * world, hipMemcpyDeviceToHost));
     return ck;
   }
+  // One iteration of Exploration<ModelT>::control's loop body (exploration.hpp:220-279) for EVERY agent of this rank on the
+  // shared occupancy grid, on the device (eea_tick_batch): control() of the agents that follow no dynamic-window twist,
+  // validate_control, the dynamic window per agent in its mode, the follow_dwa / i state machine.  The poses are those of
+  // setPoses; vb: 3 x n body twists (odometry).  map_seq != 0: the caller vouches that (grid, map_seq) names one map content
+  // (the inflated collision map is reused between ticks).  addStateMemory is the caller's (this class keeps no replay
+  // memory).  Returns the commanded twists, 3 x n.
+  mat tick(const GridMap& grid, const DynamicWindow& dwa, const mat& vb, double val_dt, double val_horizon,
+           unsigned long long map_seq = 0)
+  {
+    if (vb.n_rows() != 3 || vb.n_cols() != n_) throw std::invalid_argument("vb must be 3 x n_agents");
+    if (!d_follow_) {
+      alloc(d_follow_, sizeof(int) * n_);
+      alloc(d_count_, sizeof(unsigned) * n_);
+      alloc(d_cmd_, sizeof(double) * 3 * n_);
+      alloc(d_vb_, sizeof(double) * 3 * n_);
+      alloc(d_traj_, sizeof(double) * 3 * steps_ * n_);
+      alloc(d_valid_, sizeof(int) * n_);
+      alloc(d_skip_, sizeof(int) * n_);
+      alloc(d_source_, sizeof(int) * n_);
+      hip_check(hipMemset(d_follow_.get(), 0, sizeof(int) * n_));
+      hip_check(hipMemset(d_count_.get(), 0, sizeof(unsigned) * n_));
+      hip_check(hipMemset(d_cmd_.get(), 0, sizeof(double) * 3 * n_));
+    }
+    sync();
+    hip_check(hipMemcpy(d_vb_.get(), vb.memptr(), sizeof(double) * 3 * n_, hipMemcpyHostToDevice));
+    throw_on_error(eea_config_domain(engine_.get(), grid.xmin(), grid.xmax(), grid.ymin(), grid.ymax(), nullptr, streams_[0]));
+    eea_batch_io io{};
+    io.d_pose = d_pose_.get();
+    io.d_ut = d_ut_.get();
+    eea_tick_io t{};
+    t.d_follow_dwa = static_cast<int*>(d_follow_.get());
+    t.d_dwa_count = static_cast<unsigned*>(d_count_.get());
+    t.d_u = static_cast<double*>(d_cmd_.get());
+    t.d_vb = static_cast<const double*>(d_vb_.get());
+    t.d_grid = device_cells(grid);
+    t.d_traj = static_cast<double*>(d_traj_.get());
+    t.d_valid = static_cast<int*>(d_valid_.get());
+    t.d_skip = static_cast<int*>(d_skip_.get());
+    t.d_source = static_cast<int*>(d_source_.get());
+    t.val_dt = val_dt;
+    t.val_horizon = val_horizon;
+    t.grid_epoch = map_seq;
+    const eea_collision_cfg ccfg = dwa.collision().deviceConfig(grid);
+    throw_on_error(eea_tick_batch(engine_.get(), n_, &io, &t, &ccfg, &dwa.deviceConfig(), streams_[0]));
+    hip_check(hipStreamSynchronize(streams_[0]));
+    mat u(3, n_);
+    hip_check(hipMemcpy(u.memptr(), d_cmd_.get(), sizeof(double) * 3 * n_, hipMemcpyDeviceToHost));
+    return u;
+  }
+  // who produced each agent's twist in the last tick: 0 control(), 1 a followed DWA twist, 2 DWA along optTraj(), 3 DWA
+  // re-run towards the followed twist (Exploration::Source of the single-robot mirror, in that order)
+  std::vector<int> tickSources() const
+  {
+    std::vector<int> s(n_, 0);
+    if (d_source_) hip_check(hipMemcpy(s.data(), d_source_.get(), sizeof(int) * n_, hipMemcpyDeviceToHost));
+    return s;
+  }
   void sync()
   {
     for (hipStream_t s : streams_) hip_check(hipStreamSynchronize(s));
@@ -199,6 +257,7 @@ private:
   unsigned int groups_;
   std::shared_ptr<eea_engine> engine_;
   Dev d_pose_, d_ut_, d_u0_, d_ck_, d_agent_recs_, d_recs_;
+  Dev d_follow_, d_count_, d_cmd_, d_vb_, d_traj_, d_valid_, d_skip_, d_source_;  // tick(): per-agent loop state + scratch
   unsigned int rec_len_ = 0, step_ = 0;
   bool have_records_ = false;
   std::vector<hipStream_t> streams_;

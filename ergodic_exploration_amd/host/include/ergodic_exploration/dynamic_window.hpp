@@ -60,6 +60,9 @@ public:
   unsigned int steps() const { return static_cast<unsigned int>(std::abs(cfg_.horizon / cfg_.dt)); }
   double timeStep() const { return cfg_.dt; }
   double horizon() const { return cfg_.horizon; }
+  // the planner's configuration as the C ABI takes it (AgentBatch::tick: eea_tick_batch)
+  const eea_dwa_cfg& deviceConfig() const { return cfg_; }
+  const Collision& collision() const { return collision_; }
 
 private:
   static unsigned int at_least_one(unsigned int n, const char* name)

@@ -13,6 +13,7 @@
 #include <ergodic_exploration/dynamic_window.hpp>
 #include <ergodic_exploration/agent_batch.hpp>
 #include <ergodic_exploration/ergodic_control.hpp>
+#include <ergodic_exploration/exploration.hpp>
 
 using namespace ergodic_exploration;
 
@@ -468,6 +469,68 @@ static void test_agent_batch()
   }
 }
 
+// AgentBatch::tick (eea_tick_batch: the loop body of exploration.hpp:220-279 for a fleet) against one single-robot
+// Exploration<ModelT>::tick per agent (the mirror of the same loop body on the single-agent entry points, itself checked
+// against the oracle by tests/test_host_mirror.py): same decisions every tick, same twists
+static void test_agent_batch_tick()
+{
+  const unsigned int N = 9, ticks = 8;
+  mat Rinv(3, 3);
+  Rinv(0, 0) = 1.0;
+  Rinv(1, 1) = 1.0;
+  Rinv(2, 2) = 2.0;
+  const vec umin{ -1.0, -1.0, -2.0 }, umax{ 1.0, 1.0, 2.0 };
+  GridData cells(240 * 120, 0);
+  for (unsigned int i = 24; i < 72; ++i) {       // an obstacle at x in [2.4, 3.0], y in [0.2, 2.6]
+    for (unsigned int j = 68; j < 80; ++j) cells[i * 240 + j] = 100;
+  }
+  const GridMap grid(-1.0, 11.0, -1.0, 5.0, 0.05, cells);
+  const Target target({ Gaussian({ 2.5, 2.5 }, { 1.5, 1.5 }), Gaussian({ 8.5, 2.5 }, { 1.5, 1.5 }) });
+  const Collision collision(0.7, 1.0, 0.2, 0.8);
+  const DynamicWindow dwa(collision, 0.1, 2.0, 0.2, 2.5, 2.5, 1.0, 1.0, -1.0, 1.0, -1.0, 2.0, -2.0, 3, 8, 5);
+  AgentBatch<models::Omni> batch(N, 0.1, 5.0, 0.1, 1.0, 10, Rinv, umin, umax);
+  batch.setTarget(target);
+  std::vector<Exploration<models::Omni>> single;
+  for (unsigned int a = 0; a < N; ++a) {
+    // (batch_size 0: the replay buffer never contributes a column, buffer.cpp:92-108 -- the batch keeps no replay memory)
+    ErgodicControl<models::Omni> ec(models::Omni(), collision, 0.1, 5.0, 0.1, 1.0, 10, 1000000, 0, Rinv, umin, umax);
+    single.emplace_back(ec, collision, dwa);
+    single.back().setTarget(target);
+  }
+  mat poses(3, N), vb(3, N);
+  for (unsigned int a = 0; a < N; ++a) {
+    poses(0, a) = 1.0 + 0.1 * a;     // heading for the obstacle
+    poses(1, a) = 0.6 + 0.2 * a;
+    poses(2, a) = -0.2 + 0.05 * a;
+  }
+  int dwa_ticks = 0;
+  double worst = 0.0;
+  for (unsigned int t = 0; t < ticks; ++t) {
+    batch.setPoses(poses);
+    const mat u = batch.tick(grid, dwa, vb, 0.1, 0.5, 1);
+    const std::vector<int> src = batch.tickSources();
+    for (unsigned int a = 0; a < N; ++a) {
+      const vec x{ poses(0, a), poses(1, a), poses(2, a) }, v{ vb(0, a), vb(1, a), vb(2, a) };
+      const vec us = single[a].tick(grid, x, v, 0.1, 0.5);
+      CHECK(src[a] == static_cast<int>(single[a].source()));
+      for (int r = 0; r < 3; ++r) worst = std::max(worst, std::fabs(u(r, a) - us(r)));
+      dwa_ticks += src[a] != 0;
+    }
+    for (unsigned int a = 0; a < N; ++a) {
+      const vec x{ poses(0, a), poses(1, a), poses(2, a) }, ua{ u(0, a), u(1, a), u(2, a) };
+      const vec xn = integrate_twist(x, ua, 0.1);
+      for (int r = 0; r < 3; ++r) {
+        poses(r, a) = xn(r);
+        vb(r, a) = u(r, a);
+      }
+    }
+  }
+  CHECK(worst < 1e-6);
+  CHECK(dwa_ticks > 0);
+  std::printf("  AgentBatch::tick: %u agents x %u ticks, decisions equal to the single-robot loops, |u diff| %.2e, DWA ticks %d\n",
+              N, ticks, worst, dwa_ticks);
+}
+
 int main(int argc, char** argv)
 {
   const std::string mode = argc > 1 ? argv[1] : "cpu";
@@ -479,6 +542,7 @@ int main(int argc, char** argv)
     test_device_ops();
     test_ergodic_control();
     test_agent_batch();
+    test_agent_batch_tick();
   }
   std::printf("%s: %d checks, %d failures\n", mode.c_str(), g_checks, g_fail);
   return g_fail ? 1 : 0;
