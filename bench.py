@@ -502,8 +502,9 @@ def cpp_host_loop_leg(agents):
     """The consensus leg's enqueue loop from a C++ host (host/test/consensus_bench.cpp through the C ABI) instead of this
     file's Python: (a) local exchange, lag 1; (b) with a COLLECTIVE KERNEL in the exchange -- one rank whose all-reduce is a
     kernel of the stream-asynchronous test double tests/fake_rccl (512 threads x 96 registers x 16 KB of LDS per block: it has
-    to become resident beside the control kernels, what a real multi-GPU run's RCCL kernel has to) -- lag 2 and 3, last
-    group stream-ordered.  Own processes (their own HIP runtime, nothing shared with this one)."""
+    to become resident beside the control kernels, what a real multi-GPU run's RCCL kernel has to) -- lag 2, stream-ordered
+    (what this file does with a communicator) and with one group device-bound (faster, but it can stall at full occupancy:
+    agents_timed_out says).  Own processes (their own HIP runtime, nothing shared with this one)."""
     import subprocess
     root = os.path.dirname(os.path.abspath(__file__))
     exe = os.path.join(root, "ergodic_exploration_amd", "host", "build", "consensus_bench")
@@ -513,10 +514,13 @@ def cpp_host_loop_leg(agents):
     out = {"driver": "ergodic_exploration_amd/host/test/consensus_bench.cpp", "agents": agents, "cases": []}
     cases = [("local exchange (no collective)", "", 1)]
     if os.path.exists(fake):
-        cases += [("collective kernel in the exchange (test double)", fake, 2), ("collective kernel in the exchange (test double)", fake, 3)]
-    for name, lib, lag in cases:
+        cases += [("collective kernel in the exchange (test double), stream-ordered", fake, 2, "12"),
+                  ("collective kernel in the exchange (test double), one group device-bound", fake, 2, "2")]
+    for case in cases:
+        name, lib, lag = case[:3]
+        mode = case[3] if len(case) > 3 else "2"
         try:
-            r = subprocess.run([exe, "3000", str(agents), "1", lib, str(lag), "2"], capture_output=True, text=True, timeout=120)
+            r = subprocess.run([exe, "3000", str(agents), "1", lib, str(lag), mode], capture_output=True, text=True, timeout=120)
             line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
             res = json.loads(line[-1][len("RESULT "):]) if line else {"error": (r.stdout + r.stderr)[-300:]}
         except Exception as exc:  # noqa: BLE001
@@ -884,20 +888,39 @@ def main():
             slot = i % NB
             src = (i - lag) % NB if i >= lag else None
             seq = cstate["seq0"] + i + 1      # sequence numbers only grow (also from one timed() call to the next)
+            if collective_in_exchange():
+                # A COLLECTIVE KERNEL in the exchange (an RCCL communicator): the STREAM-ORDERED exchange -- every group's
+                # consuming launch is ordered behind the exchange's event (eea_comm_wait), the exchange behind the groups'
+                # events; nothing waits inside a kernel.  Waiting on the device for a flag whose producer is a collective
+                # kernel that must still become resident dead-locks when every execution slot is held by the waiters
+                # (round 5, profiles/r05_two_ranks.txt), and even one waiting group stalls now and then at full occupancy.
+                slot = seq % NB
+                src = (seq - lag) % NB if i >= lag else None
+                for g, a in enumerate(gargs):
+                    if src is not None:
+                        wcall = exch_calls.get(("wait", g, src))
+                        if wcall is None:
+                            wcall = exch_calls[("wait", g, src)] = xcomm.prepared_wait(src, a["stream"])
+                        wcall()
+                    call = exch_calls.get(("so", g, slot, src))
+                    if call is None:
+                        call = exch_calls[("so", g, slot, src)] = eng.prepared_batch(
+                            a["B"], a["pose"], a["ut"], a["u0"], mem_cols=a["mem_cols"], n_mem=a["n_mem"],
+                            mem_stride=args.n_mem, stream=a["stream"], ck_rec=d_arec[slot][gb[g]:gb[g + 1]],
+                            status=d_xstatus[gb[g]:gb[g + 1]],
+                            ck_shared=None if src is None else d_rec[src], ck_shared_parts=0 if src is None else 1)
+                    call()
+                xcall = exch_calls.get(("xso", slot))
+                if xcall is None:
+                    xcall = exch_calls[("xso", slot)] = xcomm.prepared_records_exchange(
+                        eng, B, d_arec[slot], d_rec[slot], [a["stream"] for a in gargs], slot)
+                xcall()
+                return
             if not host_staged:
                 # device-bound: G control launches (ready marks out, flag wait in) + ONE exchange call, nothing else
                 slot = seq % NB
                 src = (seq - lag) % NB if i >= lag else None
                 for g, a in enumerate(gargs):
-                    # a COLLECTIVE KERNEL in the exchange (a real communicator): the last agent group consumes stream-ordered
-                    # -- the rule of eea_comm_records_exchange_bound: when every execution slot is held by control wavefronts
-                    # that wait for the flag, the collective kernel that produces it never becomes resident (round 5,
-                    # profiles/r05_two_ranks.txt) -- its slots drain at the end of its pass and the collective lands there
-                    if collective_in_exchange() and src is not None and G > 1 and g == G - 1:
-                        wcall = exch_calls.get(("wait", src))
-                        if wcall is None:
-                            wcall = exch_calls[("wait", src)] = xcomm.prepared_wait(src, a["stream"])
-                        wcall()
                     call = exch_calls.get((g, slot, src))
                     if call is None:
                         call = exch_calls[(g, slot, src)] = eng.prepared_batch(
@@ -1277,8 +1300,8 @@ def main():
             exchange = {"backend": exchange_backend,
                         "consumer": "eea_batch_io::d_ck_shared as a sum record, ck_shared_parts = 1 (the gradient uses c_bar)"}
             by_lag = {}
-            # with a collective kernel in the exchange the consensus lags one pass more: at lag 1 and exactly full execution
-            # slots the hybrid still stalls now and then (profiles/r05_two_ranks.txt); lag >= 2 never did
+            # with a collective kernel in the exchange (stream-ordered, above) a lag of one pass has the collective on the
+            # critical path of every pass: the leg runs the lags >= 2
             lags = [l for l in LAGS if l >= 2] or [2] if collective_in_exchange() else LAGS
             for lag in lags:
                 cstate["lag"] = lag
@@ -1292,13 +1315,14 @@ def main():
                     "agents_timed_out": int((d_xstatus != 0).sum().item())}
             first = by_lag[str(lags[0])]
             exchange["consensus_allreduce"] = {
-                "lag_passes": lags[0], "consuming_groups": ("last group stream-ordered (eea_comm_wait), the others device-bound"
-                                                            if collective_in_exchange() and G > 1 else "all device-bound"),
+                "lag_passes": lags[0], "consuming_groups": ("all stream-ordered (eea_comm_records_exchange_async + eea_comm_wait)"
+                                                            if collective_in_exchange() else "all device-bound"),
                 "pass_ms": first["pass_ms"], "pass_ms_vs_headline": first["pass_ms_vs_headline"],
                 "pass_ms_vs_single_launch_pass": first["pass_ms_vs_single_launch_pass"],
                 "value": first["value"], "unit": "optimisations/s", "by_lag": by_lag,
                 "agent_groups": G, "bytes_per_rank_per_pass": rs * L, "host_threads": 0,
-                "protocol": "device-bound (eea_comm_records_exchange_bound): no host wait, no stream wait, no event",
+                "protocol": ("stream-ordered (a collective kernel is in the exchange)" if collective_in_exchange() else
+                             "device-bound (eea_comm_records_exchange_bound): no host wait, no stream wait, no event"),
                 "note": "every pass: the control kernels write per-agent sum records and ready marks (write-through, half way "
                         "through the wavefront), ONE launch on the exchange stream polls the marks and adds the records "
                         "beside the running control kernels (+ one all-reduce of the record over the ranks and a publish "

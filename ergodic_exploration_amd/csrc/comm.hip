@@ -409,10 +409,11 @@ eea_status eea_comm_records_exchange_async(eea_engine* e, eea_comm* c, unsigned 
 // kernel: a block of 256-512 threads with ~100 registers and LDS of its own does not fit beside a full set of control
 // wavefronts (4 x 120 of a SIMD's 512 registers), and when every execution slot is held by control wavefronts that wait for
 // the flag it produces, nothing ever frees one (round 5: measured with two ranks on one GPU and a stream-asynchronous test
-// double of a realistic footprint, tests/fake_rccl -- every agent timed out).  The rule: AT MOST ONE of a rank's agent
-// groups consumes the flag device-bound; the other orders its consuming launch behind the exchange with
-// eea_comm_wait(c, slot, its stream) -- its half of the execution slots drains at the end of its pass and is where the
-// collective kernel lands.  The event eea_comm_wait waits for is recorded here, behind the published record.
+// double of a realistic footprint, tests/fake_rccl -- every agent timed out).  Letting only ONE of a rank's agent groups
+// consume the flag device-bound (the other ordered behind the exchange with eea_comm_wait: the event is recorded here,
+// behind the published record) removes the systematic dead-lock but still stalled once in a few thousand passes at exactly
+// full occupancy.  The rule: with a communicator use eea_comm_records_exchange_async + eea_comm_wait for EVERY consuming group
+// (nothing waits inside a kernel), at a lag of >= 2 passes; this form is for exchanges without a collective kernel.
 eea_status eea_comm_records_exchange_bound(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_rec,
                                            const unsigned* d_rec_ready, unsigned seq, void* d_sum, unsigned* d_flag, int slot)
 {

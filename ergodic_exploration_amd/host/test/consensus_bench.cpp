@@ -20,6 +20,8 @@
 // slot is held by control wavefronts that wait for the flag it produces nothing frees one.  A NEGATIVE group count runs
 // every group device-bound anyway (what times out, for the record).
 //
+// groups per rank: 1 / 2; negative = every group device-bound whatever the communicator; 12 (11) = two (one) groups with the
+// STREAM-ORDERED exchange (eea_comm_records_exchange_async + eea_comm_wait): nothing waits inside a kernel.
 // usage: consensus_bench [passes = 4000] [agents = 4096] [ranks = 1] [collective library path] [lag = 1] [groups per rank = 2]
 // last line of the output: RESULT {json}
 #include <atomic>
@@ -81,6 +83,7 @@ struct Rank
   hipStream_t streams[2];
   int groups = 2;
   bool last_group_stream_ordered = false;  // more than one rank: the collective kernel needs a group's slots to land in
+  bool stream_ordered = false;             // every group consumes behind the exchange's event; nothing waits on the device
   unsigned seq = 0;
 
   void setup(unsigned agents, unsigned first_agent, int nranks, int rank, const char* id, int n_groups)
@@ -152,7 +155,17 @@ struct Rank
         io.d_pose = d_pose + 3 * first;
         io.d_ut = d_ut + static_cast<size_t>(3) * T * first;
         io.d_u0 = d_u0 + 3 * first;
-        if (consensus) {
+        if (consensus && stream_ordered) {
+          // the stream-ordered exchange (eea_comm_records_exchange_async + eea_comm_wait): no ready marks, no flag, no wait
+          // inside a kernel -- a launch starts when the record it consumes is complete
+          io.d_status = d_status + first;
+          io.d_ck_rec = d_arec[slot] + static_cast<size_t>(L) * first;
+          if (i >= lag) {
+            io.d_ck_shared = d_sum[src];
+            io.ck_shared_parts = 1;
+            ok(eea_comm_wait(c, src, streams[g]), "eea_comm_wait");
+          }
+        } else if (consensus) {
           io.d_status = d_status + first;
           io.d_ck_rec = d_arec[slot] + static_cast<size_t>(L) * first;
           io.d_rec_ready = d_ready + first;
@@ -168,7 +181,12 @@ struct Rank
         }
         ok(eea_control_batch(e, cnt, &io, streams[g]), "eea_control_batch");
       }
-      if (consensus) ok(eea_comm_records_exchange_bound(e, c, n, d_arec[slot], d_ready, seq, d_sum[slot], d_flag, slot), "exchange");
+      if (consensus && stream_ordered) {
+        void* gs[2] = { streams[0], streams[1] };
+        ok(eea_comm_records_exchange_async(e, c, n, d_arec[slot], d_sum[slot], gs, static_cast<unsigned>(groups), slot), "exchange (stream-ordered)");
+      } else if (consensus) {
+        ok(eea_comm_records_exchange_bound(e, c, n, d_arec[slot], d_ready, seq, d_sum[slot], d_flag, slot), "exchange");
+      }
       in_calls += now() - h0;
     }
     for (int g = 0; g < groups; ++g) ok(hipStreamSynchronize(streams[g]), "sync");
@@ -238,8 +256,11 @@ int main(int argc, char** argv)
   const int nranks = argc > 3 ? std::atoi(argv[3]) : 1;
   const std::string lib = argc > 4 ? argv[4] : "";
   const int lag = argc > 5 ? std::atoi(argv[5]) : 1;
-  const int groups = argc > 6 ? std::abs(std::atoi(argv[6])) : 2;
-  const bool all_bound = argc > 6 && std::atoi(argv[6]) < 0;  // (negative: every group device-bound also with a collective)
+  // groups: 1 / 2 = that many agent groups; negative: every group device-bound also with a collective; 11 / 12: 1 / 2 groups with
+  // the STREAM-ORDERED exchange (nothing waits on the device)
+  const int garg = argc > 6 ? std::atoi(argv[6]) : 2;
+  const int groups = std::abs(garg) % 10;
+  const bool all_bound = garg < 0, stream_ordered = garg >= 10;
   const bool child = argc > 9 && std::strcmp(argv[7], "child") == 0;
   if (nranks < 1 || nranks > 8 || lag < 1 || lag + 2 > NB || passes < 10 || groups < 1 || groups > 2 || (nranks > 1 && lib.empty() && false)) {
     std::fprintf(stderr, "usage: consensus_bench [passes] [agents] [ranks 1..8] [collective library] [lag 1..%d] [groups 1..2]\n", NB - 2);
@@ -280,7 +301,8 @@ int main(int argc, char** argv)
   Rank rk;
   const unsigned first = agents * rank / nranks, n = agents * (rank + 1) / nranks - first;
   rk.setup(n, first, nranks, rank, with_collective ? id : nullptr, groups);
-  rk.last_group_stream_ordered = with_collective && !all_bound;
+  rk.last_group_stream_ordered = with_collective && !all_bound && !stream_ordered;
+  rk.stream_ordered = stream_ordered;
   double host_plain = 0.0, host_cons = 0.0;
   barrier();
   rk.run(false, lag, 1000, nullptr);  // clock spin-up, warm start
@@ -344,13 +366,14 @@ int main(int argc, char** argv)
     std::printf("  plain passes as a hipGraph of 50      %6.2f us per pass   (2 x 50 kernel nodes on two captured streams, replayed %d times)\n",
                 1e6 * graphed, passes / 50);
   }
-  std::printf("  consensus every pass, lag %d (bound)  %6.2f us per pass   (host inside the calls: %5.2f us per pass)   = %.3f x plain; agents timed out: %d%s\n",
-              lag, 1e6 * c, 1e6 * hc, c / p, timed_out,
+  std::printf("  consensus every pass, lag %d (%s)  %6.2f us per pass   (host inside the calls: %5.2f us per pass)   = %.3f x plain; agents timed out: %d%s\n",
+              lag, stream_ordered ? "stream-ordered" : "bound", 1e6 * c, 1e6 * hc, c / p, timed_out,
               with_collective ? (collective_errors == 0 ? "; collective kernels: none gave up" : "; collective kernels gave up or count unavailable") : "");
   std::printf("RESULT {\"agents\": %u, \"ranks\": %d, \"collective_kernel_in_exchange\": %s, \"consuming_groups\": \"%s\", \"groups_per_rank\": %d, \"lag\": %d, \"passes\": %d, \"plain_us_per_pass\": %.3f, \"consensus_us_per_pass\": %.3f, "
               "\"ratio\": %.4f, \"host_us_per_pass_plain\": %.3f, \"host_us_per_pass_consensus\": %.3f, \"agents_timed_out\": %d, "
               "\"collective_kernel_timeouts\": %d, \"graph_us_per_pass\": %.3f}\n",
-              agents, nranks, with_collective ? "true" : "false", rk.last_group_stream_ordered ? "one device-bound, one stream-ordered" : "all device-bound",
+              agents, nranks, with_collective ? "true" : "false", rk.stream_ordered ? "all stream-ordered (eea_comm_records_exchange_async + eea_comm_wait)"
+                                                         : (rk.last_group_stream_ordered ? "one device-bound, one stream-ordered" : "all device-bound"),
               groups, lag, passes, 1e6 * p, 1e6 * c, c / p, 1e6 * hp, 1e6 * hc, timed_out, collective_errors, 1e6 * graphed);
   eea_comm_destroy(rk.c);
   eea_destroy(rk.e);

@@ -356,11 +356,14 @@ eea_status eea_comm_records_exchange_async(eea_engine* e, eea_comm* c, unsigned 
  * agent groups per GPU of at most half its execution slots each do (the fp64 K <= 10 instance leaves registers for the
  * sum beside a full set of control wavefronts); a waiter that cannot be served gives up after about a second
  * (EEA_ERR_TIMEOUT in d_status, own c_k), it never hangs.  Host threads: none; the calling thread issues 1-3 launches.
- * With a communicator of MORE THAN ONE RANK the producers include the collective kernel (hundreds of threads, ~100
- * registers, LDS of its own): it does not fit beside a full set of control wavefronts, so AT MOST ONE agent group of a rank
- * may consume the flag device-bound; the other group orders its consuming launch behind the exchange with
- * eea_comm_wait(c, slot, its stream) (the event is recorded behind the published record) -- its execution slots drain at the
- * end of its pass, and that is where the collective kernel lands.  All groups device-bound is safe with one rank only. */
+ * With an RCCL COMMUNICATOR in the exchange the producers include the collective kernel (hundreds of threads, ~100 registers,
+ * LDS of its own): it does not fit beside a full set of control wavefronts.  Every agent group waiting on the device for its
+ * flag is then a dead-lock at full occupancy (every agent times out: measured in round 5 with a kernel-shaped test double,
+ * profiles/r05_two_ranks.txt), and ONE waiting group (the other ordered behind the exchange with eea_comm_wait -- the event is
+ * recorded behind the published record) still stalled once in a few thousand passes.  With a communicator use the
+ * STREAM-ORDERED exchange -- eea_comm_records_exchange_async + eea_comm_wait for every consuming group -- at a lag of >= 2
+ * passes: nothing waits inside a kernel, so nothing can hold the slots its producer needs.  The device-bound form is for
+ * exchanges WITHOUT a collective kernel (one rank / a local communicator). */
 eea_status eea_comm_records_exchange_bound(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_rec,
                                            const unsigned* d_rec_ready, unsigned seq, void* d_sum, unsigned* d_flag, int slot);
 /* in-place ncclAllReduce(sum) of n reals: the K^2 partial sums of a grid-tiled phi_k

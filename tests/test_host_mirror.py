@@ -72,29 +72,30 @@ def test_two_ranks_on_one_gpu_through_the_rccl_test_double():
 
 
 @pytest.mark.gpu
-def test_device_bound_exchange_beside_a_collective_kernel():
-    """the device-bound consensus exchange with a COLLECTIVE KERNEL in it, free-running from a C++ host
+def test_consensus_exchange_beside_a_collective_kernel():
+    """the consensus exchange of every pass with a COLLECTIVE KERNEL in it, free-running from a C++ host
     loop (host/test/consensus_bench.cpp), in the production shape -- ONE process per GPU, 4096 agents as two agent groups,
     every execution slot of the GPU held by control wavefronts.  The all-reduce is a kernel of the stream-asynchronous test
     double (512 threads x 96 registers x 16 KB of LDS per block; RCCL's one-rank all-reduce may launch nothing at all): it
-    has to become resident beside the control kernels.  Protocol under test (include/ergodic_amd.h,
-    eea_comm_records_exchange_bound): lag 2, the last group consumes stream-ordered (eea_comm_wait), the other device-bound.
-    No agent and no collective kernel may give up (EEA_ERR_TIMEOUT / fake_rccl_errors); the pass costs <= 1.6 x the plain
-    pass of the same loop (measured 1.36 - 1.43; the host's 24 us per pass inside the calls is the limit).  All groups
-    device-bound at lag 1 -- round 4's form -- dead-locks here: profiles/r05_two_ranks.txt.
+    has to become resident beside the control kernels.  Round 5's findings (profiles/r05_two_ranks.txt):
+    every group waiting ON THE DEVICE for that collective's flag is a dead-lock at full occupancy, and one waiting group still
+    stalls now and then -- so with a communicator the exchange is STREAM-ORDERED (eea_comm_records_exchange_async +
+    eea_comm_wait: a launch starts when the record it consumes is complete; nothing waits inside a kernel), at lag 2.
+    Asserted here: that form never times out and no collective kernel gives up; the pass costs <= 2.2 x the plain pass of the
+    same loop (measured 1.7: the host's ~40 us of calls per pass are the limit, not the device).
     Semantics: decentralised ergodic control shares c_k (reference README.md:225-227)."""
     import json
     _build()
     fake = os.path.join(ROOT, "tests", "fake_rccl")
     subprocess.run(["make", "-s", "-C", fake], check=True)
     for lag in ("2", "3"):
-        out = subprocess.run([os.path.join(BUILD, "consensus_bench"), "1500", "4096", "1", os.path.join(fake, "librccl.so.1"), lag, "2"],
+        out = subprocess.run([os.path.join(BUILD, "consensus_bench"), "1500", "4096", "1", os.path.join(fake, "librccl.so.1"), lag, "12"],
                              capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
         res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
-        assert res["collective_kernel_in_exchange"] is True and res["consuming_groups"].startswith("one device-bound")
+        assert res["collective_kernel_in_exchange"] is True and res["consuming_groups"].startswith("all stream-ordered")
         assert res["agents_timed_out"] == 0 and res["collective_kernel_timeouts"] == 0, res
-        assert res["ratio"] <= 1.6, res
+        assert res["ratio"] <= 2.2, res
 
 
 @pytest.mark.gpu
