@@ -308,3 +308,36 @@ def test_automatic_choice_full_batches_against_oracle(model, K, horizon, B):
             assert np.abs(ut[b].T - st["ut"]).max() <= bar and np.abs(u0[b] - u).max() <= bar, (b, call)
         prev = ut
     eng.close()
+
+
+@pytest.mark.parametrize("L,steps,K", [(8, 20, 10), (16, 50, 10), (32, 50, 10), (8, 5, 5)])
+def test_packed_result_does_not_depend_on_the_position_in_the_batch(lanes, L, steps, K):
+    """The same agent (pose, warm start, replay memory) at different places of a batch -- another lane group of its
+    wavefront (another block of the matrix instructions), another wavefront, the ragged last wavefront -- gives bitwise the
+    same c_k, controls and u0: the blocks of v_mfma_f64_4x4x4_4b and the segments of the scans are independent, and
+    nothing an agent computes depends on its neighbours (size-independent property, as test_full_size_batch_properties
+    has it for the wavefront-per-agent kernel)."""
+    lanes(L)
+    A = 64 // L
+    B = 5 * A + 3
+    eng, _ = make_pair("omni", K, steps * 0.1, n_oracles=0)
+    assert eng.agent_lanes(B) == L
+    T, K2, n_mem = eng.T, eng.K2, 11
+    rng = np.random.default_rng(99)
+    poses = random_poses(rng, B)
+    ut0 = rng.uniform(-0.5, 0.5, (B, T, 3))
+    mem = random_poses(rng, B * n_mem).reshape(B, n_mem, 3)
+    twins = [0, 1, A - 1, A, 2 * A + 1, 5 * A, B - 1]   # every one a copy of agent 0
+    for t in twins[1:]:
+        poses[t], ut0[t], mem[t] = poses[0], ut0[0], mem[0]
+    d_ut, d_u0 = dev(ut0), torch.empty((B, 3), dtype=torch.float64, device="cuda")
+    d_ck = torch.empty((B, K2), dtype=torch.float64, device="cuda")
+    for _ in range(2):
+        eng.control_batch(B, dev(poses), d_ut, d_u0, mem_cols=dev(mem), n_mem=torch.full((B,), n_mem, dtype=torch.int32, device="cuda"),
+                          mem_stride=n_mem, ck=d_ck)
+    torch.cuda.synchronize()
+    ut, u0, ck = d_ut.cpu().numpy(), d_u0.cpu().numpy(), d_ck.cpu().numpy()
+    for t in twins[1:]:
+        assert np.array_equal(ut[t], ut[0]) and np.array_equal(u0[t], u0[0]) and np.array_equal(ck[t], ck[0]), t
+    assert (ck[:, 0] == 1.0).all()   # mode (0,0) of c_k is the mean of ones, exactly
+    eng.close()
