@@ -341,3 +341,22 @@ def test_packed_result_does_not_depend_on_the_position_in_the_batch(lanes, L, st
         assert np.array_equal(ut[t], ut[0]) and np.array_equal(u0[t], u0[0]) and np.array_equal(ck[t], ck[0]), t
     assert (ck[:, 0] == 1.0).all()   # mode (0,0) of c_k is the mean of ones, exactly
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_packed_random_shapes(lanes, seed):
+    """seeded random draws of (lanes per agent, horizon, model, K, batch size, replay memory, time step) inside the packed
+    kernel's domain, stage outputs on and off, against the oracle"""
+    rng = np.random.default_rng(1000 + seed)
+    L = int(rng.choice([8, 16, 32]))
+    lanes(L)
+    A = 64 // L
+    steps = int(rng.integers(2, 4 * L + 1))
+    model = "omni" if rng.uniform() < 0.5 else "simple_cart"
+    K = int(rng.choice([5, 10]))
+    B = int(rng.integers(1, 4 * A + 2))
+    n_mem = int(rng.choice([0, 0, 3, 17, 64]))
+    dt = float(rng.choice([0.1, 0.125, 0.05]))
+    _check_lanes(model, K, steps, dt, L, B) if dt == 0.125 else None
+    run_batch_vs_oracle(model, K, steps * dt + 1e-9 if dt != 0.125 else steps * dt, dt, B=B, n_mem=n_mem, calls=2, seed=seed,
+                        stages=bool(seed % 2))
