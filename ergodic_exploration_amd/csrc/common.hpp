@@ -74,6 +74,11 @@ struct ControlParams
   // n * pose_step_stride + b and writes u0 row n * u0_step_stride + b (strides in agents: 0 = the same row every step)
   int n_steps;
   unsigned pose_step_stride, u0_step_stride;
+  // resident single-robot wavefront (control_wave_impl.hpp, RESIDENT instances): the host-mapped mailbox (ResidentMail<R>),
+  // the request number it has seen already and the idle time (100 MHz ticks) after which it leaves; unused elsewhere
+  void* res_mail;
+  unsigned res_first;
+  long long res_idle;
 };
 
 template <typename R>
@@ -126,6 +131,10 @@ bool control_wave_eligible(const ControlParams<R>& p, bool rollout_only);
 template <typename R>
 hipError_t launch_control_wave(const ControlParams<R>& p, unsigned B, int model, bool rollout_only,
                                hipStream_t stream);
+// The wavefront kernel as a RESIDENT single-robot server (EEA_OPT_RESIDENT_CONTROL at horizons of one slot: fp64, T <= 64,
+// K <= 16): one wavefront that serves p.res_mail until told to leave or idle.  hipErrorInvalidValue: the shape has no instance
+bool control_wave_resident_eligible(const ControlParams<double>& p);
+hipError_t launch_control_wave_resident(const ControlParams<double>& p, int model, hipStream_t stream);
 // Several agents per wavefront (control_pack_impl.hpp): groups of 8 / 16 / 32 lanes per agent, fp64, K = 5 / 10,
 // T <= 4 lanes.  control_pack_lanes: the group size for a batch of B agents (0 = one wavefront per agent); forced = the
 // value of EEA_OPT_AGENT_LANES

@@ -257,7 +257,12 @@ namespace wave
 // per SIMD leave 32 registers free, room for the wavefronts of the record sum (control_kernel.hip) BESIDE a fully
 // resident control kernel.  (Rounds 3-4 needed a second, register-capped compilation of this text with two values parked
 // in LDS to get there; since the lane id and the launch arguments are re-derived per step it fits by itself.)
-template <typename R, int MODEL, int KC, bool STAGES, int WPB>
+//
+// RESIDENT (EEA_OPT_RESIDENT_CONTROL, horizons of one slot): the step loop never ends by itself -- every step is one request
+// from the host-mapped mailbox p.res_mail (ResidentMail<R>: the poll fetches the 64-byte request line, pose / map position /
+// column count come out of it by v_readlane, nothing of the request is read from memory again), u0 and the request's number go
+// back to the mailbox; the controls stay in LDS from request to request as between the steps of a multi-step launch.
+template <typename R, int MODEL, int KC, bool STAGES, int WPB, bool RESIDENT = false>
 __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void control_wave_kernel(
     const ControlParams<R> p_arg, const unsigned B, const int S_arg, const int rollout_arg)
 {
@@ -271,7 +276,9 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   // cost the body ~460 B of scratch per lane; recomputed they cost what they cost a launch.
   typedef const __attribute__((address_space(4))) ControlParams<R> KernArgParams;
   const int wave_of_block = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-  const int n_steps = ((KernArgParams*)__builtin_amdgcn_kernarg_segment_ptr())->n_steps;
+  const int n_steps = RESIDENT ? 0x7fffffff : ((KernArgParams*)__builtin_amdgcn_kernarg_segment_ptr())->n_steps;
+  unsigned res_last = RESIDENT ? ((KernArgParams*)__builtin_amdgcn_kernarg_segment_ptr())->res_first : 0u;  // request seen
+  bool res_handover = false;  // RESIDENT: a served request has left its controls in LDS
   // The controls a step leaves for the next one are handed over in LDS (the tiles and the park are dead between the
   // update and the next forward half): s_next[r][step index], read back one column to the right
   // (ergodic_control.hpp:233-234).  Reading them back from L2 put that latency at the head of every step of every wavefront
@@ -295,6 +302,69 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   // v_readlane every step; recomputed they are scalar compares)
   int S = S_arg, rollout_only = rollout_arg;
   asm volatile("" : "+s"(S), "+s"(rollout_only));
+  // RESIDENT: wait for the next request (lanes 0..15 fetch the request line, one dword each: one PCIe read that brings a new
+  // request number together with its data)
+  R res_pose[3] = { R(0), R(0), R(0) }, res_map_x = R(0), res_map_y = R(0);
+  int res_nmem = 0;
+  if constexpr (RESIDENT) {
+    using Mail = ResidentMail<R>;
+    constexpr int kReq = offsetof(Mail, req) / 4, kCmd = offsetof(Mail, cmd) / 4;
+    constexpr int kNmem = offsetof(Mail, n_mem) / 4, kMapX = offsetof(Mail, map_x) / 4;
+    Mail* const mail = static_cast<Mail*>(p.res_mail);
+    const unsigned* const line = reinterpret_cast<const unsigned*>(mail);
+    const long long t0 = wall_clock64();
+    unsigned v, r;
+    bool idle = false;
+    for (;;) {
+      v = __hip_atomic_load(line + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      r = __builtin_amdgcn_readlane(v, kReq);
+      if (r != res_last) break;
+      if (wall_clock64() - t0 > p.res_idle) {
+        idle = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    if (idle) {
+      // idle for too long: say so FIRST, then look once more -- a request posted before the host can have seen alive = 0 is
+      // still served, one posted later finds alive = 0 and launches again (engine.cpp control_resident)
+      if (lane == 0) __hip_atomic_store(&mail->alive, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __builtin_amdgcn_s_sleep(64);
+      v = __hip_atomic_load(line + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      r = __builtin_amdgcn_readlane(v, kReq);
+      if (r == res_last) return;
+    }
+    res_last = r;
+    if (__builtin_amdgcn_readlane(v, kCmd) != 0u) {  // told to leave
+      if (lane == 0) {
+        __hip_atomic_store(&mail->alive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&mail->done, static_cast<int>(r), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+    }
+    if constexpr (sizeof(R) == 8) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        res_pose[i] = static_cast<R>(__hiloint2double(static_cast<int>(__builtin_amdgcn_readlane(v, 2 * i + 1)),
+                                                      static_cast<int>(__builtin_amdgcn_readlane(v, 2 * i))));
+      }
+      res_map_x = static_cast<R>(__hiloint2double(static_cast<int>(__builtin_amdgcn_readlane(v, kMapX + 1)),
+                                                  static_cast<int>(__builtin_amdgcn_readlane(v, kMapX))));
+      res_map_y = static_cast<R>(__hiloint2double(static_cast<int>(__builtin_amdgcn_readlane(v, kMapX + 3)),
+                                                  static_cast<int>(__builtin_amdgcn_readlane(v, kMapX + 2))));
+    } else {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) res_pose[i] = static_cast<R>(__int_as_float(static_cast<int>(__builtin_amdgcn_readlane(v, i))));
+      res_map_x = static_cast<R>(__int_as_float(static_cast<int>(__builtin_amdgcn_readlane(v, kMapX))));
+      res_map_y = static_cast<R>(__int_as_float(static_cast<int>(__builtin_amdgcn_readlane(v, kMapX + 1))));
+    }
+    res_nmem = static_cast<int>(__builtin_amdgcn_readlane(v, kNmem));
+    // the replay-memory columns the host wrote for this request are behind this CU's L1 (an earlier request's loads left
+    // their cache lines there)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    if (step > (1 << 30)) step = 1;  // (the step index only tells the first request from the later ones)
+  }
+  const R map_x = RESIDENT ? res_map_x : p.map_x, map_y = RESIDENT ? res_map_y : p.map_y;
   const unsigned b = blockIdx.x * WPB + wv;
   if (b >= B) return;  // wavefront-uniform
   // eea_batch_io::d_skip (the fleet tick: a robot that follows a dynamic-window twist does not call control(),
@@ -354,7 +424,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   // ---- controls: shift left by one column, last column zero (ergodic_control.hpp:233-234) ------------
   R vx[kMaxS], vy[kMaxS], w[kMaxS];
   bool bad = false;
-  if (step == 0) {  // wavefront-uniform
+  if (RESIDENT ? !res_handover : step == 0) {  // wavefront-uniform
 #pragma unroll
     for (int j = 0; j < kMaxS; ++j) {
       vx[j] = vy[j] = w[j] = R(0);
@@ -385,7 +455,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
     }
     lds_fence();  // (read before the forward half writes the park and the tiles)
   }
-  const R x0 = pose[0], y0 = pose[1], th0 = pose[2];
+  const R x0 = RESIDENT ? res_pose[0] : pose[0], y0 = RESIDENT ? res_pose[1] : pose[1], th0 = RESIDENT ? res_pose[2] : pose[2];
   // record elements per lane of an agent's sum record (K^2 + 1 reals rounded up to even)
   constexpr int kRecRounds = (ck_record_len((KC == 16 ? 16 : KC) * (KC == 16 ? 16 : KC)) + kWave - 1) / kWave;
   if (__any(bad)) {
@@ -403,13 +473,15 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
     }
     if (lane == 0 && p.status != nullptr) p.status[b] = 2;  // EEA_ERR_INVALID_TWIST
     if (lane == 0 && p.done != nullptr && b == 0) {
-      __hip_atomic_store(p.done, p.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(p.done, RESIDENT ? static_cast<int>(res_last) : p.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    if constexpr (RESIDENT) continue;  // (nothing was written: the controls in ut / LDS are what they were)
     return;
   }
   // (a time-out of an earlier step of the launch stays; device-bound exchange: so does one an earlier PASS left in a reused
   // buffer, until the caller clears it)
-  if (lane == 0 && p.status != nullptr && step == 0 && !(p.ck_flag != nullptr && p.status[b] == 6)) p.status[b] = 0;
+  // (RESIDENT: the host clears the mailbox's status with the request)
+  if (!RESIDENT && lane == 0 && p.status != nullptr && step == 0 && !(p.ck_flag != nullptr && p.status[b] == 6)) p.status[b] = 0;
   EEA_WSTAMP(1);
 
   const R dt = p.dt, dt6 = p.dt6;
@@ -531,7 +603,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   for (int j = 0; j < kMaxS; ++j) {
     c1x[j] = s1x[j] = c1y[j] = s1y[j] = g0[j] = g1[j] = R(0);
     if (j < S) {
-      const R x = px[j] - p.map_x, y = py[j] - p.map_y;
+      const R x = px[j] - map_x, y = py[j] - map_y;
       if (j > 0 && fast_b) {  // wavefront-uniform
         R sd, cd;
         sincospi_small(incx[j] * p.inv_lx, &sd, &cd);
@@ -559,7 +631,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   // sampled past states are prepended (buffer.cpp:78-108) and shifted like the rollout
   int nmem = 0;
   if (p.mem_cols != nullptr) {
-    nmem = (p.n_mem != nullptr) ? p.n_mem[b] : static_cast<int>(p.mem_stride);
+    nmem = RESIDENT ? res_nmem : (p.n_mem != nullptr) ? p.n_mem[b] : static_cast<int>(p.mem_stride);
     nmem = nmem < 0 ? 0 : (nmem > static_cast<int>(p.mem_stride) ? static_cast<int>(p.mem_stride) : nmem);
   }
   const int N = T + nmem;
@@ -975,8 +1047,8 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
       const bool valid = q < nmem;
       R sa, ca = R(0), sb, cb = R(0);
       if (valid) {
-        sincospi_r((mem[3 * q + 0] - p.map_x) * p.inv_lx, &sa, &ca);
-        sincospi_r((mem[3 * q + 1] - p.map_y) * p.inv_ly, &sb, &cb);
+        sincospi_r((mem[3 * q + 0] - map_x) * p.inv_lx, &sa, &ca);
+        sincospi_r((mem[3 * q + 1] - map_y) * p.inv_ly, &sb, &cb);
       }
       const int nl = nmem - c0;  // > 0
       R cl, cu;
@@ -1642,8 +1714,9 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
         o[1] = u[1];
         o[2] = u[2];
         if (p.done != nullptr && b == 0) {
-          // the host polls this word instead of waiting for the kernel's completion signal
-          __hip_atomic_store(p.done, p.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          // the host polls this word instead of waiting for the kernel's completion signal (RESIDENT: the request's number,
+          // behind every store of the request -- they are all this wavefront's)
+          __hip_atomic_store(p.done, RESIDENT ? static_cast<int>(res_last) : p.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
       }
     }
@@ -1661,6 +1734,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
     lds_fence();
   }
   EEA_WSTAMP_RT(11);
+  if constexpr (RESIDENT) res_handover = true;
   }  // step
 }
 

@@ -65,6 +65,40 @@ hipError_t launch_control_wave(const ControlParams<R>& p, unsigned B, int model,
                 : launch_wave_k<R, kModelSimpleCart, false>(p, B, rollout_only, stream);
 }
 
+// ---- the resident single-robot wavefront (RESIDENT instances: fp64, one slot, K = 5 / 10 / any K <= 16) ---------------------
+namespace
+{
+template <int MODEL, int KC>
+hipError_t launch_resident_one(const ControlParams<double>& p, hipStream_t stream)
+{
+  const size_t lds = wave::wave_lds_elems(KC) * sizeof(double);
+  void (*kern)(const ControlParams<double>, const unsigned, const int, const int) =
+      wave::control_wave_kernel<double, MODEL, KC, false, 1, true>;
+  hipLaunchKernelGGL(kern, dim3(1), dim3(kWave), lds, stream, p, 1u, 1, 0);
+  return hipGetLastError();
+}
+template <int MODEL>
+hipError_t launch_resident_k(const ControlParams<double>& p, hipStream_t stream)
+{
+  switch (p.K) {
+    case 5:
+      return launch_resident_one<MODEL, 5>(p, stream);
+    case 10:
+      return launch_resident_one<MODEL, 10>(p, stream);
+    default:
+      return launch_resident_one<MODEL, 16>(p, stream);
+  }
+}
+}  // namespace
+
+bool control_wave_resident_eligible(const ControlParams<double>& p) { return p.T >= 1 && p.T <= kWave && p.K >= 1 && p.K <= 16; }
+
+hipError_t launch_control_wave_resident(const ControlParams<double>& p, int model, hipStream_t stream)
+{
+  if (!control_wave_resident_eligible(p) || p.res_mail == nullptr) return hipErrorInvalidValue;
+  return model == kModelOmni ? launch_resident_k<kModelOmni>(p, stream) : launch_resident_k<kModelSimpleCart>(p, stream);
+}
+
 template bool control_wave_eligible<double>(const ControlParams<double>&, bool);
 template bool control_wave_eligible<float>(const ControlParams<float>&, bool);
 template hipError_t launch_control_wave<double>(const ControlParams<double>&, unsigned, int, bool, hipStream_t);

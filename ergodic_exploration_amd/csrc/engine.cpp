@@ -152,6 +152,7 @@ struct eea_engine
   DevBuf d_rstage;             // ResidentStage: the request's pose / column count in device memory
   hipStream_t stream_res = nullptr;
   bool res_launched = false;   // a workgroup was launched and has not been seen to leave
+  bool res_one_wavefront = false;  // ... the one-wavefront form (horizons of one slot): its controls live in LDS between requests
   unsigned res_seq = 0;        // last request number
   unsigned long res_gen = 0;   // phik_gen it was launched with
 };
@@ -628,9 +629,11 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
   const int n_mem_max = rollout_only ? 0 : static_cast<int>(p.mem_stride);
   p.dbg = d_stamps;  // phase stamps: null in the product (only the A/B library's kernels read it, tools/ab/)
   // two kernels ship: one wavefront per agent (horizons <= 256 steps, K <= 16 or K = 20) and one workgroup per agent
-  // (everything else).  The single-agent entry (eea_control / eea_opt_traj: one agent, latency) keeps four
-  // wavefronts per agent; batches take the throughput kernel unless EEA_OPT_CONTROL_KERNEL says otherwise
-  const bool use_wave = eea::option(EEA_OPT_CONTROL_KERNEL) == 0 && e->mail_done == nullptr &&
+  // (everything else).  Batches take the throughput kernel unless EEA_OPT_CONTROL_KERNEL says otherwise.  The single-agent
+  // entry (eea_control: one agent, latency) takes it for horizons of one slot (T <= 64: one step per lane, no barrier --
+  // 3.0 / 4.9 / 4.3 us of device time at configs[0] / configs[1] / the yaml's T = 50 against 5.1 / 7.4 / 5.2 of the
+  // workgroup) and keeps four wavefronts per agent beyond (T = 200: 7.2 against 11.6 us; profiles/r05_one_agent_kernels.txt)
+  const bool use_wave = eea::option(EEA_OPT_CONTROL_KERNEL) == 0 && (e->mail_done == nullptr || p.T <= 64) &&
                         eea::control_wave_eligible<R>(p, rollout_only);
   p.ck_rec = rollout_only ? nullptr : static_cast<R*>(io->d_ck_rec);
   if (use_wave) {
@@ -782,13 +785,29 @@ eea_status resident_start(eea_engine* e)
   p.mem_cols = static_cast<const R*>(e->d_rmem);
   p.mem_stride = static_cast<unsigned>(eea::kResidentMemCols);
   p.rec_len = eea::ck_record_len(e->K2);
+  // horizons of one slot: ONE wavefront (the kernel the launch path takes at these shapes, control_batch_impl), otherwise the
+  // workgroup
+  bool one_wavefront = false;
+  if constexpr (sizeof(R) == 8) one_wavefront = eea::option(EEA_OPT_CONTROL_KERNEL) == 0 && eea::control_wave_resident_eligible(p);
   const size_t lds = eea::control_lds_bytes<R>(p.T, p.K, eea::kResidentMemCols, p.chunk);
-  if (lds > 160 * 1024) return EEA_ERR_UNSUPPORTED;  // (no message: the caller takes the launch path)
+  if (!one_wavefront && lds > 160 * 1024) return EEA_ERR_UNSUPPORTED;  // (no message: the caller takes the launch path)
   hm->alive = 1;
   hm->cmd = 0;
   __atomic_thread_fence(__ATOMIC_SEQ_CST);
-  EEA_HIP(eea::launch_control_resident<R>(p, e->cfg.model, eea::kResidentMemCols, e->d_rmail, e->d_rstage.p, e->res_seq,
-                                          kResidentIdleTicks, e->stream_res));
+  if constexpr (sizeof(R) == 8) {
+    if (one_wavefront) {
+      p.done = &dm->done;
+      p.res_mail = e->d_rmail;
+      p.res_first = e->res_seq;
+      p.res_idle = kResidentIdleTicks;
+      EEA_HIP(eea::launch_control_wave_resident(p, e->cfg.model, e->stream_res));
+    }
+  }
+  if (!one_wavefront) {
+    EEA_HIP(eea::launch_control_resident<R>(p, e->cfg.model, eea::kResidentMemCols, e->d_rmail, e->d_rstage.p, e->res_seq,
+                                            kResidentIdleTicks, e->stream_res));
+  }
+  e->res_one_wavefront = one_wavefront;
   e->res_launched = true;
   e->res_gen = e->phik_gen;
   return EEA_OK;
@@ -1476,6 +1495,10 @@ eea_status eea_set_ut(eea_engine* e, const double* h_ut)
   eea_status st = use_device(e);
   if (st != EEA_OK) return st;
   const size_t n = 3 * static_cast<size_t>(e->T);
+  if (e->res_launched && e->res_one_wavefront) {  // its warm start is in LDS: the next call starts another one from d_ut1
+    st = resident_stop(e);
+    if (st != EEA_OK) return st;
+  }
   EEA_HIP(hipStreamSynchronize(e->stream1));
   if (e->f32) {
     std::vector<float> tmp(n);

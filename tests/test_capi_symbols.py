@@ -128,8 +128,9 @@ def test_timed_control_instances_leave_room_for_the_record_sum():
     seen = 0
     for name, k in wave.items():
         if "control_wave_kernel<double, " in name and (", 10, " in name or ", 5, " in name):
-            assert int(k["vgpr_count"]) <= 120 and int(k["private_segment_fixed_size"]) == 0, (name, k)
-            seen += 1
-    assert seen == 8   # 2 models x K in {5, 10} x stage outputs on / off
+            resident = ", true>(" in name   # the resident single-robot wavefront: alone on its SIMD, no register bar
+            assert (resident or int(k["vgpr_count"]) <= 120) and int(k["private_segment_fixed_size"]) == 0, (name, k)
+            seen += 1 if not resident else 100
+    assert seen == 408   # 2 models x K in {5, 10} x stage outputs on / off, + 2 x 2 resident instances
     sums = [k for n, k in demangled(os.path.join(build, "control_kernel.o")).items() if "ck_records_sum_kernel" in n]
     assert len(sums) == 2 and all(int(k["vgpr_count"]) <= 32 and int(k["group_segment_fixed_size"]) == 0 for k in sums), sums

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--agents", type=int, default=24576)
     ap.add_argument("--spl", type=int, default=1)
     ap.add_argument("--launches", type=int, default=10)
+    ap.add_argument("--workgroup", action="store_true", help="the workgroup-per-agent kernel (EEA_OPT_CONTROL_KERNEL = 1)")
     ap.add_argument("--steps", type=int, default=0, help="horizon steps (overrides the shape's horizon; dt = 0.125)")
     a = ap.parse_args()
     sh = dict(SHAPES[a.shape])
@@ -36,7 +37,10 @@ def main():
     eng.config_domain(MAP_BOUNDS)
     capi.set_option(capi.OPT_AGENT_LANES, a.lanes)
     B, T = a.agents, eng.T
-    assert eng.agent_lanes(B) == a.lanes, eng.agent_lanes(B)
+    if a.workgroup:
+        capi.set_option(capi.OPT_CONTROL_KERNEL, 1)
+    else:
+        assert eng.agent_lanes(B) == a.lanes, eng.agent_lanes(B)
     rng = np.random.default_rng(777)
     b = MAP_BOUNDS
     poses = np.stack([rng.uniform(0.5, 11.5, B) + b[0], rng.uniform(0.5, 5.5, B) + b[2], rng.uniform(-np.pi, np.pi, B)], 1)
