@@ -78,7 +78,7 @@ def main():
     text = open(os.path.join(csrc, "control_wave_impl.hpp")).read()
     subs = [("  int S = S_arg, rollout_only = rollout_arg;\n  asm volatile(\"\" : \"+s\"(S), \"+s\"(rollout_only));\n",
              "  constexpr int S = %d;\n  constexpr int rollout_only = 0;\n" % ((TC + 63) // 64)),
-            ("  const int n_steps = ((KernArgParams*)__builtin_amdgcn_kernarg_segment_ptr())->n_steps;\n",
+            ("  const int n_steps = RESIDENT ? 0x7fffffff : ((KernArgParams*)__builtin_amdgcn_kernarg_segment_ptr())->n_steps;\n",
              "  constexpr int n_steps = 1;\n"),
             ("  KernArgParams* ka = (KernArgParams*)__builtin_amdgcn_kernarg_segment_ptr();  // p_arg is argument 0\n"
              "  asm volatile(\"\" : \"+s\"(ka));\n  KernArgParams& p = *ka;\n",
@@ -94,7 +94,7 @@ def main():
         f.write(text)
     unit = os.path.join(tmp, "budget_unit.hip")
     with open(unit, "w") as f:
-        f.write('#include "budget_impl.hpp"\nnamespace eea {\ntemplate __global__ void wave::%s<%s, %d, %d, false, %d>('
+        f.write('#include "budget_impl.hpp"\nnamespace eea {\ntemplate __global__ void wave::%s<%s, %d, %d, false, %d, false>('
                 "const ControlParams<%s>, const unsigned, const int, const int);\n}\n"
                 % ("control_wave_kernel", real, model, KC, wpb, real))
     cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-Wno-unused-function", "-fno-slp-vectorize",
