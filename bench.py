@@ -1181,8 +1181,8 @@ def main():
                 out["single_robot_tick"] = {
                     "note": "the reference's own use: ONE robot, one control() per tick (exploration.hpp:232) -- dependent "
                             "eea_control calls at every BASELINE shape, wall time per call incl. the host round trip; "
-                            "gpu_us_per_call_resident: served by the resident workgroup (EEA_OPT_RESIDENT_CONTROL: a host-mapped "
-                            "mailbox instead of a launch per call); cpp_host: the same calls from a C++ loop; "
+                            "gpu_us_per_call_resident: served by the resident server (EEA_OPT_RESIDENT_CONTROL: one wavefront at horizons "
+                            "<= 64 steps, a workgroup beyond; a host-mapped mailbox instead of a launch per call); cpp_host: the same calls from a C++ loop; "
                             "cpu_port_us_per_call = the oracle's control() at the same shape, 1 thread, this host",
                     "cases": single_robot_ticks(torch, capi, np),
                     "cpp_host": cpp_tick_latency()}
