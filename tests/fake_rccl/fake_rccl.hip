@@ -32,6 +32,7 @@
 #include <atomic>
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <mutex>
@@ -88,19 +89,24 @@ __device__ __forceinline__ T ld_agent(const T* q) { return __hip_atomic_load(q, 
 template <typename T>
 __device__ __forceinline__ void st_agent(T* q, T v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-template <typename T>
-__global__ __launch_bounds__(512) void fake_collective_kernel(unsigned* arrived, unsigned char* stage, int* err, int nranks, int rank,
-                                                              unsigned op, const T* send, T* recv, size_t count, int gather)
+// BIG: the footprint of a real collective kernel (512 threads, 96 registers, 16 KB of LDS: it needs two free wavefront slots on
+// every SIMD of ONE compute unit at the same moment).  FAKE_RCCL_SMALL=1 launches the same protocol as one wavefront with a
+// minimal footprint -- the A/B that tells resource starvation from protocol errors.
+template <typename T, bool BIG>
+__global__ __launch_bounds__(BIG ? 512 : 64) void fake_collective_kernel(unsigned* arrived, unsigned char* stage, int* err, int nranks,
+                                                                         int rank, unsigned op, const T* send, T* recv, size_t count,
+                                                                         int gather)
 {
-  __shared__ double s_pad[2048];  // 16 KB: the LDS footprint of a collective kernel's staging FIFOs
+  constexpr unsigned NT = BIG ? 512u : 64u;
+  __shared__ double s_pad[BIG ? 2048 : 64];  // 16 KB: the LDS footprint of a collective kernel's staging FIFOs
   __shared__ int s_ok;
-  asm volatile("" ::: "v95");     // ... and its registers: the allocation is 96 vector registers per lane
+  if constexpr (BIG) asm volatile("" ::: "v95");  // ... and its registers: the allocation is 96 vector registers per lane
   const unsigned tid = threadIdx.x, blk = blockIdx.x, nb = gridDim.x;
   const unsigned slot = op % kRing, tag = op + 1u;
-  for (unsigned i = tid; i < 2048; i += 512) s_pad[i] = static_cast<double>(i);  // (keeps the array)
+  for (unsigned i = tid; i < (BIG ? 2048u : 64u); i += NT) s_pad[i] = static_cast<double>(i);  // (keeps the array)
   const size_t per = (count + nb - 1) / nb, lo = blk * per, hi = (lo + per < count) ? lo + per : count;
   T* const mine = reinterpret_cast<T*>(stage + (static_cast<size_t>(slot) * nranks + rank) * kMaxBytes);
-  for (size_t i = lo + tid; i < hi; i += 512) st_agent(mine + i, send[i]);
+  for (size_t i = lo + tid; i < hi; i += NT) st_agent(mine + i, send[i]);
   __threadfence();
   __syncthreads();
   if (tid == 0) {
@@ -125,10 +131,10 @@ __global__ __launch_bounds__(512) void fake_collective_kernel(unsigned* arrived,
   if (gather) {
     for (int r = 0; r < nranks; ++r) {
       const T* const src = reinterpret_cast<const T*>(stage + (static_cast<size_t>(slot) * nranks + r) * kMaxBytes);
-      for (size_t i = lo + tid; i < hi; i += 512) recv[static_cast<size_t>(r) * count + i] = ld_agent(src + i);
+      for (size_t i = lo + tid; i < hi; i += NT) recv[static_cast<size_t>(r) * count + i] = ld_agent(src + i);
     }
   } else {
-    for (size_t i = lo + tid; i < hi; i += 512) {
+    for (size_t i = lo + tid; i < hi; i += NT) {
       T acc = ld_agent(reinterpret_cast<const T*>(stage + static_cast<size_t>(slot) * nranks * kMaxBytes) + i);
       for (int r = 1; r < nranks; ++r) {
         acc += ld_agent(reinterpret_cast<const T*>(stage + (static_cast<size_t>(slot) * nranks + r) * kMaxBytes) + i);
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(512) void fake_collective_kernel(unsigned* arrived,
       recv[i] = acc;
     }
   }
-  if (s_pad[(tid * 7) & 2047] < 0.0) recv[0] = T(0);  // (never true: the array holds its indices)
+  if (s_pad[(tid * 7) & (BIG ? 2047 : 63)] < 0.0) recv[0] = T(0);  // (never true: the array holds its indices)
 }
 
 ncclResult_t enqueue(ncclComm_t comm, const void* send, void* recv, size_t count, ncclDataType_t type, int gather, hipStream_t stream)
@@ -146,13 +152,21 @@ ncclResult_t enqueue(ncclComm_t comm, const void* send, void* recv, size_t count
   FakeGroup* const g = comm->group;
   const unsigned op = comm->next_op++;
   const unsigned nb = count * ts > (size_t(32) << 10) ? kMaxBlocks : 1u;
+  static const bool small = [] {
+    const char* const v = std::getenv("FAKE_RCCL_SMALL");
+    return v != nullptr && v[0] != '0';
+  }();
+#define FAKE_LAUNCH(T, BIG)                                                                                                        \
+  hipLaunchKernelGGL((fake_collective_kernel<T, BIG>), dim3(nb), dim3(BIG ? 512 : 64), 0, stream, g->d_arrived, g->d_stage, g->d_err, \
+                     g->nranks, comm->rank, op, static_cast<const T*>(send), static_cast<T*>(recv), count, gather)
   if (ts == 8) {
-    hipLaunchKernelGGL(fake_collective_kernel<double>, dim3(nb), dim3(512), 0, stream, g->d_arrived, g->d_stage, g->d_err, g->nranks,
-                       comm->rank, op, static_cast<const double*>(send), static_cast<double*>(recv), count, gather);
+    if (small) FAKE_LAUNCH(double, false);
+    else FAKE_LAUNCH(double, true);
   } else {
-    hipLaunchKernelGGL(fake_collective_kernel<float>, dim3(nb), dim3(512), 0, stream, g->d_arrived, g->d_stage, g->d_err, g->nranks,
-                       comm->rank, op, static_cast<const float*>(send), static_cast<float*>(recv), count, gather);
+    if (small) FAKE_LAUNCH(float, false);
+    else FAKE_LAUNCH(float, true);
   }
+#undef FAKE_LAUNCH
   return hipGetLastError() == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
 }
 }  // namespace
