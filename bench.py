@@ -827,10 +827,26 @@ def main():
             return
         if args.no_exchange:
             return
+        double = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "fake_rccl", "librccl.so.1")
+        via_double = False
         if backend != "nccl":
-            exchange_backend = "gloo, staged through the host (ranks share a GPU: plumbing run)"
-            host_staged = True
-            return
+            # ranks share a GPU (RCCL refuses two ranks on one device): the C ABI's exchange steps through the test double of
+            # RCCL -- collective KERNELS that meet on the device, the ranks are processes -- when it is there; else the
+            # collectives go over gloo, staged through the host (plumbing run either way: the GPU is shared)
+            have = torch.tensor([1 if os.path.exists(double) else 0], dtype=torch.int32)
+            dist.all_reduce(have, op=dist.ReduceOp.MIN)
+            if int(have.item()):
+                try:
+                    capi.comm_set_library(double)
+                    via_double = True
+                except Exception as exc:  # noqa: BLE001
+                    sys.stderr.write("rank %d: eea_comm_set_library failed (%r)\n" % (rank, exc))
+            ok_lib = torch.tensor([1 if via_double else 0], dtype=torch.int32)
+            dist.all_reduce(ok_lib, op=dist.ReduceOp.MIN)
+            if not int(ok_lib.item()):
+                exchange_backend = "gloo, staged through the host (ranks share a GPU: plumbing run)"
+                host_staged = True
+                return
         # the C ABI's own RCCL communicator: rank 0 creates the id, torch.distributed only carries it.  If that fails on
         # some rank, every rank falls back to torch.distributed's collectives (the run must not die with a secondary leg)
         ok = 1
@@ -851,13 +867,16 @@ def main():
         flag = torch.tensor([ok], dtype=torch.int32)  # host tensor: gloo
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()):
-            exchange_backend = "rccl through the C ABI (eea_comm_*)"
+            exchange_backend = ("the RCCL test double (tests/fake_rccl: collective kernels that meet on the device) through the C "
+                                "ABI (eea_comm_*); the ranks share a GPU: plumbing run" if via_double
+                                else "rccl through the C ABI (eea_comm_*)")
             xcomm = comm
         else:
             if comm is not None:
                 comm.close()
             comm = None
-            exchange_backend = "rccl through torch.distributed, staged (eea_comm_create failed)"
+            exchange_backend = ("gloo, staged through the host (ranks share a GPU; eea_comm_create through the test double failed)"
+                                if via_double else "rccl through torch.distributed, staged (eea_comm_create failed)")
             host_staged = True
 
     state = {"i": 0}

@@ -144,6 +144,8 @@ def lib():
         if hasattr(L, "eea_debug_phase_timing"):  # A/B library only (EEA_LIB_VARIANT=_ab, tools/ab/)
             L.eea_debug_phase_timing.argtypes = [C.c_void_p, C.c_uint, C.POINTER(BatchIO), C.c_void_p, C.c_void_p]
         L.eea_comm_get_unique_id.argtypes = [C.c_void_p]
+        L.eea_comm_set_library.argtypes = [C.c_char_p]
+        L.eea_comm_set_library.restype = C.c_int
         L.eea_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]
         L.eea_comm_destroy.argtypes = [C.c_void_p]
         L.eea_comm_destroy.restype = None
@@ -532,6 +534,11 @@ def get_option(option):
 
 
 COMM_ID_BYTES = 128
+
+
+def comm_set_library(path):
+    """binds the collectives to the RCCL at `path` (process-wide, before the first other comm call): eea_comm_set_library"""
+    check(lib().eea_comm_set_library(os.fsencode(path)))
 
 
 def comm_unique_id():

@@ -302,7 +302,7 @@ eea_status eea_rollout_batch(eea_engine* e, unsigned B, const void* d_pose, cons
 typedef struct eea_comm eea_comm;
 /* Binds the collectives to the RCCL at `path` (dlopen, own symbol scope) instead of the one already mapped into the process
  * or the default librccl.so -- for deployments that carry several RCCL builds; the one-GPU tests and bench.py point it at the
- * test double tests/fake_rccl/librccl.so.1 to run several ranks as threads on one device.  Process-wide, before the first
+ * test double tests/fake_rccl/librccl.so.1 to run several ranks (processes) on one device.  Process-wide, before the first
  * other eea_comm_* call (EEA_ERR_UNSUPPORTED once the library is bound). */
 eea_status eea_comm_set_library(const char* path);
 eea_status eea_comm_get_unique_id(void* id);

@@ -695,7 +695,7 @@ def test_prepared_batch_is_the_same_call():
 def test_bench_self_launches_its_ranks(extra):
     """`python bench.py --gpus 2` exactly as the driver would type it for N > 1 without a launcher: the
     parent makes no GPU call and starts the two ranks itself; on this 1-GPU box the ranks share the device
-    (gloo rendezvous, host-staged exchange).  One JSON line, n_gpus = 2, rc 0."""
+    (gloo rendezvous; the exchange steps through the C ABI and the RCCL test double).  One JSON line, n_gpus = 2, rc 0."""
     env = dict(os.environ)
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
@@ -713,6 +713,14 @@ def test_bench_self_launches_its_ranks(extra):
     else:
         assert rec["exchange"]["consensus_allreduce"]["value"] > 0
         assert rec["exchange"]["allgather_ck"]["value"] > 0
+        # the ranks share the GPU, so the exchange steps go through the C ABI and the test double of
+        # RCCL (collective kernels that meet on the device) -- not through gloo staged over the host -- and, with a collective
+        # kernel in the exchange, every consuming group is stream-ordered: no agent times out
+        assert "test double" in rec["exchange"]["backend"], rec["exchange"]["backend"]
+        ca = rec["exchange"]["consensus_allreduce"]
+        assert "stream-ordered" in ca["consuming_groups"] and min(int(k) for k in ca["by_lag"]) >= 2
+        assert all(v["agents_timed_out"] == 0 for v in ca["by_lag"].values()), ca["by_lag"]
+        assert "test double" in rec["grid_tile"]["collective"]
         # BASELINE config 5 shard: the 1024 rows tiled over the two ranks, one all-reduce, phi_k installed on the device
         gt = rec["grid_tile"]
         assert gt["rows_per_rank"] == 512 and abs(gt["phik_00_check"] - 1.0) < 1e-12 and gt["us_per_rebuild_back_to_back"] > 0
