@@ -16,6 +16,9 @@
 //     32..63: conflict-free ds_read_b64), only the point -> tile row map differs; one accumulator set per half;
 //   * D = lambda (c - phi) per agent in LDS, agents 2 K^2 dwords apart (K = 10: 8 banks: the A row reads of a gradient
 //     step -- every lane of an agent the same address -- are conflict-free);
+//   * top-heavy horizons (T = 3 L + 1 .. 3 L + L / 8: the yaml's T = 50 on 16 lanes): the first r lanes of an agent own four
+//     steps, the others three, and the gradient of the r-step tail slot is taken by all lanes together, 8 lanes per step
+//     (control_wave_kernel's cooperative tail with the 8-lane groups inside the agents): 0.292 -> 0.314 at T = 50;
 //   * compiled for 3 wavefronts per SIMD (168 registers): the barrier gradient stays in registers, the LDS holds the
 //     tiles / the A agents' D and the parked headings (<= 10.8 KB per wavefront, 12 wavefronts per CU).
 //
@@ -35,9 +38,10 @@ using wave::lds_fence;
 using wave::tab_stride;
 
 __host__ __device__ constexpr int d_stride(int K) { return (K * K + 3) & ~3; }  // K = 10: 100 (200 dwords = 8 mod 64), K = 5: 28
+constexpr int kTailElems = 24;  // hand-over space of the cooperative tail gradient, behind the agents' D: [3][8] reals
 __host__ __device__ constexpr int region_elems(int K, int A)
 {
-  const int t = 2 * kStageRows * tab_stride(K), d = A * d_stride(K);
+  const int t = 2 * kStageRows * tab_stride(K), d = A * d_stride(K) + kTailElems;
   return ((t > d ? t : d) + 3) & ~3;
 }
 // the parked post-step headings: cos and sin, [S][64] each.  S is a launch argument: a horizon of <= 3 steps per lane leaves
@@ -177,11 +181,16 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_k
   R* const s_sp = s_cp + S * kWave;          // sin
   R* const s_D = tabx;                       // D of agent a at a * DS (after the contraction)
 
-  // lane -> horizon steps of its agent: S consecutive steps from S * tl
-  const int i0 = S * tl;
-  const int cnt = max(0, min(S, T - i0));
+  // lane -> horizon steps of its agent: S consecutive steps from S * tl.  Top-heavy horizons -- T = L (S - 1) + r with
+  // r <= L / 8 at S = 4 (the yaml's T = 50 on 16 lanes: 3 x 16 + 2) -- as in control_wave_kernel: the first r lanes own S
+  // steps, all others S - 1; the last slot then holds r steps per agent, whose gradient all lanes take together (8 lanes per
+  // step, below) instead of a full pass at r / L of the lanes
+  const int r_top = T - L * (S - 1);
+  const bool top_heavy = S == kMaxS && r_top >= 1 && r_top <= L / 8;  // wavefront-uniform
+  const int i0 = top_heavy ? (tl < r_top ? S * tl : S * r_top + (S - 1) * (tl - r_top)) : S * tl;
+  const int cnt = top_heavy ? (tl < r_top ? S : S - 1) : max(0, min(S, T - i0));
   // lanes of an agent that own a step in slot j
-  auto lanes_in_slot = [&](int j) { return min(L, max(0, (T - j + S - 1) / S)); };
+  auto lanes_in_slot = [&](int j) { return top_heavy ? (j < S - 1 ? L : r_top) : min(L, max(0, (T - j + S - 1) / S)); };
   R* const ut = p.ut + 3 * static_cast<size_t>(T) * b;
   const R* const pose = p.pose + 3 * (static_cast<size_t>(step) * p.pose_step_stride + b);
   // ---- controls: shift left by one column, last column zero (ergodic_control.hpp:233-234) ------------
@@ -589,7 +598,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_k
     if (STAGES) ex[j] = ey[j] = R(0);
     asm volatile("" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
-    if (j < S) {
+    if (j < S && !(j == kMaxS - 1 && top_heavy)) {
       R accx = R(0), accy = R(0);
       const R twox = c1x[j] + c1x[j], twoy = c1y[j] + c1y[j];
       R cxa[K], G[K];
@@ -647,6 +656,109 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_k
         g0[j] = act ? exj + g0[j] : R(0);
         g1[j] = act ? eyj + g1[j] : R(0);
       }
+    }
+  }
+  if (top_heavy) {  // wavefront-uniform
+    // The tail slot, all lanes together (control_wave_kernel's cooperative tail with BLOCK <-> AGENT): lane l = 8 st + sub
+    // works on tail step e = (l % L) / 8 of ITS OWN agent -- the step of that agent's lane e --, rows k2 = sub and sub + 8 of
+    // that agent's D:
+    //   edx_x = -pi/lx sin(a) sum_k2 cos(k2 b) Bx(k2),   Bx(k2) = sum_k1 D(k2,k1) k1 U_{k1-1}(cos a)
+    //   edx_y = -pi/ly        sum_k2 k2 sin(k2 b) A(k2),  A(k2)  = sum_k1 D(k2,k1) cos(k1 a)
+    // (the same sums as above in another order).  Nothing crosses an agent: the 8 lanes of a step are lanes of its agent.
+    constexpr int jt = kMaxS - 1;
+    constexpr int E = L / 8;  // tail steps per agent at most
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    const int st = lane >> 3, sub = lane & 7;
+    R* const s_tail = s_D + A * DS;  // [3][8]
+    const int own = al * E + (tl & (E - 1));  // the hand-over slot of this lane's own tail step (lanes tl < E)
+    if (tl < E) {
+      s_tail[own] = c1x[jt];
+      s_tail[8 + own] = c1y[jt];
+      s_tail[16 + own] = s1y[jt];
+    }
+    lds_fence();
+    const R cxs = s_tail[st], cys = s_tail[8 + st], sys = s_tail[16 + st];
+    lds_fence();  // (the hand-over space is written again below)
+    R cxa[K], kux[K];  // cos(k1 a), k1 U_{k1-1}(cos a)
+    {
+      const R two = cxs + cxs;
+      R ta = R(1), tb = cxs, ua = R(0), ub = R(1);
+#pragma unroll
+      for (int k1 = 0; k1 < K; ++k1) {
+        cxa[k1] = ta;
+        kux[k1] = static_cast<R>(k1) * ua;
+        const R tn = two * tb - ta, un = two * ub - ua;
+        ta = tb;
+        tb = tn;
+        ua = ub;
+        ub = un;
+      }
+    }
+    // (cos, sin)(k2 b) for k2 = sub by binary powering of z = (cos b, sin b): z^sub = z^(bit 0) z2^(bit 1) z4^(bit 2)
+    const R z2c = cys * cys - sys * sys, z2s = (cys + cys) * sys;
+    const R z4c = z2c * z2c - z2s * z2s, z4s = (z2c + z2c) * z2s;
+    R wc = (sub & 1) ? cys : R(1), ws = (sub & 1) ? sys : R(0);
+    {
+      const R mc = (sub & 2) ? z2c : R(1), ms = (sub & 2) ? z2s : R(0);
+      const R nc = wc * mc - ws * ms, ns = wc * ms + ws * mc;
+      wc = nc;
+      ws = ns;
+    }
+    {
+      const R mc = (sub & 4) ? z4c : R(1), ms = (sub & 4) ? z4s : R(0);
+      const R nc = wc * mc - ws * ms, ns = wc * ms + ws * mc;
+      wc = nc;
+      ws = ns;
+    }
+    R tpx = R(0), tpy = R(0);
+    auto tail_row = [&](int k2, R cyv, R ksv) {  // k2 < K; cyv = cos(k2 b), ksv = k2 sin(k2 b) (both 0: row not taken)
+      const R* const row = Da + k2 * K;
+      R a0 = R(0), a1 = R(0), b0 = R(0), b1 = R(0);
+#pragma unroll
+      for (int k1 = 0; k1 < K; ++k1) {
+        const R d = row[k1];
+        if (k1 & 1) {
+          a1 += d * cxa[k1];
+          b1 += d * kux[k1];
+        } else {
+          a0 += d * cxa[k1];
+          if (k1 > 0) b0 += d * kux[k1];
+        }
+      }
+      tpx += cyv * (b0 + b1);
+      tpy += ksv * (a0 + a1);
+    };
+    tail_row(sub < K ? sub : K - 1, sub < K ? wc : R(0), sub < K ? static_cast<R>(sub) * ws : R(0));
+    if (K > 8) {  // rows 8 .. K-1: z^(sub + 8) = z^sub z8
+      const R z8c = z4c * z4c - z4s * z4s, z8s = (z4c + z4c) * z4s;
+      const R vc = wc * z8c - ws * z8s, vs = wc * z8s + ws * z8c;
+      const bool has = sub + 8 < K;
+      tail_row(has ? sub + 8 : K - 1, has ? vc : R(0), has ? static_cast<R>(sub + 8) * vs : R(0));
+    }
+    // the 8 lanes of a step: xor 1, xor 2 (quad permutations), then the mirror image inside the half row
+    tpx += dpp_or_zero<0xB1, 0xf>(tpx);
+    tpy += dpp_or_zero<0xB1, 0xf>(tpy);
+    tpx += dpp_or_zero<0x4E, 0xf>(tpx);
+    tpy += dpp_or_zero<0x4E, 0xf>(tpy);
+    tpx += dpp_or_zero<0x141, 0xf>(tpx);
+    tpy += dpp_or_zero<0x141, 0xf>(tpy);
+    if (sub == 0) {
+      s_tail[2 * st] = tpx;
+      s_tail[2 * st + 1] = tpy;
+    }
+    lds_fence();
+    const R accx = s_tail[2 * own], accy = s_tail[2 * own + 1];
+    lds_fence();
+    const R exj = (-p.pi_lx * s1x[jt] * accx) * p.expl_weight;
+    const R eyj = (-p.pi_ly * accy) * p.expl_weight;  // (sin b is in the row factors)
+    if (STAGES) {
+      ex[jt] = exj;
+      ey[jt] = eyj;
+    } else {
+      const bool act = jt < cnt;  // lanes tl < r of every agent
+      g0[jt] = act ? exj + g0[jt] : R(0);
+      g1[jt] = act ? eyj + g1[jt] : R(0);
     }
   }
   if (STAGES && agent_ok) {

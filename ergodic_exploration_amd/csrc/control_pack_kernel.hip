@@ -75,7 +75,11 @@ int control_pack_lanes(const ControlParams<double>& p, unsigned B, int forced)
     const unsigned waves = (B + A - 1) / A;
     if (lanes < 64 && waves < 256u) continue;
     const double w = 2.0 * static_cast<double>(waves) / 1024.0;
-    const double insts = p.K == 5 ? 500.0 + 250.0 * S : 600.0 + 580.0 * S;
+    // (a top-heavy horizon's last slot -- T = 3 L + 1 .. 3 L + L / 8, its gradient taken by all lanes together -- costs about
+    // 0.6 slots: yaml T = 50 on 16 lanes 20.85 -> 19.4 us per 12288-agent pass)
+    const int r_top = p.T - lanes * (S - 1);
+    const double slots = (lanes < 64 && S == pack::kMaxS && r_top <= lanes / 8) ? S - 0.4 : static_cast<double>(S);
+    const double insts = p.K == 5 ? 500.0 + 250.0 * slots : 600.0 + 580.0 * slots;
     const double cost = insts * (5.0 * w > 16.0 ? 5.0 * w : 16.0);
     if (best_l == 0 || cost <= best) {
       best = cost;

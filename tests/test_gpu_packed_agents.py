@@ -38,11 +38,11 @@ def _check_lanes(model, K, steps, dt, L, B):
         eng.close()
 
 
-# horizons per group size: around every steps-per-lane boundary (L, 2 L, 3 L, 4 L), partial second instruction group
+# horizons per group size: around every steps-per-lane boundary (L, 2 L, 3 L, 4 L), the top-heavy horizons 3 L + 1 .. 3 L + L / 8 (cooperative tail gradient), partial second instruction group
 # (T - j <= S L / 2), the smallest horizon the reference accepts (2) and the BASELINE shapes (5, 20, 50)
 HORIZONS = {8: [2, 3, 4, 5, 7, 8, 9, 12, 13, 16, 17, 20, 23, 24, 25, 29, 32],
-            16: [2, 5, 8, 9, 15, 16, 17, 20, 31, 32, 33, 40, 47, 48, 49, 50, 63, 64],
-            32: [2, 5, 16, 17, 20, 31, 32, 33, 50, 64, 65, 95, 96, 97, 100, 127, 128]}
+            16: [2, 5, 8, 9, 15, 16, 17, 20, 31, 32, 33, 40, 47, 48, 49, 50, 51, 63, 64],
+            32: [2, 5, 16, 17, 20, 31, 32, 33, 50, 64, 65, 95, 96, 97, 98, 99, 100, 101, 127, 128]}
 CASES = [(L, T) for L in (8, 16, 32) for T in HORIZONS[L]]
 
 
