@@ -120,6 +120,10 @@ def test_resident_life_cycle(resident):
     assert np.abs(u - uo).max() < 1e-8
     u, uo = eng.control(moved, x, mem[:, :50]), orc.control(moved, x, mem[:, :50])
     assert np.abs(u - uo).max() < 1e-8
+    # (the reference's batch_size = 100 columns, and the full buffer of 128: two rounds of 64 columns in the one-wavefront server)
+    for n in (100, 128, 1, 64, 65):
+        u, uo = eng.control(moved, x, mem[:, :n]), orc.control(moved, x, mem[:, :n])
+        assert np.abs(u - uo).max() < 1e-8, n
     eng.close()   # (e) eea_destroy with the workgroup resident
     # (f) SimpleCart::operator()'s throw (cart.hpp:167-170)
     eng, _ = make_pair("simple_cart", 10, 2.0, n_oracles=0)
@@ -131,4 +135,17 @@ def test_resident_life_cycle(resident):
         eng.control(MAP_BOUNDS, x)
     assert ei.value.status == capi.ERR_INVALID_TWIST
     assert np.array_equal(eng.get_ut(), bad)   # nothing of the agent was touched
+    with pytest.raises(capi.EngineError):      # (the server is still there and still refuses: the reference keeps throwing)
+        eng.control(MAP_BOUNDS, x)
+    # ... and serves again once the controls are valid (the first request of a server was the refused one: its next one reads
+    # the controls from memory, not from a hand-over that was never written)
+    orc2 = make_pair("simple_cart", 10, 2.0, n_oracles=1)
+    orc2[0].close()
+    good = np.random.default_rng(3).uniform(-0.3, 0.3, (3, eng.T))
+    good[1] = 0.0
+    eng.set_ut(good)
+    orc2[1][0].ut = good.copy()
+    for _ in range(3):
+        u, uo = eng.control(MAP_BOUNDS, x), orc2[1][0].control(MAP_BOUNDS, x)
+        assert np.abs(u - uo).max() < 1e-8
     eng.close()
