@@ -30,6 +30,18 @@ def test_timed_top_heavy_horizons_and_cooperative_last_slot(steps):
     run_batch_vs_oracle("omni", 5, steps * 0.1, 0.1, B=3, n_mem=0, calls=2, seed=73, stages=False)
 
 
+@pytest.mark.parametrize("steps", [65, 66, 68, 71, 72, 73, 129, 130, 133, 135, 136, 137])
+def test_cooperative_last_slot_with_two_and_three_slots(steps):
+    """top-heavy horizons below four slots (T = 64 (S - 1) + 1 .. + 8 at S = 2, 3: the first lanes own S steps, the others
+    S - 1; the tail slot takes a regular gradient pass -- the cooperative one of T = 193 .. 200 generalised to a run-time slot
+    was 4 - 6 % faster here and 0.7 % slower at the headline, profiles/r05_ablation.txt) with and without stage outputs;
+    73 / 137: the first horizons past the shape"""
+    for stages in (False, True):
+        run_batch_vs_oracle("simple_cart", 10, steps * 0.125, 0.125, B=5, n_mem=0, calls=2, seed=81, stages=stages)
+        run_batch_vs_oracle("omni", 10, steps * 0.125, 0.125, B=3, n_mem=70, calls=2, seed=82, stages=stages)
+        run_batch_vs_oracle("omni", 5, steps * 0.125, 0.125, B=3, n_mem=3, calls=2, seed=83, stages=stages)
+
+
 @pytest.mark.parametrize("steps", [191, 192, 193, 255, 256, 257])
 def test_timed_steps_per_lane_boundaries(steps):
     run_batch_vs_oracle("omni", 10, steps * 0.125, 0.125, B=5, n_mem=70, calls=2, seed=41, stages=False)
