@@ -1130,6 +1130,12 @@ def main():
                               "vector_insts_per_agent": valu - mfma, "matrix_insts_per_agent": mfma,
                               "pipe_cycles_per_agent": 4.0 * (valu - mfma) + 16.0 * mfma, "shader_clock_ghz": clock,
                               "wavefronts_per_simd": waves_per_simd, "issue_bound_source": src,
+                              # north_star asks for the matrix-core utilisation: the share of the pass a SIMD's pipe spends in
+                              # v_mfma_f64_4x4x4 (16 cycles each; = SQ_VALU_MFMA_BUSY_CYCLES / SIMD-cycles of the pass).  The
+                              # contraction is K^2 T of the ~6 K^2 T + 140 T multiply-adds of a pass, and fp64 matrix
+                              # instructions run on the vector pipe's own multipliers at the vector rate: a low share is the
+                              # shape of the work, not idle matrix cores beside a busy vector pipe
+                              "mfma_busy_frac": waves_per_simd * 16.0 * mfma / (pass_ms * 1e3 * clock * 1e3),
                               "reference_formulation_cycles_per_agent": 4.0 * flops_per_opt / 2.0 / 64.0})
         except Exception:
             pass
