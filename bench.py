@@ -29,6 +29,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+import bench_line  # noqa: E402 -- the compact driver line + bench_detail.json
+
 MAP_BOUNDS = (-1.0, 11.0, -1.0, 5.0)
 MEANS = [[2.5, 2.5], [8.5, 2.5]]
 SIGMAS = [[1.5, 1.5], [1.5, 1.5]]
@@ -649,8 +651,15 @@ def dry_run(args):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        os.write(1, (json.dumps({"dryrun": True, "n_gpus": world, "gpus_arg": args.gpus, "steps": args.steps,
-                                 "warmup": args.warmup, "grid_tile": grid_tile}) + "\n").encode())
+        out = {"dryrun": True, "n_gpus": world, "gpus_arg": args.gpus, "steps": args.steps,
+               "warmup": args.warmup, "grid_tile": grid_tile}
+        if os.environ.get("EEA_BENCH_DRYRUN_FROM"):
+            # the line-size guard of tests/test_bench_line.py: a recorded full result dictionary goes through the SAME
+            # emission path as a real run (detail file + compact line)
+            with open(os.environ["EEA_BENCH_DRYRUN_FROM"]) as f:
+                out = {**json.load(f), **out}
+        bench_line.write_detail(out, os.environ.get("EEA_BENCH_DETAIL_DIR", ROOT))
+        os.write(1, (bench_line.compact(out) + "\n").encode())
 
 
 def main():
@@ -1300,7 +1309,16 @@ def main():
                 ctypes.CDLL(None).fflush(None)
             except OSError:
                 pass
-            os.write(1, (json.dumps(out) + "\n").encode())
+            # the driver parses the LAST stdout line from a bounded tail: a fixed selection of fields, <= 4 KB by
+            # construction (bench_line.compact); every leg's full record goes to bench_detail.json
+            bench_line.write_detail(out, ROOT)
+            try:
+                text = bench_line.compact(out)
+            except Exception as exc:  # noqa: BLE001 -- never lose the headline to a formatting error
+                text = json.dumps({k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
+                                                            "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+                                  | {"line_error": repr(exc)[:200]})
+            os.write(1, (text + "\n").encode())
 
     # ---- exchange legs: last, and under a watchdog.  They are the only part of this program that has never run on
     # more than one GPU; if a collective never returns, every rank gives up after the timeout, rank 0 still prints

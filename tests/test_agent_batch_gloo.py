@@ -175,7 +175,7 @@ def test_occupancy_tiled_phik_world2_gloo():
     assert abs(pk[0] - 1.0) < 1e-15
 
 
-def test_bench_starts_its_own_ranks_dry_run():
+def test_bench_starts_its_own_ranks_dry_run(tmp_path):
     """`python bench.py --gpus 2 --steps K --warmup W` with no launcher around it (what the driver types): the
     parent -- which must not touch the GPU -- starts two ranks through torch.distributed.run and exits with their
     return code; EEA_BENCH_DRYRUN keeps the ranks off the device so that the plumbing is testable here.  (The
@@ -184,7 +184,7 @@ def test_bench_starts_its_own_ranks_dry_run():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, EEA_BENCH_DRYRUN="1")
+    env = dict(os.environ, EEA_BENCH_DRYRUN="1", EEA_BENCH_DETAIL_DIR=str(tmp_path))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
@@ -194,6 +194,7 @@ def test_bench_starts_its_own_ranks_dry_run():
     assert len(lines) == 1
     rec = json.loads(lines[0])
     gt = rec.pop("grid_tile")
+    assert rec.pop("detail") == "bench_detail.json"
     assert rec == {"dryrun": True, "n_gpus": 2, "gpus_arg": 2, "steps": 3, "warmup": 1}
     # the grid-tile leg's partition + all-reduce + normalisation (numpy in place of the device kernel): 48 rows over 2 ranks
     assert gt["ok"] and gt["rows_per_rank"] == 24 and gt["max_abs_err_vs_untiled"] < 1e-12
