@@ -269,7 +269,16 @@ def phik_legs(args, torch, capi, np):
     return out
 
 
-def other_config_legs(args, torch, capi, np, spl):
+def _profiled_short_horizons():
+    """profiles/r06_pack_profile.json: {(config name, agents, steps per launch): record}"""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r06_pack_profile.json")) as f:
+            return {(r["config"], r["agents"], r["steps_per_launch"]): r for r in json.load(f)["cases"]}
+    except Exception:  # noqa: BLE001
+        return {}
+
+
+def other_config_legs(args, torch, capi, np, spl, only=None, spinup_s=0.0):
     """The other single-GPU BASELINE configurations, 4096 agents each, ~0.3 s timed, the same launch form as the headline
     (two agent groups, `spl` receding-horizon steps per launch): configs[1] (SimpleCart, K = 10, horizon 2 s @ 0.1: T = 20,
     fp64) and configs[2] (Omni, K = 20, horizon 5 s @ 0.02: T = 250, 256 x 256 target grid, fp32 -- and its fp64 twin).
@@ -303,7 +312,10 @@ def other_config_legs(args, torch, capi, np, spl):
              means=MEANS, sigmas=SIGMAS, n_mem=100),
     ]
     res = []
+    prof = _profiled_short_horizons()
     for c in cases:
+        if only is not None and c["name"] not in only:
+            continue
         B = c.get("agents", args.agents)
         f32 = c["prec"] == "f32"
         tdt = torch.float32 if f32 else torch.float64
@@ -355,6 +367,8 @@ def other_config_legs(args, torch, capi, np, spl):
             torch.cuda.synchronize()
             return ev0.elapsed_time(ev1) / (n_calls * spl)   # ms per pass
         probe = run(max(1, 200 // spl))
+        if spinup_s > 0.0:   # a stand-alone run of this leg (tools/other_config_point.py): the clock ramp the headline leg provides in bench.py
+            run(max(2, int(spinup_s / (probe * 1e-3) / spl)))
         n_calls = max(2, int(0.3 / (probe * 1e-3) / spl))
         run(max(1, n_calls // 4))
         pass_ms = run(n_calls)
@@ -378,13 +392,19 @@ def other_config_legs(args, torch, capi, np, spl):
         nx, ny = eng.target_grid()[1:]
         res.append({"config": c["name"], "kinematics": c["model"], "num_basis": K, "horizon_steps": T, "dt": c["dt"],
                     "dtype": c["prec"], "agents": B, "lanes_per_agent": eng.agent_lanes(half), "n_mem": n_mem,
-                    "steps_per_launch": spl, "passes_timed": n_calls * spl,
+                    "steps_per_launch": spl, "passes_timed": n_calls * spl, "launches_timed": n_calls * len(calls),
                     "ms_per_pass": pass_ms, "us_per_4096_agents": 1e3 * pass_ms * 4096 / B,
                     "value": B / (pass_ms * 1e-3), "unit": "optimisations/s",
                     "roofline": {"bound": "valu-%s" % c["prec"], "achieved": tfl, "peak": peak, "unit": "TFLOP/s",
                                  "frac": tfl / peak, "flops_per_optimisation": flops},
                     "config_domain_rebuild": {"grid": "%dx%d" % (nx, ny), "device_us": 1e3 * evs[0].elapsed_time(evs[1]) / 50,
                                               "enqueue_only_wall_us": 1e6 * enq}})
+        # the rocprofv3 view of this leg (tools/r06_pack_profile.sh -> profiles/r06_pack_profile.json: kernel average over the
+        # timed region of a stand-alone profiled run of the SAME launch form; not measured in this run)
+        pr = prof.get((c["name"], B, spl))
+        if pr:
+            res[-1]["kernel_avg_us_profiled"] = pr["kernel_avg_us_timed_region"]
+            res[-1]["frac_profiled"] = flops * B / (pr["kernel_avg_us_timed_region"] / spl * 1e-6) / 1e12 / peak
         eng.close()
     return {"note": "the other single-GPU BASELINE configurations in the headline's launch form (two agent groups x %d steps per "
                     "launch), 4096 agents unless the case names its batch, ~0.3 s timed each, HIP events around the launches of "

@@ -105,7 +105,7 @@ def compact(out):
             line[k] = _r(out[k])
     rf = out.get("roofline")
     if isinstance(rf, dict):
-        line["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "passes_per_launch",
+        line["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "flops_per_launch", "passes_per_launch",
                                       "agents_per_launch", "concurrent_launches", "kernel_avg_us_profiled", "frac_profiled",
                                       "issue_bound_us", "frac_of_issue_bound", "mfma_busy_frac",
                                       "wait_inst_any_over_wave_cycles"))

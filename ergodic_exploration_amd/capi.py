@@ -19,7 +19,7 @@ MODEL_OMNI, MODEL_SIMPLE_CART = 0, 1
 PREC_F64, PREC_F32 = 0, 1
 OK, ERR_INVALID_ARGUMENT, ERR_INVALID_TWIST, ERR_UNSUPPORTED, ERR_HIP, ERR_NO_TARGET, ERR_TIMEOUT = range(7)
 # eea_set_option (process-wide dispatch options; the library reads no environment variable)
-OPT_CONTROL_KERNEL, OPT_WORKGROUP_THREADS, OPT_COLLISION_IMPL, OPT_MAILBOX_POLL, OPT_REBUILD_IMPL, OPT_AGENT_LANES, OPT_RESIDENT_CONTROL = range(7)
+OPT_CONTROL_KERNEL, OPT_WORKGROUP_THREADS, OPT_COLLISION_IMPL, OPT_MAILBOX_POLL, OPT_REBUILD_IMPL, OPT_AGENT_LANES, OPT_RESIDENT_CONTROL, OPT_RESIDENT_IDLE_MS = range(8)
 
 
 class EngineError(RuntimeError):
@@ -114,7 +114,7 @@ def lib():
         L.eea_ck_records_sum_bound.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p,
                                                C.c_void_p]
         L.eea_publish_record.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
-        for name in ("eea_steps", "eea_num_modes", "eea_real_size", "eea_time_step", "eea_destroy"):
+        for name in ("eea_steps", "eea_num_modes", "eea_real_size", "eea_time_step", "eea_destroy", "eea_resident_stop"):
             getattr(L, name).argtypes = [C.c_void_p]
         L.eea_destroy.restype = None
         L.eea_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
@@ -315,7 +315,7 @@ class Engine:
     def control_batch(self, B, pose, ut, u0, mem_cols=None, n_mem=None, mem_stride=0, traj=None,
                       ck=None, edx=None, bdx=None, rhot=None, status=None, stream=None, ck_shared=None,
                       ck_rec=None, ck_shared_parts=0, n_steps=None, pose_step_stride=0, u0_step_stride=0,
-                      rec_ready=None, rec_seq=0, ck_flag=None, ck_flag_seq=0):
+                      rec_ready=None, rec_seq=0, ck_flag=None, ck_flag_seq=0, skip=None):
         """n_steps (ABI 4, eea_control_batch_steps): that many consecutive control() calls per agent in one launch;
         pose / u0 rows per step by the strides (in agents; 0 = the same row every step)."""
         io = BatchIO()
@@ -326,6 +326,7 @@ class Engine:
         io.d_traj, io.d_ck, io.d_edx, io.d_bdx = _ptr(traj), _ptr(ck), _ptr(edx), _ptr(bdx)
         io.d_rhot, io.d_status = _ptr(rhot), _ptr(status)
         io.d_rec_ready, io.rec_seq, io.d_ck_flag, io.ck_flag_seq = _ptr(rec_ready), rec_seq, _ptr(ck_flag), ck_flag_seq
+        io.d_skip = _ptr(skip)
         if n_steps is None:
             check(lib().eea_control_batch(self.h, B, C.byref(io), C.c_void_p(stream or 0)))
         else:
@@ -430,6 +431,11 @@ class Engine:
         check(lib().eea_control(self.h, *[float(b) for b in bounds], _ptr(x), _ptr(mem), n_mem,
                                 _ptr(u)))
         return u
+
+    def resident_stop(self):
+        """eea_resident_stop: the resident single-robot workgroup (OPT_RESIDENT_CONTROL) leaves now; the next control() starts
+        another one"""
+        check(lib().eea_resident_stop(self.h))
 
     def opt_traj(self):
         import numpy as np

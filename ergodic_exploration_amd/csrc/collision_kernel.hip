@@ -528,6 +528,7 @@ hipError_t build_hit_map(const CollisionParams& c, const int8_t* d_grid, MapScra
 
   uint8_t* cells = nullptr;
   unsigned stamp = 1;
+  bool from_table = false;  // the map lives in a per-stream buffer of the table (its cache key is recorded after the launch)
   {
     std::lock_guard<std::mutex> lock(g_maps_mutex);
     MapBuffer* buf = nullptr;
@@ -564,11 +565,13 @@ hipError_t build_hit_map(const CollisionParams& c, const int8_t* d_grid, MapScra
         if (e != hipSuccess) return e;
         buf->stamp = 1;
       }
-      buf->built_grid = epoch != 0 ? d_grid : nullptr;
-      buf->built_epoch = epoch;
-      buf->built_params = c;
+      // (the cache key is recorded only once the dilation launch below has succeeded -- ADVICE r05: after a failed launch the
+      // next tick with the same (grid, epoch) must not validate against a map that was never stamped)
+      buf->built_grid = nullptr;
+      buf->built_epoch = 0;
       cells = buf->cells;
       stamp = buf->stamp;
+      from_table = true;
     }
   }
   if (cells == nullptr) {
@@ -584,6 +587,16 @@ hipError_t build_hit_map(const CollisionParams& c, const int8_t* d_grid, MapScra
                        d_grid, d_off, n_off, cells, R, w, static_cast<uint8_t>(stamp));
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+  }
+  if (from_table && epoch != 0) {  // valid for work ordered behind this launch (the caller's stream contract)
+    std::lock_guard<std::mutex> lock(g_maps_mutex);  // (the table may have grown: look the buffer up again)
+    for (MapBuffer& b : g_maps) {
+      if (b.device == device && b.stream == s && b.cells == cells) {
+        b.built_grid = d_grid;
+        b.built_epoch = epoch;
+        b.built_params = c;
+      }
+    }
   }
   sc.map.cells = cells;
   sc.map.R = R;

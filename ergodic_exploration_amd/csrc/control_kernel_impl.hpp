@@ -919,6 +919,8 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_resident_
     const unsigned first_seen, const long long idle_ticks)
 {
   __shared__ unsigned s_line[16];
+  __shared__ unsigned s_leaving;  // alive = 0 has been announced: the request being served (if any) is the last one
+  if (threadIdx.x == 0) s_leaving = 0u;
   constexpr int kReq = offsetof(ResidentMail<R>, req) / 4, kCmd = offsetof(ResidentMail<R>, cmd) / 4;
   constexpr int kNmem = offsetof(ResidentMail<R>, n_mem) / 4, kMapX = offsetof(ResidentMail<R>, map_x) / 4;
   unsigned last = first_seen;
@@ -942,7 +944,10 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_resident_
       if (idle) {
         // idle for too long: say so FIRST, then look once more -- a request posted before the host can have seen alive = 0 is
         // still served, one posted later finds alive = 0 and launches a new workgroup (eea_control)
-        if (threadIdx.x == 0) __hip_atomic_store(&mail->alive, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) {
+          __hip_atomic_store(&mail->alive, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          s_leaving = 1u;
+        }
         __builtin_amdgcn_s_sleep(64);
         v = __hip_atomic_load(line + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
@@ -991,6 +996,9 @@ __global__ __launch_bounds__(BLK, min_waves_per_simd(KC)) void control_resident_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(&mail->done, static_cast<int>(r), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // a request that landed between "alive = 0" and the last look has been served; the workgroup has told the host that it
+    // is gone, so it leaves now (back in the poll loop it would race the successor the host launches)
+    if (s_leaving != 0u) return;  // (written before the barrier that published s_line: workgroup-uniform)
   }
 }
 

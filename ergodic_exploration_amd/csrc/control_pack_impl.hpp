@@ -171,7 +171,8 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_k
   // (eea_batch_io::d_skip: an agent that is left out of the call is treated like one beyond the batch)
   const bool agent_in = b < B && !(p.skip != nullptr && p.skip[b < B ? b : 0] != 0);
   // the agent of lane ^ 32 (the partner whose other axis this lane stages)
-  const bool partner_in = (wave_base + (al ^ (A / 2))) < B;
+  const unsigned pb = wave_base + (al ^ (A / 2));
+  const bool partner_in = pb < B && !(p.skip != nullptr && p.skip[pb < B ? pb : 0] != 0);
 
   const int T = p.T;
   R* const sm = reinterpret_cast<R*>(smem_raw) + static_cast<size_t>(wv) * wave_lds_elems(KC, A, S);
@@ -247,10 +248,10 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_k
     agent_ok = agent_in && !agent_bad;
     if (tl == 0 && agent_in && p.status != nullptr) {
       if (agent_bad) p.status[b] = 2;  // EEA_ERR_INVALID_TWIST
-      else if (step == 0) p.status[b] = 0;
+      else if (step == 0 && !(p.ck_flag != nullptr && p.status[b] == 6)) p.status[b] = 0;
     }
-  } else if (tl == 0 && agent_in && p.status != nullptr && step == 0) {
-    p.status[b] = 0;
+  } else if (tl == 0 && agent_in && p.status != nullptr && step == 0 && !(p.ck_flag != nullptr && p.status[b] == 6)) {
+    p.status[b] = 0;  // (device-bound exchange: a time-out an earlier pass left in a reused buffer stays, as in control_wave_kernel)
   }
 
   const R dt = p.dt, dt6 = p.dt6;
@@ -554,17 +555,29 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_k
       }
     }
     const bool writer = (L == 8) || (L == 16 && db < 2) || (L == 32 && db == 0);  // one copy stores c_k
+    // The agents' sum records (eea_batch_io::d_ck_rec: [c_k, 1, pad]; decentralised consensus, README ref. [2]) leave from the
+    // registers that hold c_k -- the same lanes, the same addresses within the agent as the d_ck stores --, BEFORE anything
+    // of the shared c_k is read: with the device-bound exchange (d_rec_ready) they go write-through, the agents' ready marks
+    // follow once they have left, and only then does the wavefront wait for the flag of the record it consumes
+    // (control_wave_kernel's publish_record / bind_shared_ck, per agent of the wavefront).  A rejected agent's record is all
+    // zero (it does not count in the sum), an agent left out of the call (d_skip) writes nothing.
+    const bool rec_on = p.ck_rec != nullptr && !rollout_only;  // wavefront-uniform
+    const bool rec_wt = p.rec_ready != nullptr;                // wavefront-uniform: write-through + ready marks
+    constexpr unsigned long long kGrp = (L == 32) ? 0xffffffffull : ((1ull << L) - 1ull);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int ab = block_agent<L>(h, db);
       const unsigned bb = wave_base + ab;
-      const bool in = bb < B;
+      // (an agent left out of the call is treated like one beyond the batch: nothing of it is read or written)
+      const bool in = bb < B && !(p.skip != nullptr && p.skip[bb < B ? bb : 0] != 0);
+      const bool counts = ((rejected >> (ab * L)) & kGrp) == 0ull;  // not rejected by SimpleCart::operator()
       int nm = 0;
       if (p.mem_cols != nullptr && in) {
         nm = (p.n_mem != nullptr) ? p.n_mem[bb] : static_cast<int>(p.mem_stride);
         nm = nm < 0 ? 0 : (nm > static_cast<int>(p.mem_stride) ? static_cast<int>(p.mem_stride) : nm);
       }
       const R invN = R(1) / static_cast<R>(T + nm);
+      R* const rec = rec_on ? p.ck_rec + static_cast<size_t>(bb < B ? bb : 0) * p.rec_len : nullptr;
 #pragma unroll
       for (int I = 0; I < NB; ++I) {
 #pragma unroll
@@ -572,13 +585,57 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_k
           R v = cacc[h][I][J];
           if constexpr (L == 16) v = wave::add_row_ror<8>(v);
           if constexpr (L == 32) v = wave::add_row_ror<8>(wave::add_row_ror<4>(v));
+          const R c = invN * v;
+          cacc[h][I][J] = c;
+          const int k1 = 4 * I + di, k2 = 4 * J + dj;
+          if (k1 < K && k2 < K && in && writer) {
+            const int idx = k2 * K + k1;
+            if (p.ck != nullptr && (MODEL != kModelSimpleCart || counts)) p.ck[static_cast<size_t>(bb) * K2 + idx] = c;
+            if (rec_on) {
+              const R cr = counts ? c : R(0);
+              if (rec_wt) store_agent(rec + idx, cr);
+              else rec[idx] = cr;
+            }
+          }
+        }
+      }
+    }
+    if (rec_on) {  // wavefront-uniform
+      if (tl == 0 && agent_in) {  // element K^2 = 1 (this agent counts), pad 0
+        R* const rec = p.ck_rec + static_cast<size_t>(b) * p.rec_len;
+        for (unsigned e = static_cast<unsigned>(K2); e < p.rec_len; ++e) {
+          const R v = (e == static_cast<unsigned>(K2) && agent_ok) ? R(1) : R(0);
+          if (rec_wt) store_agent(rec + e, v);
+          else rec[e] = v;
+        }
+      }
+      if (rec_wt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the records of every agent of this wavefront have left
+        if (tl == 0 && agent_in) store_agent(p.rec_ready + b, p.rec_seq);
+      }
+    }
+    // device-bound exchange, consumer side: the shared c_k may still be on its way -- wait for its flag here, right before
+    // its first use.  On a time-out the agents of this wavefront go on with their own c_k and say so
+    bool use_shared = p.ck_shared != nullptr;  // wavefront-uniform
+    if (use_shared && p.ck_flag != nullptr) {
+      bool ok = wait_flag(p.ck_flag, p.ck_flag_seq);
+      if (ok && p.ck_shared_parts > 0) ok = !(load_agent(p.ck_shared + K2) < R(0));  // a producer that gave up
+      if (!ok && tl == 0 && agent_ok && p.status != nullptr) p.status[b] = 6;  // EEA_ERR_TIMEOUT
+      use_shared = ok;
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ab = block_agent<L>(h, db);
+#pragma unroll
+      for (int I = 0; I < NB; ++I) {
+#pragma unroll
+        for (int J = 0; J < NB; ++J) {
           const int k1 = 4 * I + di, k2 = 4 * J + dj;
           if (k1 < K && k2 < K) {
             const int idx = k2 * K + k1;
-            R c = invN * v;
-            if (p.ck != nullptr && in && writer) p.ck[static_cast<size_t>(bb) * K2 + idx] = c;
+            R c = cacc[h][I][J];
             // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
-            if (p.ck_shared != nullptr) c = shared_ck_value(p, p.ck_shared, idx, K2, c);
+            if (use_shared) c = shared_ck_value(p, p.ck_shared, idx, K2, c);
             s_D[ab * DS + idx] = lamv[I][J] * (c - phiv[I][J]);
           }
         }

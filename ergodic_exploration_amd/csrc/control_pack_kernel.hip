@@ -40,14 +40,15 @@ hipError_t launch_pack_k(const ControlParams<double>& p, unsigned B, bool rollou
 }
 }  // namespace
 
-// Can a group of `lanes` lanes per agent take this call?  fp64, K = 5 / 10, T <= 4 lanes; none of the device-bound
-// exchange's buffers, not the single-agent mailbox.
+// Can a group of `lanes` lanes per agent take this call?  fp64, K = 5 / 10, T <= 4 lanes; not the single-agent mailbox.
+// (Round 6: the exchange's buffers -- sum records out, ready marks, the flag of the shared c_k -- are served here too, so
+// decentralised consensus keeps packing at short horizons.)
 bool control_pack_eligible(const ControlParams<double>& p, int lanes)
 {
   if (lanes != 8 && lanes != 16 && lanes != 32) return false;
   if (p.K != 5 && p.K != 10) return false;
   if (p.T < 1 || p.T > pack::kMaxS * lanes) return false;
-  if (p.ck_rec != nullptr || p.rec_ready != nullptr || p.ck_flag != nullptr || p.done != nullptr || p.dbg != nullptr) return false;
+  if (p.done != nullptr || p.dbg != nullptr) return false;
   return true;
 }
 

@@ -279,6 +279,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
   const int n_steps = RESIDENT ? 0x7fffffff : ((KernArgParams*)__builtin_amdgcn_kernarg_segment_ptr())->n_steps;
   unsigned res_last = RESIDENT ? ((KernArgParams*)__builtin_amdgcn_kernarg_segment_ptr())->res_first : 0u;  // request seen
   bool res_handover = false;  // RESIDENT: a served request has left its controls in LDS
+  bool res_leaving = false;   // RESIDENT: alive = 0 has been announced -- the request being served is the last one
   // The controls a step leaves for the next one are handed over in LDS (the tiles and the park are dead between the
   // update and the next forward half): s_next[r][step index], read back one column to the right
   // (ergodic_control.hpp:233-234).  Reading them back from L2 put that latency at the head of every step of every wavefront
@@ -333,6 +334,10 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
       v = __hip_atomic_load(line + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       r = __builtin_amdgcn_readlane(v, kReq);
       if (r == res_last) return;
+      // a request that landed in that window is served -- and then the wavefront LEAVES: it has told the host
+      // that it is gone, so it must not go back to polling (the host may already be launching its successor, which would
+      // serve the same request a second time and shift the warm start twice)
+      res_leaving = true;
     }
     res_last = r;
     if (__builtin_amdgcn_readlane(v, kCmd) != 0u) {  // told to leave
@@ -475,7 +480,10 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
     if (lane == 0 && p.done != nullptr && b == 0) {
       __hip_atomic_store(p.done, RESIDENT ? static_cast<int>(res_last) : p.done_seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    if constexpr (RESIDENT) continue;  // (nothing was written: the controls in ut / LDS are what they were)
+    if constexpr (RESIDENT) {
+      if (res_leaving) return;
+      continue;  // (nothing was written: the controls in ut / LDS are what they were)
+    }
     return;
   }
   // (a time-out of an earlier step of the launch stays; device-bound exchange: so does one an earlier PASS left in a reused
@@ -1734,7 +1742,10 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
     lds_fence();
   }
   EEA_WSTAMP_RT(11);
-  if constexpr (RESIDENT) res_handover = true;
+  if constexpr (RESIDENT) {
+    if (res_leaving) return;  // (the controls of this request are in ut: every step stores them)
+    res_handover = true;
+  }
   }  // step
 }
 

@@ -23,7 +23,7 @@ namespace
 using eea::fail;
 
 // process-wide dispatch options (eea_set_option); index = EEA_OPT_*
-std::atomic<int> g_options[EEA_OPT_COUNT] = { { 0 }, { 0 }, { 0 }, { 1 }, { 0 }, { 0 }, { 0 } };
+std::atomic<int> g_options[EEA_OPT_COUNT] = { { 0 }, { 0 }, { 0 }, { 1 }, { 0 }, { 0 }, { 0 }, { 250 } };
 }  // namespace
 
 namespace eea
@@ -564,7 +564,7 @@ eea_status sum_workspace(eea_engine* e, const void* key, unsigned B, hipStream_t
     // earlier launch may still use are retired behind an event on that launch's stream and freed once it has completed
     // (no device-wide sweep); a recycled workspace gets fresh buffers for the same reason.
     for (size_t i = 0; i < e->retired.size();) {
-      if (hipEventQuery(e->retired[i].done) == hipSuccess) {
+      if (e->retired[i].done != nullptr && hipEventQuery(e->retired[i].done) == hipSuccess) {
         (void)hipEventDestroy(e->retired[i].done);
         (void)hipFree(e->retired[i].p);
         e->retired[i] = e->retired.back();
@@ -574,17 +574,24 @@ eea_status sum_workspace(eea_engine* e, const void* key, unsigned B, hipStream_t
       }
     }
     (void)hipGetLastError();  // (hipErrorNotReady of the queries is not an error of this call)
-    for (void* q : { w->ws.p, w->ctr.p }) {
+    // Each buffer moves to the retired list individually, and the workspace forgets it the moment it has (a failed
+    // record must neither leak the event nor leave w->ws.p pointing at a buffer the list will free).  last_stream is a
+    // CALLER-owned handle remembered from an earlier call: if the caller has destroyed it the record fails -- the event is
+    // destroyed and the buffer stays in the list without one, until eea_destroy (its last launch cannot be proven complete).
+    for (DevBuf* buf : { &w->ws, &w->ctr }) {
+      void* const q = buf->p;
       if (q == nullptr) continue;
       hipEvent_t ev = nullptr;
-      EEA_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-      EEA_HIP(hipEventRecord(ev, w->last_stream));
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) ev = nullptr;
+      if (ev != nullptr && hipEventRecord(ev, w->last_stream) != hipSuccess) {
+        (void)hipEventDestroy(ev);
+        ev = nullptr;
+      }
+      (void)hipGetLastError();
       e->retired.push_back({ q, ev });
+      buf->p = nullptr;  // (ownership moved to the retired list)
+      *buf = DevBuf();
     }
-    w->ws.p = nullptr;   // (ownership moved to the retired list)
-    w->ctr.p = nullptr;
-    w->ws = DevBuf();
-    w->ctr = DevBuf();
     EEA_HIP(w->ws.reserve(need_ws));
     EEA_HIP(w->ctr.reserve(need_ctr));
     EEA_HIP(hipMemsetAsync(w->ctr.p, 0, w->ctr.cap, s));  // the tickets reset themselves from here on
@@ -732,7 +739,9 @@ eea_status make_dwa_params(const eea_dwa_cfg* dcfg, eea::DwaParams& d)
 }
 
 // ---- resident single-robot workgroup (control_kernel_impl.hpp control_resident_kernel) --------------------------------------
-constexpr long long kResidentIdleTicks = 25000000LL;  // 250 ms of the 100 MHz clock: a 10 Hz loop keeps it alive
+// idle time of a resident workgroup in ticks of the constant 100 MHz clock (EEA_OPT_RESIDENT_IDLE_MS, default 250 ms: a 10 Hz
+// loop keeps it alive)
+long long resident_idle_ticks() { return 100000LL * static_cast<long long>(eea::option(EEA_OPT_RESIDENT_IDLE_MS)); }
 
 // tells the workgroup to leave and waits until it has (no-op when none was launched)
 eea_status resident_stop(eea_engine* e)
@@ -799,13 +808,13 @@ eea_status resident_start(eea_engine* e)
       p.done = &dm->done;
       p.res_mail = e->d_rmail;
       p.res_first = e->res_seq;
-      p.res_idle = kResidentIdleTicks;
+      p.res_idle = resident_idle_ticks();
       EEA_HIP(eea::launch_control_wave_resident(p, e->cfg.model, e->stream_res));
     }
   }
   if (!one_wavefront) {
     EEA_HIP(eea::launch_control_resident<R>(p, e->cfg.model, eea::kResidentMemCols, e->d_rmail, e->d_rstage.p, e->res_seq,
-                                            kResidentIdleTicks, e->stream_res));
+                                            resident_idle_ticks(), e->stream_res));
   }
   e->res_one_wavefront = one_wavefront;
   e->res_launched = true;
@@ -845,7 +854,16 @@ eea_status control_resident(eea_engine* e, const double x[3], const double* h_me
     if (__atomic_load_n(&hm->alive, __ATOMIC_ACQUIRE) == 0 &&
         __atomic_load_n(&hm->done, __ATOMIC_ACQUIRE) != static_cast<int>(seq)) {
       if (relaunched) return fail(EEA_ERR_HIP, "the resident control workgroup left twice without answering");
-      // it went idle just before the request: a new one starts from the request before this one and sees it at once
+      // It announced that it is leaving around the time of this request.  It may still be SERVING it (a request that lands
+      // between "alive = 0" and its last look at the mailbox is served, and then it leaves -- it never polls again): wait
+      // until it has left, then look at the answer once more.  Only a request that is still unanswered then gets a new
+      // workgroup, which starts from the request before this one and sees it at once.  (Relaunching without this wait served
+      // such a request twice: the warm start shifted twice, u0 rewritten under the host's read -- ADVICE r05.)
+      EEA_HIP(hipStreamSynchronize(e->stream_res));
+      if (__atomic_load_n(&hm->done, __ATOMIC_ACQUIRE) == static_cast<int>(seq)) {
+        e->res_launched = false;  // answered by the leaving workgroup; the next call starts another one
+        break;
+      }
       e->res_launched = false;
       --e->res_seq;
       st = resident_start<R>(e);
@@ -882,6 +900,7 @@ eea_status eea_set_option(int option, int value)
     case EEA_OPT_REBUILD_IMPL: ok = value == 0 || value == 1; break;
     case EEA_OPT_AGENT_LANES: ok = value == 0 || value == 8 || value == 16 || value == 32 || value == 64; break;
     case EEA_OPT_RESIDENT_CONTROL: ok = value == 0 || value == 1; break;
+    case EEA_OPT_RESIDENT_IDLE_MS: ok = value >= 1 && value <= 60000; break;
     default: return fail(EEA_ERR_INVALID_ARGUMENT, "unknown option");
   }
   if (!ok) return fail(EEA_ERR_INVALID_ARGUMENT, "option value out of range");
@@ -972,7 +991,7 @@ void eea_destroy(eea_engine* e)
     w->ctr.release();
   }
   for (auto& r : e->retired) {
-    (void)hipEventDestroy(r.done);
+    if (r.done != nullptr) (void)hipEventDestroy(r.done);
     (void)hipFree(r.p);
   }
   if (e->ev_done) (void)hipEventDestroy(e->ev_done);
@@ -1462,6 +1481,14 @@ eea_status eea_control(eea_engine* e, double xmin, double xmax, double ymin, dou
     std::memcpy(u_out, e->h_mail->u0, sizeof(double) * 3);
   }
   return EEA_OK;
+}
+
+eea_status eea_resident_stop(eea_engine* e)
+{
+  if (check_engine(e) != EEA_OK) return fail(EEA_ERR_INVALID_ARGUMENT, "null engine");
+  eea_status st = use_device(e);
+  if (st != EEA_OK) return st;
+  return resident_stop(e);
 }
 
 eea_status eea_opt_traj(eea_engine* e, double* h_traj)

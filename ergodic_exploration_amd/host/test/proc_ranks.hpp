@@ -5,13 +5,16 @@
 #pragma once
 
 #include <fcntl.h>
+#include <poll.h>
 #include <sys/mman.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
 #include <atomic>
 #include <chrono>
+#include <cerrno>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -73,8 +76,29 @@ inline bool fetch_id(const std::string& file, void* id, size_t bytes, double tim
 // parent: start `nranks` copies of this program with the arguments `args` + { "child", rank, base }, where base names the
 // shared segment ("/" + base) and prefixes the id files ("/tmp/" + base + ".<n>").  Returns 0 if every child returned 0;
 // the children's standard output is collected per child (in rank order) when `outputs` is given.
+// The parent is a fork + execv LAUNCHER and must never have initialised the GPU (on this pool an exec from a process that has
+// takes the machine down).  That holds for a plain run -- the parent makes no HIP call -- but NOT under a profiler: rocprofv3
+// preloads a tool library that initialises the GPU before main().  So the launcher form refuses to start under a profiler
+// preload; profile ONE rank by putting the `child <rank> <base>` form itself after `rocprofv3 --`.
+inline bool profiler_preloaded()
+{
+  for (const char* var : { "LD_PRELOAD", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCP_TOOL_LIBRARIES", "ROCPROF_ATT_LIBRARY_PATH" }) {
+    const char* v = std::getenv(var);
+    if (v != nullptr && (std::strstr(v, "rocprof") != nullptr || std::strstr(v, "roctracer") != nullptr ||
+                         std::strstr(v, "rocprofiler") != nullptr)) {
+      return true;
+    }
+  }
+  return false;
+}
+
 inline int spawn(const char* self, const std::vector<std::string>& args, int nranks, std::vector<std::string>* outputs = nullptr)
 {
+  if (profiler_preloaded()) {
+    std::fprintf(stderr, "proc_ranks::spawn: refusing to fork + exec the ranks under a profiler preload (the preloaded tool "
+                         "has initialised the GPU in this process); profile one rank as `%s ... child <rank> <base>`\n", self);
+    return 4;
+  }
   const std::string base = "eea-ranks-" + std::to_string(getpid());
   shm_unlink(("/" + base).c_str());
   std::vector<pid_t> kids;
@@ -108,12 +132,31 @@ inline int spawn(const char* self, const std::vector<std::string>& args, int nra
   }
   if (outputs) {
     outputs->assign(nranks, std::string());
-    // (the children print a few KB: the pipes are drained one after the other)
+    // all pipes are drained TOGETHER (poll): the children barrier with each other, so a child blocked on a full pipe while
+    // the parent reads another child's to its end would dead-lock the whole group
+    std::vector<pollfd> pf(nranks);
+    int open_fds = nranks;
+    for (int r = 0; r < nranks; ++r) pf[r] = pollfd{ fds[r], POLLIN, 0 };
+    while (open_fds > 0) {
+      if (poll(pf.data(), static_cast<nfds_t>(nranks), -1) < 0) {
+        if (errno == EINTR) continue;
+        break;
+      }
+      for (int r = 0; r < nranks; ++r) {
+        if (pf[r].fd < 0 || (pf[r].revents & (POLLIN | POLLHUP | POLLERR)) == 0) continue;
+        char buf[4096];
+        const ssize_t n = read(pf[r].fd, buf, sizeof(buf));
+        if (n > 0) {
+          (*outputs)[r].append(buf, static_cast<size_t>(n));
+        } else if (n == 0 || errno != EINTR) {
+          close(pf[r].fd);
+          pf[r].fd = -1;  // (poll ignores negative descriptors)
+          --open_fds;
+        }
+      }
+    }
     for (int r = 0; r < nranks; ++r) {
-      char buf[4096];
-      ssize_t n;
-      while ((n = read(fds[r], buf, sizeof(buf))) > 0) (*outputs)[r].append(buf, static_cast<size_t>(n));
-      close(fds[r]);
+      if (pf[r].fd >= 0) close(pf[r].fd);
     }
   }
   int worst = 0;

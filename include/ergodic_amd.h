@@ -95,10 +95,14 @@ enum { EEA_OPT_CONTROL_KERNEL = 0,    /* 0 = automatic (wavefront-per-agent kern
                                          wherever it is eligible (tests, A/B) */
        EEA_OPT_RESIDENT_CONTROL = 6,  /* eea_control (one robot, one control() per tick): 1 = a RESIDENT workgroup serves the calls
                                          from a host-mapped mailbox instead of one launch per call (the launch round trip is
-                                         18-22 us whatever the shape).  It leaves by itself after 250 ms without a call and
-                                         on eea_destroy; while it is there, device-wide waits (hipDeviceSynchronize, hipFree)
-                                         of the process take up to that long.  0 (default) = one launch per call */
-       EEA_OPT_COUNT = 7 };
+                                         18-22 us whatever the shape).  It leaves by itself after EEA_OPT_RESIDENT_IDLE_MS
+                                         without a call, on eea_resident_stop and on eea_destroy; while it is there,
+                                         device-wide waits (hipDeviceSynchronize, hipFree) of the process take up to that
+                                         long.  0 (default) = one launch per call */
+       EEA_OPT_RESIDENT_IDLE_MS = 7,  /* how long the resident workgroup waits for the next call before it leaves, in
+                                         milliseconds: 1 .. 60000, default 250 (a 10 Hz loop, exploration.hpp:232, keeps it
+                                         alive).  Read when a resident workgroup is started */
+       EEA_OPT_COUNT = 8 };
 eea_status eea_set_option(int option, int value);
 int eea_get_option(int option);
 
@@ -380,6 +384,11 @@ eea_status eea_comm_allreduce_sum_async(eea_engine* e, eea_comm* c, void* d_buf,
 eea_status eea_control(eea_engine* e, double xmin, double xmax, double ymin, double ymax,
                        const double x[3], const double* h_mem_cols, unsigned n_mem,
                        double u_out[3]);
+/* EEA_OPT_RESIDENT_CONTROL: tells the engine's resident workgroup (if one is there) to leave and returns when it has; the
+ * next eea_control starts another one.  For a caller about to make device-wide waits (hipDeviceSynchronize, hipFree,
+ * hipMalloc) that would otherwise take up to the idle time.  The warm-start controls are kept (they are in device memory
+ * after every request).  No reference counterpart; EEA_OK also when nothing was resident. */
+eea_status eea_resident_stop(eea_engine* e);
 /* mat optTraj() const (ergodic_control.hpp:313-317): 3 x T doubles */
 eea_status eea_opt_traj(eea_engine* e, double* h_traj);
 /* read / overwrite the engine-held warm-start controls ut_ (3 x T doubles) */

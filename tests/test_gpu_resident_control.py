@@ -149,3 +149,83 @@ def test_resident_life_cycle(resident):
         u, uo = eng.control(MAP_BOUNDS, x), orc2[1][0].control(MAP_BOUNDS, x)
         assert np.abs(u - uo).max() < 1e-8
     eng.close()
+
+
+@pytest.mark.parametrize("model,K,horizon", [("omni", 10, 5.0),            # the one-wavefront server (T = 50)
+                                             ("simple_cart", 10, 20.0)])   # the workgroup server (T = 200)
+def test_calls_at_the_idle_period_are_served_once(model, K, horizon):
+    """a request that arrives just as the server goes idle.  With the idle time cut to a few milliseconds
+    (EEA_OPT_RESIDENT_IDLE_MS) and a call period swept ACROSS it in fine steps, many calls land in the window between the
+    server's "alive = 0" and its last look at the mailbox.  Each must be served exactly once: the sequence of controls and the
+    final warm start are bitwise those of the launch path (a request served twice shifts the warm start twice)."""
+    idle_ms = 3
+    rng = np.random.default_rng(11)
+    n = 120
+    walk = np.array([3.0, 2.0, 0.3]) + np.cumsum(rng.normal(scale=0.02, size=(n, 3)), axis=0)
+    # periods from 0.6 to 1.4 idle times, and a stretch exactly around it in 10 us steps
+    periods = np.concatenate([np.linspace(0.6, 1.4, 40) * idle_ms * 1e-3, idle_ms * 1e-3 + np.arange(-40, 40) * 1e-5])
+    out = {}
+    for mode in (0, 1):
+        capi.set_option(capi.OPT_RESIDENT_CONTROL, mode)
+        capi.set_option(capi.OPT_RESIDENT_IDLE_MS, idle_ms)
+        try:
+            eng, _ = make_pair(model, K, horizon, n_oracles=0)
+            us = []
+            for t in range(n):
+                us.append(eng.control(MAP_BOUNDS, walk[t]))
+                if mode:   # (the launch path needs no pacing)
+                    t_end = time.perf_counter() + periods[t]
+                    while time.perf_counter() < t_end:
+                        pass
+            out[mode] = (np.array(us), eng.get_ut())
+            eng.close()
+        finally:
+            capi.set_option(capi.OPT_RESIDENT_CONTROL, 0)
+            capi.set_option(capi.OPT_RESIDENT_IDLE_MS, 250)
+    assert np.array_equal(out[0][0], out[1][0])
+    assert np.array_equal(out[0][1], out[1][1])
+
+
+def test_resident_stop_and_idle_option(resident):
+    """eea_resident_stop makes the server leave at once (device-wide waits are cheap again), the next call
+    starts another one with the warm start intact; EEA_OPT_RESIDENT_IDLE_MS is validated and honoured"""
+    with pytest.raises(capi.EngineError):
+        capi.set_option(capi.OPT_RESIDENT_IDLE_MS, 0)
+    with pytest.raises(capi.EngineError):
+        capi.set_option(capi.OPT_RESIDENT_IDLE_MS, 60001)
+    assert capi.lib().eea_get_option(capi.OPT_RESIDENT_IDLE_MS) == 250
+    eng, (orc,) = make_pair("omni", 10, 5.0)
+    x = np.array([1.0, 1.0, 0.3])
+    eng.resident_stop()   # nothing resident yet: EEA_OK
+    for _ in range(3):
+        u, uo = eng.control(MAP_BOUNDS, x), orc.control(MAP_BOUNDS, x)
+        assert np.abs(u - uo).max() < 1e-9
+    # resident: a device-wide wait takes until the idle time-out ...
+    capi.set_option(capi.OPT_RESIDENT_IDLE_MS, 2000)
+    try:
+        eng.resident_stop()
+        eng.control(MAP_BOUNDS, x), orc.control(MAP_BOUNDS, x)    # (a new server with the 2 s idle time)
+        eng.resident_stop()                                        # ... unless it is told to leave first
+        t0 = time.perf_counter()
+        torch.cuda.synchronize()
+        assert time.perf_counter() - t0 < 0.5
+        for _ in range(3):   # the warm start survived the stop
+            u, uo = eng.control(MAP_BOUNDS, x), orc.control(MAP_BOUNDS, x)
+            assert np.abs(u - uo).max() < 1e-8
+        eng.resident_stop()
+        eng.resident_stop()   # idempotent
+    finally:
+        capi.set_option(capi.OPT_RESIDENT_IDLE_MS, 250)
+    # a short idle time is honoured: after 3 x the idle time the server is gone and a device-wide wait returns at once
+    capi.set_option(capi.OPT_RESIDENT_IDLE_MS, 20)
+    try:
+        eng.control(MAP_BOUNDS, x), orc.control(MAP_BOUNDS, x)
+        time.sleep(0.06)
+        t0 = time.perf_counter()
+        torch.cuda.synchronize()
+        assert time.perf_counter() - t0 < 0.015
+        u, uo = eng.control(MAP_BOUNDS, x), orc.control(MAP_BOUNDS, x)
+        assert np.abs(u - uo).max() < 1e-8
+    finally:
+        capi.set_option(capi.OPT_RESIDENT_IDLE_MS, 250)
+    eng.close()
