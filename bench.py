@@ -536,8 +536,11 @@ def cpp_host_loop_leg(agents):
     out = {"driver": "ergodic_exploration_amd/host/test/consensus_bench.cpp", "agents": agents, "cases": []}
     cases = [("local exchange (no collective)", "", 1)]
     if os.path.exists(fake):
-        cases += [("collective kernel in the exchange (test double), stream-ordered", fake, 2, "12"),
+        cases += [("collective kernel in the exchange (test double), stream-ordered, ONE device graph per 48 passes "
+                   "(eea_consensus_plan)", fake, 2, "22"),
+                  ("collective kernel in the exchange (test double), stream-ordered", fake, 2, "12"),
                   ("collective kernel in the exchange (test double), one group device-bound", fake, 2, "2")]
+    cases += [("local exchange (no collective), stream-ordered, ONE device graph per 48 passes (eea_consensus_plan)", "", 2, "22")]
     for case in cases:
         name, lib, lag = case[:3]
         mode = case[3] if len(case) > 3 else "2"

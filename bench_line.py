@@ -82,12 +82,15 @@ def _exchange(ex):
         for c in cpp.get("cases", []):
             if not isinstance(c, dict):
                 continue
-            rows.append({"form": str(c.get("form") or c.get("consuming_groups", ""))[:24],
+            form = str(c.get("form") or c.get("consuming_groups", ""))
+            form = "plan" if "eea_consensus_plan" in form else ("stream-ordered" if form.startswith("all stream") else
+                                                                  ("device-bound" if form.startswith("all device") else "hybrid"))
+            rows.append({"form": form,
                          "collective_kernel": c.get("collective_kernel_in_exchange"), "lag": c.get("lag"),
                          "plain_us": _r(c.get("plain_us_per_pass"), 5), "consensus_us": _r(c.get("consensus_us_per_pass"), 5),
                          "ratio": _r(c.get("ratio"), 4), "host_us": _r(c.get("host_us_per_pass_consensus"), 4),
                          "timeouts": c.get("agents_timed_out")})
-        o["cpp_host_loop"] = rows[:4]
+        o["cpp_host_loop"] = rows[:5]
     return o
 
 

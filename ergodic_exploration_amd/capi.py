@@ -45,6 +45,11 @@ class BatchIO(C.Structure):
                 ("d_skip", C.c_void_p)]
 
 
+class ConsensusDesc(C.Structure):
+    _fields_ = [("n_groups", C.c_uint), ("group_agents", C.POINTER(C.c_uint)), ("group_io", C.POINTER(BatchIO)),
+                ("lag", C.c_uint), ("passes_per_launch", C.c_uint)]
+
+
 class TickIO(C.Structure):
     _fields_ = [("d_follow_dwa", C.c_void_p), ("d_dwa_count", C.c_void_p), ("d_u", C.c_void_p), ("d_vb", C.c_void_p),
                 ("d_grid", C.c_void_p), ("d_traj", C.c_void_p), ("d_valid", C.c_void_p), ("d_skip", C.c_void_p),
@@ -114,6 +119,14 @@ def lib():
         L.eea_ck_records_sum_bound.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p,
                                                C.c_void_p]
         L.eea_publish_record.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, C.c_void_p]
+        L.eea_stream_wait_flag.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p]
+        L.eea_consensus_plan_create.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]
+        L.eea_consensus_plan_launch.argtypes = [C.c_void_p, C.c_void_p]
+        L.eea_consensus_plan_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint), C.POINTER(C.c_void_p)]
+        L.eea_consensus_plan_destroy.argtypes = [C.c_void_p]
+        L.eea_consensus_plan_destroy.restype = None
+        L.eea_ck_records_sum_ws_bytes.argtypes = [C.c_void_p, C.c_uint, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+        L.eea_ck_records_sum_ws.argtypes = [C.c_void_p, C.c_uint, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         for name in ("eea_steps", "eea_num_modes", "eea_real_size", "eea_time_step", "eea_destroy", "eea_resident_stop"):
             getattr(L, name).argtypes = [C.c_void_p]
         L.eea_destroy.restype = None
@@ -535,6 +548,20 @@ def set_option(option, value):
     check(lib().eea_set_option(option, value))
 
 
+def stream_wait_flag(flag, seq, timeouts=None, stream=None):
+    """eea_stream_wait_flag (ABI 6): what follows on `stream` starts once *flag - seq >= 0 -- a one-wavefront gate kernel"""
+    check(lib().eea_stream_wait_flag(_ptr(flag), seq, _ptr(timeouts), C.c_void_p(stream or 0)))
+
+
+def prepared_stream_wait_flag(flag, timeouts=None, stream=None):
+    """a callable gate(seq) with the pointers converted once (a pass of 4096 agents takes ~23 us: per-pass host work counts)"""
+    fn, f, t, s = lib().eea_stream_wait_flag, _ptr(flag), _ptr(timeouts), C.c_void_p(stream or 0)
+
+    def gate(seq):
+        check(fn(f, seq, t, s))
+    return gate
+
+
 def get_option(option):
     return lib().eea_get_option(option)
 
@@ -552,6 +579,55 @@ def comm_unique_id():
     buf = C.create_string_buffer(COMM_ID_BYTES)
     check(lib().eea_comm_get_unique_id(buf))
     return buf.raw
+
+
+class ConsensusPlan:
+    """eea_consensus_plan (ABI 6): `passes_per_launch` consensus passes of a rank -- per pass and agent group one control launch
+    (records out, the sum record of pass i - lag in), the record sum and the all-reduce over the ranks -- as ONE replayable
+    device graph.  groups: a list of dicts with B, pose, ut, u0 and optionally mem_cols, n_mem, mem_stride, status, skip
+    (device tensors; the plan keeps them alive)."""
+
+    def __init__(self, eng, comm, groups, lag=2, passes_per_launch=48):
+        self.h = C.c_void_p()
+        self._keep = list(groups)
+        n = len(groups)
+        agents = (C.c_uint * n)(*[int(g["B"]) for g in groups])
+        ios = (BatchIO * n)()
+        for io, g in zip(ios, groups):
+            io.d_pose, io.d_ut, io.d_u0 = _ptr(g["pose"]), _ptr(g["ut"]), _ptr(g["u0"])
+            io.d_mem_cols, io.d_n_mem, io.mem_stride = _ptr(g.get("mem_cols")), _ptr(g.get("n_mem")), int(g.get("mem_stride", 0) or 0)
+            io.d_status, io.d_skip = _ptr(g.get("status")), _ptr(g.get("skip"))
+        d = ConsensusDesc(n, agents, ios, lag, passes_per_launch)
+        check(lib().eea_consensus_plan_create(eng.h, comm.h, C.byref(d), C.byref(self.h)))
+        passes, last = C.c_uint(), C.c_void_p()
+        check(lib().eea_consensus_plan_info(self.h, C.byref(passes), C.byref(last)))
+        self.passes_per_launch, self.d_last_sum = passes.value, last.value
+        self._launch = lib().eea_consensus_plan_launch
+
+    def launch(self, stream=None):
+        check(self._launch(self.h, C.c_void_p(stream or 0)))
+
+    def last_sum(self, eng):
+        """the sum record the last pass of a launch leaves, as a host array [eea_ck_record_len] (synchronise first)"""
+        import numpy as np
+        n = eng.ck_record_len
+        out = np.empty(n, dtype=np.float32 if eng.real_size == 4 else np.float64)
+        hip = C.CDLL("libamdhip64.so")   # (already mapped: the library links it)
+        hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        if hip.hipMemcpy(out.ctypes.data, self.d_last_sum, out.nbytes, 2) != 0:   # hipMemcpyDeviceToHost
+            raise EngineError(ERR_HIP, "hipMemcpy of the plan's sum record failed")
+        return out
+
+    def close(self):
+        if self.h:
+            lib().eea_consensus_plan_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Comm:

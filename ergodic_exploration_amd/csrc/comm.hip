@@ -14,6 +14,7 @@
 #include <rccl/rccl.h>
 
 #include <atomic>
+#include <memory>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -456,5 +457,265 @@ eea_status eea_comm_wait(eea_comm* c, int slot, void* stream)
   EEA_HIP(hipStreamWaitEvent(static_cast<hipStream_t>(stream), c->ev_done[slot], 0));
   return EEA_OK;
 }
+
+}  // extern "C"
+
+// ---- ABI 6: a stream-level wait for a device flag (the GATED exchange) --------------------------------------------------------
+// One wavefront that returns once *flag - seq >= 0 (mod 2^32), polling past the L1 with a sleep between polls, bounded like
+// wait_flag (about a second: then it counts a time-out and returns -- the launches behind it go on with whatever the record
+// holds).  Enqueued IN FRONT of a group's control launch it does what the in-kernel flag wait of the device-bound exchange
+// does, but holds ONE execution slot while it waits instead of the group's thousands: the group's half of the chip stays
+// empty until the record is there, so the collective kernel that produces it always finds room (the dead-lock of waiting
+// control wavefronts that fill every slot, profiles/r05_two_ranks.txt, cannot form), and nothing of the protocol needs an
+// event: per pass the host issues launches only (an event record + wait pair costs 4.6 us of host time on this runtime, a
+// small launch 0.7 - 2.6: tools/ubench/host_calls.hip).
+namespace
+{
+__global__ __launch_bounds__(64) void flag_gate_kernel(const unsigned* flag, unsigned seq, unsigned* timeouts)
+{
+  for (int i = 0; i < eea::kFlagPolls; ++i) {
+    const unsigned v = __builtin_amdgcn_readfirstlane(eea::load_agent(flag));
+    if (static_cast<int>(v - seq) >= 0) return;
+    __builtin_amdgcn_s_sleep(32);
+  }
+  if (timeouts != nullptr && threadIdx.x == 0) atomicAdd(timeouts, 1u);
+}
+}  // namespace
+
+extern "C" eea_status eea_stream_wait_flag(const unsigned* d_flag, unsigned seq, unsigned* d_timeouts, void* stream)
+{
+  if (d_flag == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null flag");
+  hipLaunchKernelGGL(flag_gate_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), d_flag, seq, d_timeouts);
+  EEA_HIP(hipGetLastError());
+  return EEA_OK;
+}
+
+// ---- ABI 6: the consensus loop of a rank as one replayable device graph (include/ergodic_amd.h) ----------------------------
+// `passes_per_launch` passes of the stream-ordered protocol -- per pass: the groups' control launches (records out, the sum
+// record of pass i - lag in), then on the exchange branch the record sum (caller-owned workspace: eea_ck_records_sum_ws) and the
+// all-reduce over the ranks -- captured ONCE from an exchange stream of the plan's own (the origin) + the group streams, and replayed with
+// one hipGraphLaunch.  Dependencies inside a launch are the captured events; across launches the device serialises the
+// launches of one executable graph, which is why the first `lag` passes of the capture carry no wait for "their" exchange (it
+// ran in the launch before).  Slot rotation is periodic in the launch (passes_per_launch % slots == 0).
+struct eea_consensus_plan
+{
+  eea_engine* e = nullptr;
+  eea_comm* c = nullptr;
+  int device = 0;
+  unsigned n_groups = 0, lag = 0, slots = 0, passes = 0, B = 0, rec_len = 0;
+  size_t rs = 8;
+  std::vector<unsigned> agents, first;
+  std::vector<eea_batch_io> io;
+  std::vector<hipStream_t> gstreams;
+  hipStream_t xs = nullptr;
+  std::vector<hipEvent_t> ev_group;  // [n_groups]: a group's launch of the pass being captured
+  std::vector<hipEvent_t> ev_x;      // [slots]: the exchange of the pass that wrote the slot
+  hipEvent_t ev_fork = nullptr;
+  void* d_arec = nullptr;     // [slots][B][rec_len]
+  void* d_sum = nullptr;      // [slots][rec_len]
+  void* d_ws = nullptr;       // [slots] record-sum workspaces
+  void* d_tickets = nullptr;  // [slots]
+  size_t ws_bytes = 0, ticket_bytes = 0;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+namespace
+{
+void plan_release(eea_consensus_plan* p)
+{
+  if (p == nullptr) return;
+  (void)hipSetDevice(p->device);
+  if (p->exec) (void)hipGraphExecDestroy(p->exec);
+  if (p->graph) (void)hipGraphDestroy(p->graph);
+  for (hipStream_t s : p->gstreams) {
+    if (s) {
+      (void)hipStreamSynchronize(s);
+      (void)hipStreamDestroy(s);
+    }
+  }
+  if (p->xs) {
+    (void)hipStreamSynchronize(p->xs);
+    (void)hipStreamDestroy(p->xs);
+  }
+  for (hipEvent_t ev : p->ev_group) {
+    if (ev) (void)hipEventDestroy(ev);
+  }
+  for (hipEvent_t ev : p->ev_x) {
+    if (ev) (void)hipEventDestroy(ev);
+  }
+  if (p->ev_fork) (void)hipEventDestroy(p->ev_fork);
+  for (void* q : { p->d_arec, p->d_sum, p->d_ws, p->d_tickets }) {
+    if (q) (void)hipFree(q);
+  }
+  delete p;
+}
+
+// the passes of one launch, enqueued on the plan's streams inside a capture that began on the EXCHANGE stream.
+// The exchange stream is the capture's origin on purpose: this HIP runtime (ROCm 7) re-parents every NON-origin stream that
+// waits for a captured event to the event's stream and lists it there as a "parallel capture stream", every time -- two
+// non-origin streams that wait for each other's events (a group stream for the exchange, the exchange stream for the group)
+// become each other's children and hipStreamEndCapture recurses for ever (found the hard way: a 174 000-frame stack).  With
+// the exchange stream as the origin every wait is between the origin and a group stream, never between two group streams.
+eea_status plan_enqueue(eea_consensus_plan* p)
+{
+  char* const arec = static_cast<char*>(p->d_arec);
+  char* const sum = static_cast<char*>(p->d_sum);
+  const size_t rec_bytes = p->rs * p->rec_len;
+  // fork: the group streams join the capture behind the origin
+  EEA_HIP(hipEventRecord(p->ev_fork, p->xs));
+  for (unsigned g = 0; g < p->n_groups; ++g) EEA_HIP(hipStreamWaitEvent(p->gstreams[g], p->ev_fork, 0));
+  for (unsigned i = 0; i < p->passes; ++i) {
+    const unsigned slot = i % p->slots, src = (i + p->slots - p->lag) % p->slots;
+    for (unsigned g = 0; g < p->n_groups; ++g) {
+      // the sum record this pass consumes is complete: the exchange of pass i - lag (of the launch before for i < lag --
+      // ordered by the device's serialisation of the launches, no captured dependency)
+      if (i >= p->lag) EEA_HIP(hipStreamWaitEvent(p->gstreams[g], p->ev_x[src], 0));
+      eea_batch_io io = p->io[g];
+      io.d_ck_rec = arec + (static_cast<size_t>(slot) * p->B + p->first[g]) * rec_bytes;
+      io.d_ck_shared = sum + static_cast<size_t>(src) * rec_bytes;
+      io.ck_shared_parts = 1;
+      const eea_status st = eea_control_batch(p->e, p->agents[g], &io, p->gstreams[g]);
+      if (st != EEA_OK) return st;
+      EEA_HIP(hipEventRecord(p->ev_group[g], p->gstreams[g]));
+      EEA_HIP(hipStreamWaitEvent(p->xs, p->ev_group[g], 0));
+    }
+    void* const s_slot = sum + static_cast<size_t>(slot) * rec_bytes;
+    eea_status st = eea_ck_records_sum_ws(p->e, p->B, arec + static_cast<size_t>(slot) * p->B * rec_bytes, s_slot,
+                                          static_cast<char*>(p->d_ws) + static_cast<size_t>(slot) * p->ws_bytes,
+                                          static_cast<char*>(p->d_tickets) + static_cast<size_t>(slot) * p->ticket_bytes, p->xs);
+    if (st != EEA_OK) return st;
+    st = eea_comm_allreduce_sum(p->e, p->c, s_slot, p->rec_len, p->xs);  // (nothing without an RCCL communicator)
+    if (st != EEA_OK) return st;
+    EEA_HIP(hipEventRecord(p->ev_x[slot], p->xs));
+  }
+  // join: the origin ends behind every group stream (its own last node is the last exchange, which follows the last launches)
+  for (unsigned g = 0; g < p->n_groups; ++g) {
+    EEA_HIP(hipEventRecord(p->ev_group[g], p->gstreams[g]));
+    EEA_HIP(hipStreamWaitEvent(p->xs, p->ev_group[g], 0));
+  }
+  return EEA_OK;
+}
+}  // namespace
+
+extern "C" {
+
+eea_status eea_consensus_plan_create(eea_engine* e, eea_comm* c, const eea_consensus_desc* d, eea_consensus_plan** out)
+{
+  if (out == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  *out = nullptr;
+  if (e == nullptr || c == nullptr || d == nullptr || d->group_agents == nullptr || d->group_io == nullptr) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  }
+  if (d->n_groups < 1 || d->n_groups > eea_comm::kMaxGroups) return fail(EEA_ERR_INVALID_ARGUMENT, "1 .. 8 agent groups");
+  if (d->lag < 1 || d->lag + 2 > EEA_COMM_SLOTS) return fail(EEA_ERR_INVALID_ARGUMENT, "lag must be in 1 .. EEA_COMM_SLOTS - 2");
+  if (d->passes_per_launch < 1 || d->passes_per_launch > 4096) return fail(EEA_ERR_INVALID_ARGUMENT, "passes_per_launch in 1 .. 4096");
+  std::unique_ptr<eea_consensus_plan, void (*)(eea_consensus_plan*)> p(new eea_consensus_plan(), plan_release);
+  p->e = e;
+  p->c = c;
+  p->device = c->device;
+  p->n_groups = d->n_groups;
+  p->lag = d->lag;
+  p->slots = d->lag + 2;
+  p->passes = (d->passes_per_launch + p->slots - 1) / p->slots * p->slots;
+  p->rec_len = eea_ck_record_len(e);
+  p->rs = eea_real_size(e);
+  for (unsigned g = 0; g < d->n_groups; ++g) {
+    const eea_batch_io& io = d->group_io[g];
+    if (d->group_agents[g] == 0 || io.d_pose == nullptr || io.d_ut == nullptr || io.d_u0 == nullptr) {
+      return fail(EEA_ERR_INVALID_ARGUMENT, "every group needs agents, d_pose, d_ut and d_u0");
+    }
+    p->first.push_back(p->B);
+    p->agents.push_back(d->group_agents[g]);
+    p->B += d->group_agents[g];
+    eea_batch_io mine = io;  // the exchange fields are the plan's
+    mine.d_ck_shared = nullptr;
+    mine.d_ck_rec = nullptr;
+    mine.ck_shared_parts = 0;
+    mine.d_rec_ready = nullptr;
+    mine.rec_seq = 0;
+    mine.d_ck_flag = nullptr;
+    mine.ck_flag_seq = 0;
+    p->io.push_back(mine);
+  }
+  EEA_HIP(hipSetDevice(p->device));
+  // phi_k of a rebuild that is still enqueued is complete before anything is captured (a capture must not wait for an
+  // event of the world outside it)
+  {
+    std::vector<double> phik(eea_num_modes(e));
+    const eea_status st = eea_get_phik(e, phik.data());
+    if (st != EEA_OK) return st;
+  }
+  eea_status st = eea_ck_records_sum_ws_bytes(e, p->B, &p->ws_bytes, &p->ticket_bytes);
+  if (st != EEA_OK) return st;
+  p->ws_bytes = (p->ws_bytes + 255) / 256 * 256;
+  p->ticket_bytes = (p->ticket_bytes + 255) / 256 * 256;
+  const size_t rec_bytes = p->rs * p->rec_len;
+  EEA_HIP(hipMalloc(&p->d_arec, static_cast<size_t>(p->slots) * p->B * rec_bytes));
+  EEA_HIP(hipMalloc(&p->d_sum, static_cast<size_t>(p->slots) * rec_bytes));
+  EEA_HIP(hipMalloc(&p->d_ws, static_cast<size_t>(p->slots) * p->ws_bytes));
+  EEA_HIP(hipMalloc(&p->d_tickets, static_cast<size_t>(p->slots) * p->ticket_bytes));
+  // empty sum records (agent count 0: the first `lag` passes keep their own c_k), zeroed tickets
+  EEA_HIP(hipMemset(p->d_arec, 0, static_cast<size_t>(p->slots) * p->B * rec_bytes));
+  EEA_HIP(hipMemset(p->d_sum, 0, static_cast<size_t>(p->slots) * rec_bytes));
+  EEA_HIP(hipMemset(p->d_tickets, 0, static_cast<size_t>(p->slots) * p->ticket_bytes));
+  int least = 0, greatest = 0;
+  EEA_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+  p->gstreams.assign(p->n_groups, nullptr);
+  for (unsigned g = 0; g < p->n_groups; ++g) EEA_HIP(hipStreamCreateWithFlags(&p->gstreams[g], hipStreamNonBlocking));
+  EEA_HIP(hipStreamCreateWithPriority(&p->xs, hipStreamNonBlocking, greatest));
+  p->ev_group.assign(p->n_groups, nullptr);
+  for (unsigned g = 0; g < p->n_groups; ++g) EEA_HIP(hipEventCreateWithFlags(&p->ev_group[g], kDeviceEvent));
+  p->ev_x.assign(p->slots, nullptr);
+  for (unsigned s = 0; s < p->slots; ++s) EEA_HIP(hipEventCreateWithFlags(&p->ev_x[s], kDeviceEvent));
+  EEA_HIP(hipEventCreateWithFlags(&p->ev_fork, kDeviceEvent));
+  if (c->comm != nullptr) {
+    // the collective library's first call on a communicator sets up its own state (buffers, proxy): outside the capture,
+    // on the empty sum record of slot 0 (zeros stay zeros; every rank makes this call in plan_create)
+    st = eea_comm_allreduce_sum(e, c, p->d_sum, p->rec_len, p->xs);
+    if (st != EEA_OK) return st;
+    EEA_HIP(hipStreamSynchronize(p->xs));
+  }
+  EEA_HIP(hipDeviceSynchronize());
+  // capture (relaxed mode: other threads of the process may be making runtime calls of their own)
+  hipError_t he = hipStreamBeginCapture(p->xs, hipStreamCaptureModeRelaxed);
+  if (he != hipSuccess) return fail(EEA_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(he));
+  st = plan_enqueue(p.get());
+  const std::string why = st != EEA_OK ? std::string(eea_last_error()) : std::string();
+  he = hipStreamEndCapture(p->xs, &p->graph);
+  if (st != EEA_OK || he != hipSuccess || p->graph == nullptr) {
+    (void)hipGetLastError();
+    return fail(st == EEA_ERR_INVALID_ARGUMENT ? st : EEA_ERR_UNSUPPORTED,
+                "the consensus passes could not be captured into a graph (" +
+                    (st != EEA_OK ? why : std::string(hipGetErrorString(he))) + "): use the per-call exchange");
+  }
+  he = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
+  if (he != hipSuccess) {
+    (void)hipGetLastError();
+    return fail(EEA_ERR_UNSUPPORTED, std::string("hipGraphInstantiate: ") + hipGetErrorString(he));
+  }
+  *out = p.release();
+  return EEA_OK;
+}
+
+eea_status eea_consensus_plan_launch(eea_consensus_plan* p, void* stream)
+{
+  if (p == nullptr || p->exec == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null plan");
+  EEA_HIP(hipSetDevice(p->device));
+  EEA_HIP(hipGraphLaunch(p->exec, static_cast<hipStream_t>(stream)));
+  return EEA_OK;
+}
+
+eea_status eea_consensus_plan_info(const eea_consensus_plan* p, unsigned* passes_per_launch, const void** d_last_sum)
+{
+  if (p == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null plan");
+  if (passes_per_launch) *passes_per_launch = p->passes;
+  if (d_last_sum) {
+    *d_last_sum = static_cast<const char*>(p->d_sum) + static_cast<size_t>((p->passes - 1) % p->slots) * p->rs * p->rec_len;
+  }
+  return EEA_OK;
+}
+
+void eea_consensus_plan_destroy(eea_consensus_plan* p) { plan_release(p); }
 
 }  // extern "C"

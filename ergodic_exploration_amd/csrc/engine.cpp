@@ -1363,6 +1363,35 @@ eea_status eea_ck_records_sum(eea_engine* e, unsigned B, const void* d_ck_rec, v
   return records_sum_impl(e, B, d_ck_rec, d_sum, stream, nullptr, 0u, nullptr);
 }
 
+eea_status eea_ck_records_sum_ws_bytes(const eea_engine* e, unsigned B, size_t* ws_bytes, size_t* ticket_bytes)
+{
+  if (check_engine(e) != EEA_OK || B == 0) return fail(EEA_ERR_INVALID_ARGUMENT, "null engine / B == 0");
+  if (ws_bytes) *ws_bytes = (e->f32 ? sizeof(float) : sizeof(double)) * eea::ck_sum_ws_elems(B, e->K2);
+  if (ticket_bytes) *ticket_bytes = sizeof(unsigned) * eea::ck_sum_tickets(B, e->K2);
+  return EEA_OK;
+}
+
+// the plain record sum with a caller-owned workspace: no allocation, no cache look-up, nothing but the launch (capturable)
+eea_status eea_ck_records_sum_ws(eea_engine* e, unsigned B, const void* d_ck_rec, void* d_sum, void* d_ws, void* d_tickets,
+                                 void* stream)
+{
+  if (check_engine(e) != EEA_OK) return EEA_ERR_INVALID_ARGUMENT;
+  if (d_ck_rec == nullptr || d_sum == nullptr || d_ws == nullptr || d_tickets == nullptr || B == 0) {
+    return fail(EEA_ERR_INVALID_ARGUMENT, "d_ck_rec, d_sum, d_ws, d_tickets and B > 0 are required");
+  }
+  eea_status st = use_device(e);
+  if (st != EEA_OK) return st;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (e->f32) {
+    EEA_HIP(eea::launch_ck_records_sum<float>(static_cast<const float*>(d_ck_rec), B, e->K2, static_cast<float*>(d_ws),
+                                              static_cast<unsigned*>(d_tickets), static_cast<float*>(d_sum), s, nullptr, 0u, nullptr));
+  } else {
+    EEA_HIP(eea::launch_ck_records_sum<double>(static_cast<const double*>(d_ck_rec), B, e->K2, static_cast<double*>(d_ws),
+                                               static_cast<unsigned*>(d_tickets), static_cast<double*>(d_sum), s, nullptr, 0u, nullptr));
+  }
+  return EEA_OK;
+}
+
 eea_status eea_ck_records_sum_bound(eea_engine* e, unsigned B, const void* d_ck_rec, const unsigned* d_rec_ready, unsigned seq,
                                     void* d_sum, unsigned* d_flag, void* stream)
 {

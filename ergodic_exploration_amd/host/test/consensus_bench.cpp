@@ -21,7 +21,10 @@
 // every group device-bound anyway (what times out, for the record).
 //
 // groups per rank: 1 / 2; negative = every group device-bound whatever the communicator; 12 (11) = two (one) groups with the
-// STREAM-ORDERED exchange (eea_comm_records_exchange_async + eea_comm_wait): nothing waits inside a kernel.
+// STREAM-ORDERED exchange (eea_comm_records_exchange_async + eea_comm_wait): nothing waits inside a kernel; 22 (21) = the same
+// protocol as ONE replayable device graph (eea_consensus_plan, ABI 6: 48 passes per launch): one runtime call per 48 passes;
+// 32 (31) = the GATED exchange (ABI 6): the device-bound exchange with the flag wait as a one-wavefront gate kernel in front of
+// each group's launch (eea_stream_wait_flag) instead of inside it -- launches only, safe with a collective kernel.
 // usage: consensus_bench [passes = 4000] [agents = 4096] [ranks = 1] [collective library path] [lag = 1] [groups per rank = 2]
 // last line of the output: RESULT {json}
 #include <atomic>
@@ -84,6 +87,8 @@ struct Rank
   int groups = 2;
   bool last_group_stream_ordered = false;  // more than one rank: the collective kernel needs a group's slots to land in
   bool stream_ordered = false;             // every group consumes behind the exchange's event; nothing waits on the device
+  bool gated = false;                      // device-bound records / sum / flag, the flag wait as a gate kernel in front of the launch
+  unsigned* d_gate_timeouts = nullptr;
   unsigned seq = 0;
 
   void setup(unsigned agents, unsigned first_agent, int nranks, int rank, const char* id, int n_groups)
@@ -129,6 +134,7 @@ struct Rank
     d_status = dev<int>(n);
     d_ready = dev<unsigned>(n);
     d_flag = dev<unsigned>(1);
+    d_gate_timeouts = dev<unsigned>(1);
     for (int s = 0; s < NB; ++s) {
       d_arec[s] = dev<double>(static_cast<size_t>(L) * n);
       d_sum[s] = dev<double>(L);
@@ -140,9 +146,11 @@ struct Rank
   }
 
   // `count` passes enqueued back to back, then this rank's streams drained; returns seconds per pass
+  double t_gate = 0.0, t_ctrl = 0.0, t_xchg = 0.0;  // host time inside the gate / control / exchange calls of the last run()
   double run(bool consensus, int lag, int count, double* host_share)
   {
     double in_calls = 0.0;
+    t_gate = t_ctrl = t_xchg = 0.0;
     const unsigned gb[3] = { 0, groups == 2 ? n / 2 : n, n };
     const double t0 = now();
     for (int i = 0; i < count; ++i) {
@@ -170,7 +178,13 @@ struct Rank
           io.d_ck_rec = d_arec[slot] + static_cast<size_t>(L) * first;
           io.d_rec_ready = d_ready + first;
           io.rec_seq = seq;
-          if (i >= lag) {
+          if (i >= lag && gated) {
+            io.d_ck_shared = d_sum[src];
+            io.ck_shared_parts = 1;
+            const double g0 = now();
+            ok(eea_stream_wait_flag(d_flag, seq - static_cast<unsigned>(lag), d_gate_timeouts, streams[g]), "eea_stream_wait_flag");
+            t_gate += now() - g0;
+          } else if (i >= lag) {
             io.d_ck_shared = d_sum[src];
             io.ck_shared_parts = 1;
             io.d_ck_flag = d_flag;
@@ -179,20 +193,64 @@ struct Rank
             if (last_group_stream_ordered && g == groups - 1) ok(eea_comm_wait(c, src, streams[g]), "eea_comm_wait");
           }
         }
+        const double c0 = now();
         ok(eea_control_batch(e, cnt, &io, streams[g]), "eea_control_batch");
+        t_ctrl += now() - c0;
       }
+      const double x0 = now();
       if (consensus && stream_ordered) {
         void* gs[2] = { streams[0], streams[1] };
         ok(eea_comm_records_exchange_async(e, c, n, d_arec[slot], d_sum[slot], gs, static_cast<unsigned>(groups), slot), "exchange (stream-ordered)");
       } else if (consensus) {
         ok(eea_comm_records_exchange_bound(e, c, n, d_arec[slot], d_ready, seq, d_sum[slot], d_flag, slot), "exchange");
       }
+      t_xchg += now() - x0;
       in_calls += now() - h0;
     }
     for (int g = 0; g < groups; ++g) ok(hipStreamSynchronize(streams[g]), "sync");
     const double dt = now() - t0;
     if (host_share) *host_share = in_calls / count;
     return dt / count;
+  }
+
+  // the stream-ordered protocol as a replayable device graph (eea_consensus_plan): `count` passes in launches of `per`
+  eea_consensus_plan* plan = nullptr;
+  unsigned plan_passes = 0;
+  double run_plan(int lag, int per, int count, double* host_share)
+  {
+    if (plan == nullptr) {
+      const unsigned gb[3] = { 0, groups == 2 ? n / 2 : n, n };
+      unsigned cnt[2];
+      eea_batch_io io[2] = {};
+      for (int g = 0; g < groups; ++g) {
+        cnt[g] = gb[g + 1] - gb[g];
+        io[g].d_pose = d_pose + 3 * gb[g];
+        io[g].d_ut = d_ut + static_cast<size_t>(3) * T * gb[g];
+        io[g].d_u0 = d_u0 + 3 * gb[g];
+        io[g].d_status = d_status + gb[g];
+      }
+      eea_consensus_desc d{};
+      d.n_groups = static_cast<unsigned>(groups);
+      d.group_agents = cnt;
+      d.group_io = io;
+      d.lag = static_cast<unsigned>(lag);
+      d.passes_per_launch = static_cast<unsigned>(per);
+      ok(eea_consensus_plan_create(e, c, &d, &plan), "eea_consensus_plan_create");
+      ok(eea_consensus_plan_info(plan, &plan_passes, nullptr), "eea_consensus_plan_info");
+    }
+    const int launches = (count + static_cast<int>(plan_passes) - 1) / static_cast<int>(plan_passes);
+    double in_calls = 0.0;
+    const double t0 = now();
+    for (int i = 0; i < launches; ++i) {
+      const double h0 = now();
+      ok(eea_consensus_plan_launch(plan, streams[0]), "eea_consensus_plan_launch");
+      in_calls += now() - h0;
+    }
+    ok(hipStreamSynchronize(streams[0]), "sync");
+    const double dt = now() - t0;
+    const double passes = static_cast<double>(launches) * plan_passes;
+    if (host_share) *host_share = in_calls / passes;
+    return dt / passes;
   }
 
   int timed_out()
@@ -203,7 +261,9 @@ struct Rank
     ok(hipMemcpy(st.data(), d_status, sizeof(int) * n, hipMemcpyDeviceToHost), "status");
     int bad = 0;
     for (int v : st) bad += v != 0;
-    return bad;
+    unsigned gate_timeouts = 0;
+    ok(hipMemcpy(&gate_timeouts, d_gate_timeouts, sizeof(unsigned), hipMemcpyDeviceToHost), "gate time-outs");
+    return bad + static_cast<int>(gate_timeouts);
   }
 };
 
@@ -260,7 +320,7 @@ int main(int argc, char** argv)
   // the STREAM-ORDERED exchange (nothing waits on the device)
   const int garg = argc > 6 ? std::atoi(argv[6]) : 2;
   const int groups = std::abs(garg) % 10;
-  const bool all_bound = garg < 0, stream_ordered = garg >= 10;
+  const bool all_bound = garg < 0, as_gated = garg >= 30, stream_ordered = garg >= 10 && !as_gated, as_plan = garg >= 20 && !as_gated;
   const bool child = argc > 9 && std::strcmp(argv[7], "child") == 0;
   if (nranks < 1 || nranks > 8 || lag < 1 || lag + 2 > NB || passes < 10 || groups < 1 || groups > 2 || (nranks > 1 && lib.empty() && false)) {
     std::fprintf(stderr, "usage: consensus_bench [passes] [agents] [ranks 1..8] [collective library] [lag 1..%d] [groups 1..2]\n", NB - 2);
@@ -301,7 +361,8 @@ int main(int argc, char** argv)
   Rank rk;
   const unsigned first = agents * rank / nranks, n = agents * (rank + 1) / nranks - first;
   rk.setup(n, first, nranks, rank, with_collective ? id : nullptr, groups);
-  rk.last_group_stream_ordered = with_collective && !all_bound && !stream_ordered;
+  rk.last_group_stream_ordered = with_collective && !all_bound && !stream_ordered && !as_gated;
+  rk.gated = as_gated;
   rk.stream_ordered = stream_ordered;
   double host_plain = 0.0, host_cons = 0.0;
   barrier();
@@ -309,10 +370,14 @@ int main(int argc, char** argv)
   barrier();
   const double plain = rk.run(false, lag, passes, &host_plain);
   barrier();
-  rk.run(true, lag, passes < 200 ? passes : 200, nullptr);
+  const int plan_per = std::getenv("CONSENSUS_PLAN_PASSES") ? std::atoi(std::getenv("CONSENSUS_PLAN_PASSES")) : 48;
+  if (as_plan) rk.run_plan(lag, plan_per, 200, nullptr);
+  else rk.run(true, lag, passes < 200 ? passes : 200, nullptr);
   barrier();
   double cons = 0.0;
-  if (const char* ch = std::getenv("CONSENSUS_BENCH_CHUNK")) {
+  if (as_plan) {
+    cons = rk.run_plan(lag, plan_per, passes, &host_cons);
+  } else if (const char* ch = std::getenv("CONSENSUS_BENCH_CHUNK")) {
     // diagnosis: the timed run in chunks (each drained), with the chunk's time and the agents that have timed out so far
     const int chunk = std::atoi(ch);
     for (int done = 0; done < passes; done += chunk) {
@@ -324,6 +389,10 @@ int main(int argc, char** argv)
     cons = rk.run(true, lag, passes, &host_cons);
   }
   barrier();
+  if (!as_plan && std::getenv("CONSENSUS_BENCH_BREAKDOWN")) {
+    std::printf("  host time per consensus pass: gates %.2f us, control calls %.2f us, exchange call %.2f us\n", 1e6 * rk.t_gate / passes,
+                1e6 * rk.t_ctrl / passes, 1e6 * rk.t_xchg / passes);
+  }
   const int bad = rk.timed_out();
   // the test double counts the blocks of its collective kernels that gave up waiting for another rank
   int collective_errors = -1;
@@ -353,6 +422,7 @@ int main(int argc, char** argv)
   }
   const int rc = (timed_out == 0 && collective_errors <= 0) ? 0 : 2;
   if (rank != 0) {
+    if (rk.plan) eea_consensus_plan_destroy(rk.plan);
     eea_comm_destroy(rk.c);
     eea_destroy(rk.e);
     return rc;
@@ -367,14 +437,17 @@ int main(int argc, char** argv)
                 1e6 * graphed, passes / 50);
   }
   std::printf("  consensus every pass, lag %d (%s)  %6.2f us per pass   (host inside the calls: %5.2f us per pass)   = %.3f x plain; agents timed out: %d%s\n",
-              lag, stream_ordered ? "stream-ordered" : "bound", 1e6 * c, 1e6 * hc, c / p, timed_out,
+              lag, as_gated ? "gated" : (as_plan ? "stream-ordered, one graph of 48 passes" : (stream_ordered ? "stream-ordered" : "bound")), 1e6 * c, 1e6 * hc, c / p, timed_out,
               with_collective ? (collective_errors == 0 ? "; collective kernels: none gave up" : "; collective kernels gave up or count unavailable") : "");
   std::printf("RESULT {\"agents\": %u, \"ranks\": %d, \"collective_kernel_in_exchange\": %s, \"consuming_groups\": \"%s\", \"groups_per_rank\": %d, \"lag\": %d, \"passes\": %d, \"plain_us_per_pass\": %.3f, \"consensus_us_per_pass\": %.3f, "
               "\"ratio\": %.4f, \"host_us_per_pass_plain\": %.3f, \"host_us_per_pass_consensus\": %.3f, \"agents_timed_out\": %d, "
               "\"collective_kernel_timeouts\": %d, \"graph_us_per_pass\": %.3f}\n",
-              agents, nranks, with_collective ? "true" : "false", rk.stream_ordered ? "all stream-ordered (eea_comm_records_exchange_async + eea_comm_wait)"
+              agents, nranks, with_collective ? "true" : "false", as_gated ? "all gated (eea_stream_wait_flag in front of every consuming launch)"
+              : as_plan ? "all stream-ordered, replayed as one device graph (eea_consensus_plan)"
+              : rk.stream_ordered ? "all stream-ordered (eea_comm_records_exchange_async + eea_comm_wait)"
                                                          : (rk.last_group_stream_ordered ? "one device-bound, one stream-ordered" : "all device-bound"),
               groups, lag, passes, 1e6 * p, 1e6 * c, c / p, 1e6 * hp, 1e6 * hc, timed_out, collective_errors, 1e6 * graphed);
+  if (rk.plan) eea_consensus_plan_destroy(rk.plan);
   eea_comm_destroy(rk.c);
   eea_destroy(rk.e);
   return rc;

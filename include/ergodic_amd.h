@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define EEA_ABI_VERSION 5
+#define EEA_ABI_VERSION 6
 
 /* models usable with ErgodicControl (Cart/Mecanum cannot run under it) */
 enum { EEA_MODEL_OMNI = 0,        /* models::Omni        models/omni.hpp:164-215 */
@@ -252,6 +252,13 @@ unsigned eea_ck_record_len(const eea_engine* e);
  * compute streams: the wavefronts use no LDS and <= 32 registers and are resident BESIDE a full fp64 K <= 10 control
  * kernel).  Concurrent calls on one engine must use distinct d_sum buffers. */
 eea_status eea_ck_records_sum(eea_engine* e, unsigned B, const void* d_ck_rec, void* d_sum, void* stream);
+/* ABI 6: the same sum with a CALLER-OWNED workspace -- d_ws (eea_ck_records_sum_ws_bytes: *ws_bytes) and d_tickets (*ticket_bytes,
+ * zeroed once; the tickets reset themselves) -- instead of the engine's per-d_sum workspace cache: nothing is allocated or
+ * looked up in the call, so it can be captured into a hipGraph and replayed for as long as the caller keeps the buffers
+ * (eea_consensus_plan below does).  Same summation tree, same bits. */
+eea_status eea_ck_records_sum_ws_bytes(const eea_engine* e, unsigned B, size_t* ws_bytes, size_t* ticket_bytes);
+eea_status eea_ck_records_sum_ws(eea_engine* e, unsigned B, const void* d_ck_rec, void* d_sum, void* d_ws, void* d_tickets,
+                                 void* stream);
 /* ABI 4, device-bound form: the same sum, but the launch does not have to be ordered behind the control kernels that
  * write the records -- every unit of the sum polls the ready marks of its 32 agents (d_rec_ready[b] - seq >= 0 mod 2^32,
  * eea_batch_io::d_rec_ready / rec_seq of the producing calls) and starts when they are there.  d_flag != NULL: *d_flag = seq
@@ -370,6 +377,52 @@ eea_status eea_comm_records_exchange_async(eea_engine* e, eea_comm* c, unsigned 
  * exchanges WITHOUT a collective kernel (one rank / a local communicator). */
 eea_status eea_comm_records_exchange_bound(eea_engine* e, eea_comm* c, unsigned B_local, const void* d_ck_rec,
                                            const unsigned* d_rec_ready, unsigned seq, void* d_sum, unsigned* d_flag, int slot);
+/* ---- ABI 6: the GATED exchange -- the device-bound exchange with the flag wait in front of the launch, not inside it -------
+ * eea_stream_wait_flag enqueues a one-wavefront kernel on `stream` that returns once *d_flag - seq >= 0 (mod 2^32); what is
+ * enqueued behind it on that stream starts after it.  A consensus pass of an agent group is then
+ *     eea_stream_wait_flag(d_flag, seq - lag, .., group stream)           the sum record of pass i - lag is published
+ *     eea_control_batch(.. d_ck_rec, d_rec_ready, rec_seq = seq, d_ck_shared = that record, ck_shared_parts = 1; NO d_ck_flag ..)
+ * and once per pass eea_comm_records_exchange_bound(.., seq, d_sum, d_flag, slot).  Launches only: no event, no stream wait,
+ * no host wait (an event record + wait pair costs the host 4.6 us on this runtime, a small launch 0.7 - 2.6).  Unlike the
+ * in-kernel wait (eea_batch_io::d_ck_flag) the waiting group holds ONE execution slot, not its half of the chip: the
+ * collective kernel of an RCCL communicator always finds room, so this form is safe WITH a communicator at a lag >= 2 (every
+ * wait is still for work enqueued before the waiter).  Bounded: after about a second the gate gives up, adds 1 to *d_timeouts
+ * (optional) and lets the stream go on -- the consuming launches then read whatever the record's slot holds at that moment: a
+ * time-out is an error to be reported (the producer never became resident), not a mode of operation.  No reference counterpart. */
+eea_status eea_stream_wait_flag(const unsigned* d_flag, unsigned seq, unsigned* d_timeouts, void* stream);
+
+/* ---- ABI 6: the consensus loop of a rank as ONE replayable device graph ----------------------------------------------------
+ * The stream-ordered exchange above costs the host ~6 C-ABI calls and ~11 runtime calls per pass (two group launches, their
+ * eea_comm_wait, eea_comm_records_exchange_async): 35-40 us of host time per 23 us pass (profiles/r05_exchange_modes.txt) -- the
+ * host, not xGMI, limits a consensus on every pass.  A plan captures `passes_per_launch` consecutive passes of that SAME protocol
+ * -- per pass and agent group one eea_control_batch (records out, the sum record of pass i - lag in: ck_shared_parts = 1), then
+ * on the exchange branch the record sum and the all-reduce over the ranks (nothing without an RCCL communicator) -- into one
+ * hipGraph; eea_consensus_plan_launch replays it with ONE runtime call.  Nothing waits inside a kernel (the rule of
+ * eea_comm_records_exchange_bound for exchanges with a collective kernel holds by construction); lag >= 2 keeps the collective
+ * off the critical path of a pass.  The plan owns the record / sum buffers (lag + 2 slots, rotating), the record sum's
+ * workspaces, the group streams and events; the caller owns what eea_batch_io names (d_pose, d_ut, d_u0, optional d_mem_cols /
+ * d_n_mem / mem_stride, d_status, d_skip per group: the exchange fields of group_io are ignored) and may rewrite the CONTENTS of
+ * those buffers between launches (new poses), not the pointers.  Across launches the protocol continues: pass 0 of a launch
+ * consumes the record of the last passes of the launch before (the first `lag` passes ever consume an empty record: own c_k).
+ * With several ranks every rank creates and launches its plan the same number of times (the all-reduces pair up in order).
+ * EEA_ERR_UNSUPPORTED: the collective library cannot be captured -- use the per-call form.  No reference counterpart
+ * (decentralised ergodic control shares c_k, README.md:225-227). */
+typedef struct eea_consensus_plan eea_consensus_plan;
+typedef struct eea_consensus_desc {
+  unsigned n_groups;             /* 1 .. 8 agent groups (contiguous slices of the rank's batch), each on a stream of its own */
+  const unsigned* group_agents;  /* [n_groups] agents per group */
+  const eea_batch_io* group_io;  /* [n_groups] the groups' buffers */
+  unsigned lag;                  /* pass i consumes the sum record of pass i - lag: 1 .. EEA_COMM_SLOTS - 2 */
+  unsigned passes_per_launch;    /* passes one launch replays; rounded UP to a multiple of the slot count lag + 2 */
+} eea_consensus_desc;
+eea_status eea_consensus_plan_create(eea_engine* e, eea_comm* c, const eea_consensus_desc* d, eea_consensus_plan** out);
+/* replays the plan's passes, asynchronous on `stream`; launch a plan on ONE stream (its launches must run in order) */
+eea_status eea_consensus_plan_launch(eea_consensus_plan* p, void* stream);
+/* passes one launch replays (after rounding), and the device address of the sum record [eea_ck_record_len] the LAST pass of a
+ * launch leaves (sum over all ranks of the agents' c_k, element K^2 = agent count); either pointer may be NULL */
+eea_status eea_consensus_plan_info(const eea_consensus_plan* p, unsigned* passes_per_launch, const void** d_last_sum);
+void eea_consensus_plan_destroy(eea_consensus_plan* p);
+
 /* in-place ncclAllReduce(sum) of n reals: the K^2 partial sums of a grid-tiled phi_k
  * (eea_spatial_coeff_rows / eea_spatial_coeff_occupancy_rows) */
 eea_status eea_comm_allreduce_sum(eea_engine* e, eea_comm* c, void* d_buf, unsigned n, void* stream);

@@ -17,7 +17,7 @@ def test_library_exports_every_declared_symbol():
     assert len(syms) >= 25
     missing = [s for s in syms if not hasattr(L, s)]
     assert missing == []
-    assert capi.lib().eea_abi_version() == 5
+    assert capi.lib().eea_abi_version() == 6
 
 
 def test_library_exports_only_the_documented_abi():
