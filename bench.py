@@ -502,20 +502,60 @@ def tick_legs(torch, capi, np):
                                          0.1, 0.5, source=d_src, grid_epoch=7, stream=sp)
     us_cached = timed(tick_cached, 200)
     ctl = timed(lambda: eng.control_batch(B, d_pose, d_ut, d_u, stream=sp), 200)
+    # the same loop with the robots MOVING: after every tick each robot advances by integrate_twist of the
+    # twist the tick chose (eea_integrate_twist_batch, numerics.hpp:273-297) and odometry reports that twist -- the branch mix
+    # (control / follow / re-plan) is then the closed loop's, not the one static poses freeze; the map is unchanged (epoch)
+    d_follow.zero_(), d_count.zero_(), d_u.zero_(), d_ut.zero_(), d_vb.zero_()
+    d_pose.copy_(torch.as_tensor(poses))
+
+    def tick_moving():
+        eng.tick_batch(B, d_pose, d_ut, d_follow, d_count, d_u, d_vb, d_grid, d_traj, d_valid, d_skip, ccfg, dcfg,
+                       0.1, 0.5, source=d_src, grid_epoch=9, stream=sp)
+        capi.integrate_twist_batch(d_pose, d_u, 0.1, normalize_heading=True, stream=sp)
+        d_vb_copy(d_u)
+    with torch.cuda.stream(st):
+        d_vb_copy = lambda src_: d_vb.copy_(src_, non_blocking=True)
+        us_moving = timed(tick_moving, 200)
+        move_only = timed(lambda: (capi.integrate_twist_batch(d_pose, d_u, 0.1, normalize_heading=True, stream=sp), d_vb_copy(d_u)), 200)
+    src_moving = d_src.cpu().numpy()
     eng.close()
+    # What the two byte-lookup kernels of a tick should cost ("state the bound"):
+    #  * dwa_control_kernel<MAP, FLEET>: one workgroup per robot that needs the window, one lane per velocity sample, a rollout of
+    #    `steps` DEPENDENT steps per lane -- per step one sincos + ~12 fp64 operations + ONE byte of the inflated map (L2-resident:
+    #    the map is 33 KB).  The chain is latency, not bytes: ~steps x (sincos ~60 + arithmetic ~30 + L2 byte ~120 cycles ~ 0.1 us at
+    #    2.3 GHz) ~ 2 us per wavefront, and with 2 wavefronts per robot (120 samples) x 4096 robots = 8192 wavefronts on 1024 SIMDs
+    #    x 8 resident = one round: the floor is ~2-4 us of chain + launch (~5 us), against 34 us measured -> the kernel is 4-5x its
+    #    dependent-chain floor; the difference is the objective (distance to optTraj: `steps` more dependent sqrt / loads of the
+    #    reference trajectory per step in the "traj" mode) and the serial first-minimum reduction over 120 samples by lane 0.
+    #  * inflate_kernel (dilation of the occupied cells by the ring offsets): bytes = grid read once (28.8 KB) + every occupied
+    #    cell stamps |offsets| ~ 250 bytes of the map; at ~10 % occupied cells of 240 x 120 that is ~0.7 MB of scattered byte
+    #    stores -> HBM/L2 bandwidth is irrelevant (<< 1 us at 8 TB/s); the floor is the launch (~5 us) + one round of the
+    #    workgroups' list-then-stamp (two barriers), against 18 us measured.
+    lookups = B * 120 * 20
     return {"tick_kernels": {"grid": "%dx%d int8 @ %.2f m" % (xs, ys, res), "dwa_window": "3 x 8 x 5 samples x 20 steps",
                              "note": "device microseconds per call (HIP events on the launch stream); ring search: dependent byte "
                                      "loads (latency-bound), inflated map: one dilation launch + one byte per pose-step "
                                      "(launch-bound at these sizes)", "cases": kernels},
             "fleet_tick": {"robots": B, "kinematics": "omni", "num_basis": 10, "horizon_steps": T, "us_per_tick": us,
                            "us_per_tick_unchanged_grid": us_cached,
+                           "us_per_tick_moving_robots": us_moving - move_only, "pose_update_us": move_only,
                            "ticks_per_s": 1e6 / us, "robot_ticks_per_s": B * 1e6 / us,
                            "control_batch_alone_us": ctl,
                            "sources_last_tick": {n: int((src == i).sum()) for i, n in enumerate(("control", "dwa_follow", "dwa_reference",
                                                                                                 "dwa_replan"))},
+                           "sources_last_tick_moving": {n: int((src_moving == i).sum()) for i, n in
+                                                        enumerate(("control", "dwa_follow", "dwa_reference", "dwa_replan"))},
+                           "bounds": {"dwa_window_lookups_per_tick_at_most": lookups,
+                                      "dwa_window_dependent_chain_floor_us": 4.0, "dilation_launch_floor_us": 5.0,
+                                      "note": "dwa_control_kernel<MAP, FLEET>: 20 dependent rollout steps per lane (sincos + one L2 byte "
+                                              "each): a latency chain of ~2-4 us + launch, not a bandwidth problem (the map is 33 KB); "
+                                              "inflate_kernel: < 1 MB of scattered byte stores, launch + two barriers ~5 us (bench.py "
+                                              "tick_legs carries the derivation)"},
                            "note": "eea_tick_batch: step counters -> control() of the robots that follow no DWA twist -> optTraj "
                                    "rollout -> validate_control -> dynamic window per robot in its mode, one stream, no host round "
-                                   "trip; static poses (the robots in front of obstacles stay in the DWA branches); "
+                                   "trip; us_per_tick: static poses (the robots in front of obstacles stay in the DWA branches); "
+                                   "us_per_tick_moving_robots: the robots advance by integrate_twist of the chosen twist after every "
+                                   "tick (eea_integrate_twist_batch), map unchanged; "
                                    "us_per_tick_unchanged_grid: eea_tick_io::grid_epoch != 0, the inflated collision map of the "
                                    "tick before is reused (maps update at ~1 Hz, the loop runs at 10 Hz)"}}
 
@@ -536,11 +576,12 @@ def cpp_host_loop_leg(agents):
     out = {"driver": "ergodic_exploration_amd/host/test/consensus_bench.cpp", "agents": agents, "cases": []}
     cases = [("local exchange (no collective)", "", 1)]
     if os.path.exists(fake):
-        cases += [("collective kernel in the exchange (test double), stream-ordered, ONE device graph per 48 passes "
+        cases += [("collective kernel in the exchange (test double), GATED (eea_stream_wait_flag in front of every consuming "
+                   "launch; what this file does with a communicator)", fake, 2, "32"),
+                  ("collective kernel in the exchange (test double), stream-ordered, ONE device graph per 48 passes "
                    "(eea_consensus_plan)", fake, 2, "22"),
-                  ("collective kernel in the exchange (test double), stream-ordered", fake, 2, "12"),
-                  ("collective kernel in the exchange (test double), one group device-bound", fake, 2, "2")]
-    cases += [("local exchange (no collective), stream-ordered, ONE device graph per 48 passes (eea_consensus_plan)", "", 2, "22")]
+                  ("collective kernel in the exchange (test double), stream-ordered per call (round 5's form)", fake, 2, "12")]
+    cases += [("local exchange (no collective), gated", "", 2, "32")]
     for case in cases:
         name, lib, lag = case[:3]
         mode = case[3] if len(case) > 3 else "2"
@@ -784,6 +825,7 @@ def main():
     d_ready = torch.zeros((B,), dtype=torch.int32, device="cuda")   # device-bound exchange: per-agent ready marks ...
     d_flag = torch.zeros((1,), dtype=torch.int32, device="cuda")    # ... and the flag of the finished exchange (sequence numbers)
     d_xstatus = torch.zeros((B,), dtype=torch.int32, device="cuda")  # per-agent status of the consensus passes (timeouts)
+    d_gate_timeouts = torch.zeros((1,), dtype=torch.int32, device="cuda")  # gates of the gated exchange that gave up
     cstate = {"lag": LAGS[0], "seq0": 0}
     d_arec_all = torch.empty((NB, B, L), dtype=tdt, device="cuda")   # per-agent records of a pass, one slot per pass in flight
     d_rec_all = torch.zeros((NB, L), dtype=tdt, device="cuda")       # their sum (over all ranks)
@@ -940,32 +982,30 @@ def main():
             src = (i - lag) % NB if i >= lag else None
             seq = cstate["seq0"] + i + 1      # sequence numbers only grow (also from one timed() call to the next)
             if collective_in_exchange():
-                # A COLLECTIVE KERNEL in the exchange (an RCCL communicator): the STREAM-ORDERED exchange -- every group's
-                # consuming launch is ordered behind the exchange's event (eea_comm_wait), the exchange behind the groups'
-                # events; nothing waits inside a kernel.  Waiting on the device for a flag whose producer is a collective
-                # kernel that must still become resident dead-locks when every execution slot is held by the waiters
-                # (round 5, profiles/r05_two_ranks.txt), and even one waiting group stalls now and then at full occupancy.
+                # A COLLECTIVE KERNEL in the exchange (an RCCL communicator): the GATED exchange (ABI 6) -- the device-bound
+                # exchange (records + ready marks out, the record sum polls the marks, all-reduce, publish, flag) with the flag
+                # wait as a one-wavefront GATE kernel in front of every consuming launch (eea_stream_wait_flag) instead of inside
+                # it: a waiting group holds one execution slot, its half of the chip stays empty until the record is there, so the
+                # collective kernel always finds room.  (Waiting INSIDE the control kernels dead-locks at full occupancy -- round
+                # 5, profiles/r05_two_ranks.txt.)  Launches only: no event, no stream wait (round 5's event-ordered form cost the
+                # host 35-40 us per 23 us pass; profiles/r06_exchange_modes.txt).
                 slot = seq % NB
                 src = (seq - lag) % NB if i >= lag else None
                 for g, a in enumerate(gargs):
                     if src is not None:
-                        wcall = exch_calls.get(("wait", g, src))
-                        if wcall is None:
-                            wcall = exch_calls[("wait", g, src)] = xcomm.prepared_wait(src, a["stream"])
-                        wcall()
-                    call = exch_calls.get(("so", g, slot, src))
+                        gate = exch_calls.get(("gate", g))
+                        if gate is None:
+                            gate = exch_calls[("gate", g)] = capi.prepared_stream_wait_flag(d_flag, d_gate_timeouts, a["stream"])
+                        gate(seq - lag)
+                    call = exch_calls.get(("gated", g, slot, src))
                     if call is None:
-                        call = exch_calls[("so", g, slot, src)] = eng.prepared_batch(
+                        call = exch_calls[("gated", g, slot, src)] = eng.prepared_batch(
                             a["B"], a["pose"], a["ut"], a["u0"], mem_cols=a["mem_cols"], n_mem=a["n_mem"],
                             mem_stride=args.n_mem, stream=a["stream"], ck_rec=d_arec[slot][gb[g]:gb[g + 1]],
-                            status=d_xstatus[gb[g]:gb[g + 1]],
+                            rec_ready=d_ready[gb[g]:gb[g + 1]], status=d_xstatus[gb[g]:gb[g + 1]],
                             ck_shared=None if src is None else d_rec[src], ck_shared_parts=0 if src is None else 1)
-                    call()
-                xcall = exch_calls.get(("xso", slot))
-                if xcall is None:
-                    xcall = exch_calls[("xso", slot)] = xcomm.prepared_records_exchange(
-                        eng, B, d_arec[slot], d_rec[slot], [a["stream"] for a in gargs], slot)
-                xcall()
+                    call(seq, 0)
+                exchange_records(slot, seq)
                 return
             if not host_staged:
                 # device-bound: G control launches (ready marks out, flag wait in) + ONE exchange call, nothing else
@@ -1018,6 +1058,7 @@ def main():
         dist.all_reduce(torch.zeros(1, dtype=torch.float64))
 
     ev_join = [torch.cuda.Event() for _ in range(G)]
+    per_rank_s = {}   # leg -> the ranks' own wall times of the last timed() call of that leg (value = work / their MAX)
 
     def fork_groups():
         """every group stream waits for what the compute stream has enqueued so far"""
@@ -1072,7 +1113,11 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         pass_ms = ev0.elapsed_time(ev1) / (steps * Rl)  # HIP events bracketing the launches of all group streams
+        per_rank_s[leg] = [elapsed]
         if use_dist:
+            every = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]   # host tensors: gloo
+            dist.all_gather(every, torch.tensor([elapsed], dtype=torch.float64))
+            per_rank_s[leg] = [float(x) for x in every]
             t = torch.tensor([elapsed, pass_ms], dtype=torch.float64)  # host tensor: gloo
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed, pass_ms = float(t[0]), float(t[1])
@@ -1187,6 +1232,10 @@ def main():
                        "dist_backend": ("gloo (host collectives: barriers, timing) + nccl (device collectives: exchange legs)"
                                         if backend == "nccl" else backend) if use_dist else None},
             "timed_region_s": elapsed, "ms_per_pass": 1e3 * elapsed / (args.steps * R),
+            # the ranks' own wall times of the timed region and what each processed per second; `value` is all
+            # ranks' work / the MAX of these times (= timed_region_s)
+            "per_rank": {"timed_region_s": per_rank_s.get("shard"),
+                         "values": [B * R * args.steps / t for t in per_rank_s.get("shard", [])]},
             "spinup_passes": SPINUP_PASSES,
             "single_launch_per_pass": {"ms_per_pass": single_pass_ms, "frac": tflops / vpeak * pass_ms / single_pass_ms,
                                        "note": "the same passes as ONE launch per pass and agent group (eea_control_batch; "
@@ -1334,7 +1383,7 @@ def main():
                 pass
             # the driver parses the LAST stdout line from a bounded tail: a fixed selection of fields, <= 4 KB by
             # construction (bench_line.compact); every leg's full record goes to bench_detail.json
-            bench_line.write_detail(out, ROOT)
+            bench_line.write_detail(out, os.environ.get("EEA_BENCH_DETAIL_DIR", ROOT))
             try:
                 text = bench_line.compact(out)
             except Exception as exc:  # noqa: BLE001 -- never lose the headline to a formatting error
@@ -1364,9 +1413,11 @@ def main():
         try:
             setup_exchange()
             exchange = {"backend": exchange_backend,
+                        # what the collective library itself reports (ncclCommCount): proves that RCCL saw every rank
+                        "rccl_nranks": (comm.library_nranks() if comm is not None else 0), "world": world,
                         "consumer": "eea_batch_io::d_ck_shared as a sum record, ck_shared_parts = 1 (the gradient uses c_bar)"}
             by_lag = {}
-            # with a collective kernel in the exchange (stream-ordered, above) a lag of one pass has the collective on the
+            # with a collective kernel in the exchange (gated, above) a lag of one pass has the collective on the
             # critical path of every pass: the leg runs the lags >= 2
             lags = [l for l in LAGS if l >= 2] or [2] if collective_in_exchange() else LAGS
             for lag in lags:
@@ -1378,16 +1429,16 @@ def main():
                     "pass_ms_vs_headline": p_ms / pass_ms,
                     "value": world * B * RX * args.steps / e_s, "unit": "optimisations/s",
                     "host_enqueue_us_per_pass": 1e6 * q_s / (args.steps * RX),
-                    "agents_timed_out": int((d_xstatus != 0).sum().item())}
+                    "agents_timed_out": int((d_xstatus != 0).sum().item()) + int(d_gate_timeouts.item())}
             first = by_lag[str(lags[0])]
             exchange["consensus_allreduce"] = {
-                "lag_passes": lags[0], "consuming_groups": ("all stream-ordered (eea_comm_records_exchange_async + eea_comm_wait)"
+                "lag_passes": lags[0], "consuming_groups": ("all gated (eea_stream_wait_flag in front of every consuming launch)"
                                                             if collective_in_exchange() else "all device-bound"),
                 "pass_ms": first["pass_ms"], "pass_ms_vs_headline": first["pass_ms_vs_headline"],
                 "pass_ms_vs_single_launch_pass": first["pass_ms_vs_single_launch_pass"],
                 "value": first["value"], "unit": "optimisations/s", "by_lag": by_lag,
                 "agent_groups": G, "bytes_per_rank_per_pass": rs * L, "host_threads": 0,
-                "protocol": ("stream-ordered (a collective kernel is in the exchange)" if collective_in_exchange() else
+                "protocol": ("gated (a collective kernel is in the exchange)" if collective_in_exchange() else
                              "device-bound (eea_comm_records_exchange_bound): no host wait, no stream wait, no event"),
                 "note": "every pass: the control kernels write per-agent sum records and ready marks (write-through, half way "
                         "through the wavefront), ONE launch on the exchange stream polls the marks and adds the records "

@@ -31,29 +31,31 @@ def _pick(d, keys, sig=6):
     return {k: _r(d[k], sig) for k in keys if k in d and d[k] is not None}
 
 
+SHORT_COLS = ("config", "agents", "lanes_per_agent", "us_per_4096", "frac", "kernel_avg_us_profiled", "frac_profiled", "variant")
+
+
 def _short_horizons(other):
-    """one entry per short-horizon BASELINE shape and batch size: config, agents, lanes per agent, us per 4096 agents,
-    fraction of the vector peak, and the rocprofv3 kernel average of the same launch form when profiles/ holds one"""
+    """one row per BASELINE shape and batch size of bench.py's other_configs, as {"cols": SHORT_COLS, "rows": [[...]]}: config,
+    agents, lanes per agent (64 = one wavefront per agent), us per 4096 agents, fraction of the dtype's vector peak, the
+    rocprofv3 kernel average of the same launch form and the fraction it gives when profiles/ holds one (else null), and
+    what makes the row a variant of its config (dtype / model / replay memory)"""
     rows = []
     for c in (other or {}).get("cases", []) if isinstance(other, dict) else []:
         if not isinstance(c, dict):
             continue
         name = str(c.get("config", ""))
         m = re.match(r"configs\[\d\]", name)
-        row = {"config": m.group(0) if m else ("yaml K10 T50" if "yaml" in name else name[:16]),
-               "agents": c.get("agents"), "lanes_per_agent": c.get("lanes_per_agent"),
-               "us_per_4096": _r(c.get("us_per_4096_agents"), 4), "frac": _r((c.get("roofline") or {}).get("frac"), 3)}
+        variant = []
         if c.get("dtype") not in (None, "f64"):
-            row["dtype"] = c["dtype"]
+            variant.append(c["dtype"])
         if c.get("kinematics") == "omni" and m and m.group(0) == "configs[3]":
-            row["kinematics"] = "omni"
+            variant.append("omni")
         if c.get("n_mem"):
-            row["n_mem"] = c["n_mem"]
-        for k in ("kernel_avg_us_profiled", "frac_profiled"):
-            if c.get(k) is not None:
-                row[k] = _r(c[k], 4)
-        rows.append({k: v for k, v in row.items() if v is not None})
-    return rows
+            variant.append("n_mem=%d" % c["n_mem"])
+        rows.append([m.group(0) if m else ("yaml K10 T50" if "yaml" in name else name[:16]), c.get("agents"), c.get("lanes_per_agent"),
+                     _r(c.get("us_per_4096_agents"), 4), _r((c.get("roofline") or {}).get("frac"), 3),
+                     _r(c.get("kernel_avg_us_profiled"), 4), _r(c.get("frac_profiled"), 3), " ".join(variant) or None])
+    return {"cols": list(SHORT_COLS), "rows": rows} if rows else None
 
 
 def _exchange(ex):
@@ -62,7 +64,7 @@ def _exchange(ex):
     if "error" in ex and "consensus_allreduce" not in ex:
         return {"error": str(ex["error"])[:200]}
     o = {"backend": str(ex.get("backend", ""))[:60]}
-    for k in ("rccl_nranks", "ranks_values", "max_over_ranks_s"):
+    for k in ("rccl_nranks", "world"):
         if ex.get(k) is not None:
             o[k] = ex[k] if not isinstance(ex[k], float) else _r(ex[k])
     ca = ex.get("consensus_allreduce")
@@ -84,13 +86,17 @@ def _exchange(ex):
                 continue
             form = str(c.get("form") or c.get("consuming_groups", ""))
             form = "plan" if "eea_consensus_plan" in form else ("stream-ordered" if form.startswith("all stream") else
-                                                                  ("device-bound" if form.startswith("all device") else "hybrid"))
-            rows.append({"form": form,
-                         "collective_kernel": c.get("collective_kernel_in_exchange"), "lag": c.get("lag"),
-                         "plain_us": _r(c.get("plain_us_per_pass"), 5), "consensus_us": _r(c.get("consensus_us_per_pass"), 5),
+                                                                  ("device-bound" if form.startswith("all device") else
+                                                                   ("gated" if form.startswith("all gated") else "hybrid")))
+            rows.append({"form": form, "collective_kernel": c.get("collective_kernel_in_exchange"), "lag": c.get("lag"),
+                         "plain_us": _r(c.get("plain_us_per_pass"), 4), "consensus_us": _r(c.get("consensus_us_per_pass"), 4),
                          "ratio": _r(c.get("ratio"), 4), "host_us": _r(c.get("host_us_per_pass_consensus"), 4),
                          "timeouts": c.get("agents_timed_out")})
-        o["cpp_host_loop"] = rows[:5]
+        # (the event-ordered per-call form and the hybrid of round 5 stay in bench_detail.json: superseded by the gated form)
+        keep = [r for r in rows if r["form"] in ("device-bound", "gated", "plan")][:4]
+        cols = ("form", "collective_kernel", "lag", "consensus_us", "ratio", "host_us", "timeouts")
+        if keep:
+            o["cpp_host_loop"] = {"plain_us": keep[0]["plain_us"], "cols": list(cols), "rows": [[r[k] for k in cols] for r in keep]}
     return o
 
 
@@ -106,6 +112,10 @@ def compact(out):
     for k in ("timed_region_s", "ms_per_pass"):
         if k in out:
             line[k] = _r(out[k])
+    pr = out.get("per_rank")
+    if isinstance(pr, dict) and isinstance(pr.get("values"), list) and len(pr["values"]) > 1:
+        line["per_rank"] = {"timed_region_s": [_r(float(x), 5) for x in (pr.get("timed_region_s") or [])][:8],
+                            "values": [_r(float(x), 5) for x in pr["values"]][:8]}
     rf = out.get("roofline")
     if isinstance(rf, dict):
         line["roofline"] = _pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "flops_per_launch", "passes_per_launch",
@@ -139,7 +149,7 @@ def compact(out):
         line["exchange"] = ex
     ft = out.get("fleet_tick")
     if isinstance(ft, dict):
-        line["fleet_tick"] = _pick(ft, ("robots", "us_per_tick", "us_per_tick_unchanged_grid", "error"), 5)
+        line["fleet_tick"] = _pick(ft, ("robots", "us_per_tick", "us_per_tick_unchanged_grid", "us_per_tick_moving_robots", "error"), 5)
     lm = out.get("latency_mode")
     if isinstance(lm, dict):
         line["latency_mode"] = _pick(lm, ("value", "us_per_call"), 5)
@@ -161,8 +171,8 @@ def compact(out):
             break
         line.pop(k, None)
         text = json.dumps(line, separators=(",", ":"))
-    while len(text) > MAX_LINE_BYTES and line.get("short_horizons"):
-        line["short_horizons"].pop()
+    while len(text) > MAX_LINE_BYTES and line.get("short_horizons", {}).get("rows"):
+        line["short_horizons"]["rows"].pop()
         text = json.dumps(line, separators=(",", ":"))
     if len(text) > MAX_LINE_BYTES:
         raise AssertionError("bench line is %d bytes (> %d)" % (len(text), MAX_LINE_BYTES))

@@ -548,6 +548,15 @@ def set_option(option, value):
     check(lib().eea_set_option(option, value))
 
 
+def integrate_twist_batch(x0, u, dt, out=None, normalize_heading=False, stream=None, device=0):
+    """eea_integrate_twist_batch (ABI 6): integrate_twist (numerics.hpp:273-297) of P poses on the device; out may be x0"""
+    out = x0 if out is None else out
+    lib().eea_integrate_twist_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_uint, C.c_void_p, C.c_int, C.c_void_p]
+    check(lib().eea_integrate_twist_batch(device, _ptr(x0), _ptr(u), float(dt), int(x0.shape[0]), _ptr(out),
+                                          1 if normalize_heading else 0, C.c_void_p(stream or 0)))
+    return out
+
+
 def stream_wait_flag(flag, seq, timeouts=None, stream=None):
     """eea_stream_wait_flag (ABI 6): what follows on `stream` starts once *flag - seq >= 0 -- a one-wavefront gate kernel"""
     check(lib().eea_stream_wait_flag(_ptr(flag), seq, _ptr(timeouts), C.c_void_p(stream or 0)))
@@ -650,6 +659,11 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+    def library_nranks(self):
+        """ncclCommCount of the communicator behind the C ABI (0: local communicator, -1: the library cannot tell)"""
+        lib().eea_comm_library_nranks.argtypes = [C.c_void_p]
+        return int(lib().eea_comm_library_nranks(self.h))
 
     def allgather_ck(self, eng, B_local, ck_local, ck_all, stream=None):
         check(lib().eea_comm_allgather_ck(eng.h, self.h, B_local, _ptr(ck_local), _ptr(ck_all),

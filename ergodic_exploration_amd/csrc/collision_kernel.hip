@@ -740,6 +740,43 @@ hipError_t launch_collision_check(const CollisionParams& c, const int8_t* d_grid
   return hipGetLastError();
 }
 
+// integrate_twist (numerics.hpp:273-297) for P poses: x + Rot(theta) dq_b, the heading NOT wrapped (the reference's callers
+// normalise it: validate_control :325, the nodes' motion updates).  One thread per pose; this translation unit is compiled
+// without FMA contraction, the sums in the reference's order.
+__global__ __launch_bounds__(kBlock) void integrate_twist_kernel(const double* __restrict__ x0, const double* __restrict__ u, double dt,
+                                                                 unsigned P, double* __restrict__ out, int wrap)
+{
+  const unsigned q = blockIdx.x * kBlock + threadIdx.x;
+  if (q >= P) return;
+  const double x = x0[3 * static_cast<size_t>(q)], y = x0[3 * static_cast<size_t>(q) + 1], th = x0[3 * static_cast<size_t>(q) + 2];
+  const double u0 = u[3 * static_cast<size_t>(q)], u1 = u[3 * static_cast<size_t>(q) + 1], u2 = u[3 * static_cast<size_t>(q) + 2];
+  double d0, d1, d2;
+  if (fabs(u2 - 0.0) < 1.0e-12) {
+    d0 = u0 * dt;
+    d1 = u1 * dt;
+    d2 = 0.0;
+  } else {
+    const double vb0 = u0 * dt, vb1 = u1 * dt, vb2 = u2 * dt;
+    double s, cc;
+    sincos(vb2, &s, &cc);
+    d0 = (vb0 * s + vb1 * (cc - 1.0)) / vb2;
+    d1 = (vb1 * s + vb0 * (1.0 - cc)) / vb2;
+    d2 = vb2;
+  }
+  double s, cc;
+  sincos(th, &s, &cc);
+  out[3 * static_cast<size_t>(q)] = x + (cc * d0 + (-s) * d1);
+  out[3 * static_cast<size_t>(q) + 1] = y + (s * d0 + cc * d1);
+  out[3 * static_cast<size_t>(q) + 2] = wrap ? wrap_pi_d(th + d2) : th + d2;
+}
+
+hipError_t launch_integrate_twist(const double* d_x0, const double* d_u, double dt, unsigned P, double* d_out, bool wrap, hipStream_t s)
+{
+  if (P == 0) return hipSuccess;
+  hipLaunchKernelGGL(integrate_twist_kernel, dim3((P + kBlock - 1) / kBlock), dim3(kBlock), 0, s, d_x0, d_u, dt, P, d_out, wrap ? 1 : 0);
+  return hipGetLastError();
+}
+
 hipError_t launch_validate_control(const CollisionParams& c, const int8_t* d_grid,
                                    const double* d_x0, const double* d_u, double dt, unsigned steps,
                                    unsigned P, int* d_valid, hipStream_t s)

@@ -34,6 +34,7 @@ struct RcclApi
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
                             hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;  // optional (introspection: eea_comm_library_nranks)
   bool ok = false;
 };
 
@@ -65,6 +66,7 @@ RcclApi& rccl()
     a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(a.handle, "ncclAllGather"));
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(a.handle, "ncclAllReduce"));
     a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(a.handle, "ncclGetErrorString"));
+    a.CommCount = reinterpret_cast<decltype(a.CommCount)>(dlsym(a.handle, "ncclCommCount"));
     a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllGather && a.AllReduce && a.GetErrorString;
     return a;
   }();
@@ -249,6 +251,13 @@ void eea_comm_destroy(eea_comm* c)
 
 int eea_comm_rank(const eea_comm* c) { return c ? c->rank : 0; }
 int eea_comm_nranks(const eea_comm* c) { return c ? c->nranks : 1; }
+int eea_comm_library_nranks(const eea_comm* c)
+{
+  if (c == nullptr || c->comm == nullptr) return 0;  // a local communicator: no collective library behind it
+  if (rccl().CommCount == nullptr) return -1;
+  int n = -1;
+  return rccl().CommCount(c->comm, &n) == ncclSuccess ? n : -1;
+}
 
 eea_status eea_ck_sum(eea_engine* e, unsigned B, const void* d_ck, void* d_sums, void* stream)
 {

@@ -260,6 +260,8 @@ struct CollisionParams
 };
 hipError_t launch_collision_check(const CollisionParams& c, const int8_t* d_grid,
                                   const double* d_pose, unsigned P, int* d_hit, hipStream_t s);
+// integrate_twist (numerics.hpp:273-297) per pose; wrap: the heading normalised to [-pi, pi) afterwards
+hipError_t launch_integrate_twist(const double* d_x0, const double* d_u, double dt, unsigned P, double* d_out, bool wrap, hipStream_t s);
 hipError_t launch_validate_control(const CollisionParams& c, const int8_t* d_grid,
                                    const double* d_x0, const double* d_u, double dt, unsigned steps,
                                    unsigned P, int* d_valid, hipStream_t s);

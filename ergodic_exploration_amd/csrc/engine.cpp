@@ -1784,6 +1784,15 @@ eea_status eea_validate_control_batch(int device, const eea_collision_cfg* cfg, 
   return EEA_OK;
 }
 
+eea_status eea_integrate_twist_batch(int device, const double* d_x0, const double* d_u, double dt, unsigned P, double* d_out,
+                                     int normalize_heading, void* stream)
+{
+  if (d_x0 == nullptr || d_u == nullptr || d_out == nullptr) return fail(EEA_ERR_INVALID_ARGUMENT, "null argument");
+  EEA_HIP(hipSetDevice(device));
+  EEA_HIP(eea::launch_integrate_twist(d_x0, d_u, dt, P, d_out, normalize_heading != 0, static_cast<hipStream_t>(stream)));
+  return EEA_OK;
+}
+
 void eea_release_collision_caches(void) { eea::release_collision_caches(); }
 
 // One tick of Exploration<ModelT>::control's loop body for B robots (exploration.hpp:220-279): see ergodic_amd.h

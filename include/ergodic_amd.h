@@ -321,6 +321,9 @@ eea_status eea_comm_create(int device, int nranks, int rank, const void* id, eea
 void eea_comm_destroy(eea_comm* c);
 int eea_comm_rank(const eea_comm* c);
 int eea_comm_nranks(const eea_comm* c);
+/* ABI 6: the number of ranks THE COLLECTIVE LIBRARY reports for this communicator (ncclCommCount) -- what a multi-GPU run shows to
+ * prove that RCCL saw every rank; 0 for a local communicator (no library behind it), -1 if the library cannot tell. */
+int eea_comm_library_nranks(const eea_comm* c);
 /* sums[m] = sum over the B local agents of d_ck[b][m], m < K^2, and sums[K^2] = B (K^2 + 1 reals,
  * device): the local half of the consensus reduction */
 eea_status eea_ck_sum(eea_engine* e, unsigned B, const void* d_ck, void* d_sums, void* stream);
@@ -486,6 +489,13 @@ eea_status eea_collision_check_batch(int device, const eea_collision_cfg* cfg, c
 eea_status eea_validate_control_batch(int device, const eea_collision_cfg* cfg, const int8_t* d_grid,
                                       const double* d_x0, const double* d_u, double dt,
                                       double horizon, unsigned P, int* d_valid, void* stream);
+
+/* ABI 6: integrate_twist (numerics.hpp:273-297) for P poses: d_out [P][3] = d_x0 + Rot(theta) * (the body-frame displacement of the
+ * constant twist d_u over dt); the motion update of the replay harness / a simulated fleet between ticks, on the device so that
+ * the tick loop needs no host round trip.  d_out may be d_x0.  normalize_heading != 0: the heading through normalize_angle_PI
+ * (numerics.hpp:77-89) as the reference's callers do (validate_control :325); 0: as integrate_twist returns it. */
+eea_status eea_integrate_twist_batch(int device, const double* d_x0, const double* d_u, double dt, unsigned P, double* d_out,
+                                     int normalize_heading, void* stream);
 
 /* DynamicWindow::control (dynamic_window.cpp:92-189), both overloads, for P robots on one grid:
  * velocity window from the current twist d_vb (dynamic_window.cpp:191-235), vx x vy x vth sample

@@ -254,6 +254,14 @@ ncclResult_t ncclCommDestroy(ncclComm_t comm)
   return ncclSuccess;
 }
 
+// the ranks that have JOINED the group (what the real call reports once ncclCommInitRank has returned: all of them)
+ncclResult_t ncclCommCount(const ncclComm_t comm, int* count)
+{
+  if (comm == nullptr || count == nullptr) return ncclInvalidArgument;
+  *count = comm->group->shm->joined.load();
+  return ncclSuccess;
+}
+
 const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : "fake RCCL: invalid argument / HIP failure"; }
 
 // recv [nranks][count] in rank order (in-place capable: send may be recv + rank * count)

@@ -32,7 +32,9 @@ def test_compact_line_of_a_recorded_run_is_small_and_complete(path):
     assert rec["roofline"]["frac"] == pytest.approx(full["roofline"]["achieved"] / full["roofline"]["peak"], rel=1e-4)
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(rec["cpu_baseline"])
     assert "workload" in rec["config"] and "model" not in rec["config"]
-    assert all(set(("config", "agents", "lanes_per_agent", "us_per_4096", "frac")) <= set(r) for r in rec["short_horizons"])
+    sh = rec["short_horizons"]
+    assert sh["cols"][:5] == ["config", "agents", "lanes_per_agent", "us_per_4096", "frac"] and len(sh["rows"]) >= 6
+    assert all(len(r) == len(sh["cols"]) for r in sh["rows"])
     assert "note" not in text   # no prose in the line
 
 

@@ -169,3 +169,36 @@ def test_release_caches_then_reuse():
     capi.collision_check_batch(cfg, d_grid, d_pose, b)
     torch.cuda.synchronize()
     assert torch.equal(a, b) and 0 < int(a.sum()) < 5000
+
+
+def test_integrate_twist_batch_matches_the_oracle():
+    """eea_integrate_twist_batch (ABI 6) = integrate_twist (numerics.hpp:273-297) per pose: against the oracle's restatement
+    (pinned by the reference's own NumericsTest.IntegrateTwist* vectors, tests/golden/reference_kats.json) to 4 ulp -- the bar
+    of the reference's ASSERT_DOUBLE_EQ; the straight-line branch (|w| < 1e-12) bitwise; the heading left as it comes or
+    wrapped to [-pi, pi) like normalize_angle_PI (pi -> -pi)."""
+    rng = np.random.default_rng(12)
+    P = 5000
+    x = np.stack([rng.uniform(-5, 15, P), rng.uniform(-5, 8, P), rng.uniform(-3.2, 3.2, P)], 1)
+    u = np.stack([rng.uniform(-1, 1, P), rng.uniform(-1, 1, P), rng.uniform(-2, 2, P)], 1)
+    u[:500, 2] = 0.0                        # straight line
+    u[500:520, 2] = 5e-13                   # below the threshold: still the straight-line branch
+    u[520:540, 2] = 2e-12                   # just above it
+    x[540, 2], u[540] = np.pi - 0.05, [0.3, 0.0, 0.5]   # the heading crosses pi
+    d_x, d_u = torch.as_tensor(x).cuda(), torch.as_tensor(u).cuda()
+    out = torch.empty_like(d_x)
+    capi.integrate_twist_batch(d_x, d_u, 0.1, out=out)
+    wrapped = torch.empty_like(d_x)
+    capi.integrate_twist_batch(d_x, d_u, 0.1, out=wrapped, normalize_heading=True)
+    torch.cuda.synchronize()
+    got, gw = out.cpu().numpy(), wrapped.cpu().numpy()
+    ref = np.array([po.integrate_twist(x[i], u[i], 0.1) for i in range(P)])
+    assert np.array_equal(got[:520], ref[:520])
+    ulp = np.spacing(np.maximum(np.abs(ref), 1e-300))
+    assert (np.abs(got - ref) <= 4 * ulp).all()
+    refw = np.array([po.normalize_angle_PI(t) for t in ref[:, 2]])
+    assert np.array_equal(gw[:, :2], got[:, :2]) and (np.abs(gw[:, 2] - refw) <= 4 * np.spacing(np.pi)).all()
+    assert (gw[:, 2] >= -np.pi).all() and (gw[:, 2] < np.pi).all() and gw[540, 2] < 0.0 < got[540, 2]
+    # in place
+    capi.integrate_twist_batch(d_x, d_u, 0.1)
+    torch.cuda.synchronize()
+    assert torch.equal(d_x, out)

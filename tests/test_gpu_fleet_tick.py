@@ -38,7 +38,25 @@ def _engine(model):
 
 @pytest.mark.parametrize("model,kernel", [("omni", "wave"), ("simple_cart", "wave"), ("omni", "packed"), ("simple_cart", "workgroup")])
 def test_fleet_tick_against_independent_oracle_loops(model, kernel):
-    ticks, B, dt = 30, 28, 0.1
+    _fleet_tick_case(model, kernel, ticks=30, B=28, wall_tick=12, sample=None)
+
+
+@pytest.mark.parametrize("model", ["omni", "simple_cart"])
+def test_fleet_tick_at_fleet_size(model):
+    """the same loop at the size the bench leg times -- 4096 robots, 10 ticks, the engine's own choice of
+    control kernel (T = 50 at 4096 robots: one wavefront per robot; the followers' skip mask thins the batch) -- checked
+    against independent oracle loops on a SAMPLE of 32 robots spread over the batch (first / last robots, wavefront and
+    workgroup boundaries, the robots that start in front of the obstacles).  Every robot moves every tick."""
+    B = 4096
+    rng = np.random.default_rng(11)
+    sample = sorted(set([0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 63, 64, 255, 256, 2047, 2048, B - 2, B - 1]) |
+                    set(int(x) for x in rng.choice(B, 10, replace=False)))[:32]
+    _fleet_tick_case(model, "auto", ticks=10, B=B, wall_tick=4, sample=sample)
+
+
+def _fleet_tick_case(model, kernel, ticks, B, wall_tick, sample):
+    dt = 0.1
+    checked = range(B) if sample is None else sample
     obstacles = [(2.4, 0.2, 3.0, 2.6), (6.0, 2.0, 6.5, 4.6), (8.8, -0.4, 9.4, 1.2)]
     wall = (4.2, -0.6, 4.5, 4.4)   # appears at tick 12
     grid_a, bounds = _grid_with(obstacles)
@@ -53,7 +71,8 @@ def test_fleet_tick_against_independent_oracle_loops(model, kernel):
             capi.set_option(capi.OPT_CONTROL_KERNEL, 1)
         eng = _engine(model)
         eng.config_domain(bounds)
-        assert eng.agent_lanes(B) == {"wave": 64, "packed": 16, "workgroup": 0}[kernel]
+        if kernel != "auto":
+            assert eng.agent_lanes(B) == {"wave": 64, "packed": 16, "workgroup": 0}[kernel]
         T = eng.T
         rng = np.random.default_rng(4)
         # start poses in free space, most of them heading for an obstacle
@@ -63,7 +82,7 @@ def test_fleet_tick_against_independent_oracle_loops(model, kernel):
         for b in range(B):   # (no robot starts inside a collision)
             while not po.validate_control(COLL, grid_b, poses[b], np.zeros(3), 0.1, 0.5):
                 poses[b, :2] = rng.uniform(0.2, 9.5), rng.uniform(-0.2, 4.2)
-        ors = [OracleExploration(model, grid_a, bounds) for _ in range(B)]
+        ors = {b: OracleExploration(model, grid_a, bounds) for b in checked}
         dev = lambda a, t=torch.float64: torch.as_tensor(np.ascontiguousarray(a), dtype=t).cuda()
         d_ut = torch.zeros((B, T, 3), dtype=torch.float64, device="cuda")
         d_follow = torch.zeros((B,), dtype=torch.int32, device="cuda")
@@ -79,7 +98,7 @@ def test_fleet_tick_against_independent_oracle_loops(model, kernel):
         vb = np.zeros((B, 3))
         seen = set()
         for t in range(ticks):
-            grid, d_grid = (grid_a, d_grid_a) if t < 12 else (grid_b, d_grid_b)
+            grid, d_grid = (grid_a, d_grid_a) if t < wall_tick else (grid_b, d_grid_b)
             mem[:, t] = poses          # addStateMemory(pose) every tick (exploration.hpp:209); <= batch size: no sampling
             ut_before = d_ut.cpu().numpy()
             eng.tick_batch(B, dev(poses), d_ut, d_follow, d_count, d_u, dev(vb), d_grid, d_traj, d_valid, d_skip, ccfg, dcfg,
@@ -88,11 +107,11 @@ def test_fleet_tick_against_independent_oracle_loops(model, kernel):
                            mem_stride=t + 1, status=d_status,
                            # (the inflated collision map is rebuilt every tick, or kept while the caller's epoch says the
                            # grid has not changed: 1 before the wall appears, 2 after)
-                           grid_epoch=0 if kernel != "wave" else (1 if t < 12 else 2))
+                           grid_epoch=0 if kernel not in ("wave", "auto") else (1 if t < wall_tick else 2))
             torch.cuda.synchronize()
             u, src, follow, count = d_u.cpu().numpy(), d_source.cpu().numpy(), d_follow.cpu().numpy(), d_count.cpu().numpy()
             valid, ut_after = d_valid.cpu().numpy(), d_ut.cpu().numpy()
-            for b in range(B):
+            for b in checked:
                 o = ors[b]
                 o.grid = grid
                 o.memory = list(mem[b, :t])           # (tick() appends the pose itself)
@@ -121,7 +140,10 @@ def test_fleet_tick_against_independent_oracle_loops(model, kernel):
             vb = u.copy()
         # every branch of the loop body ran (the re-plan of a followed twist needs the wall to cut a follower off within its
         # dwa_steps: the omni scenario does, the cart's 3 x 1 x 5 window rarely finds a twist to follow at all)
-        assert seen >= {"ergodic", "dwa-follow", "dwa-reference"} and (model != "omni" or "dwa-replan" in seen), seen
+        if sample is None:
+            assert seen >= {"ergodic", "dwa-follow", "dwa-reference"} and (model != "omni" or "dwa-replan" in seen), seen
+        else:
+            assert seen >= {"ergodic", "dwa-reference"}, seen
         eng.close()
     finally:
         capi.set_option(capi.OPT_AGENT_LANES, 0)

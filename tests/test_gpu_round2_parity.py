@@ -692,11 +692,11 @@ def test_prepared_batch_is_the_same_call():
 
 
 @pytest.mark.parametrize("extra", [["--no-exchange"], []])
-def test_bench_self_launches_its_ranks(extra):
+def test_bench_self_launches_its_ranks(extra, tmp_path):
     """`python bench.py --gpus 2` exactly as the driver would type it for N > 1 without a launcher: the
     parent makes no GPU call and starts the two ranks itself; on this 1-GPU box the ranks share the device
     (gloo rendezvous; the exchange steps through the C ABI and the RCCL test double).  One JSON line, n_gpus = 2, rc 0."""
-    env = dict(os.environ)
+    env = dict(os.environ, EEA_BENCH_DETAIL_DIR=str(tmp_path))
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
@@ -705,20 +705,32 @@ def test_bench_self_launches_its_ranks(extra):
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-3000:]
-    rec = json.loads(lines[0])
-    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and rec["value"] > 0
+    # the driver's line: small by construction (round 5's 22.5 KB line went unparsed), every leg's record in the detail file
+    assert len(lines[0]) <= 4096 and r.stdout.rstrip("\n").splitlines()[-1] == lines[0]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["value"] > 0
+    # the ranks' own times and values are in the line; value = all ranks' work / the max of the times
+    pr = line["per_rank"]
+    assert len(pr["values"]) == 2 and len(pr["timed_region_s"]) == 2
+    assert line["value"] == pytest.approx(2 * 256 * 3 * 2 / max(pr["timed_region_s"]), rel=1e-3)
+    with open(tmp_path / "bench_detail.json") as f:
+        rec = json.load(f)
+    assert rec["value"] == pytest.approx(line["value"], rel=1e-5)
     assert rec["config"]["optimisations_per_step"] == 2 * 256 * 3
     if extra:
-        assert "exchange" not in rec
+        assert "exchange" not in rec and "exchange" not in line
     else:
+        # the collective library itself reports both ranks (ncclCommCount through eea_comm_library_nranks)
+        assert line["exchange"]["rccl_nranks"] == 2 and line["exchange"]["world"] == 2 and line["exchange"]["timeouts"] == 0
         assert rec["exchange"]["consensus_allreduce"]["value"] > 0
         assert rec["exchange"]["allgather_ck"]["value"] > 0
         # the ranks share the GPU, so the exchange steps go through the C ABI and the test double of
         # RCCL (collective kernels that meet on the device) -- not through gloo staged over the host -- and, with a collective
-        # kernel in the exchange, every consuming group is stream-ordered: no agent times out
+        # kernel in the exchange, no group waits INSIDE its control kernels: every consuming launch sits behind a one-wavefront
+        # gate (the gated exchange), lag >= 2: no agent and no gate times out
         assert "test double" in rec["exchange"]["backend"], rec["exchange"]["backend"]
         ca = rec["exchange"]["consensus_allreduce"]
-        assert "stream-ordered" in ca["consuming_groups"] and min(int(k) for k in ca["by_lag"]) >= 2
+        assert "gated" in ca["consuming_groups"] and min(int(k) for k in ca["by_lag"]) >= 2
         assert all(v["agents_timed_out"] == 0 for v in ca["by_lag"].values()), ca["by_lag"]
         assert "test double" in rec["grid_tile"]["collective"]
         # BASELINE config 5 shard: the 1024 rows tiled over the two ranks, one all-reduce, phi_k installed on the device

@@ -96,6 +96,17 @@ def test_consensus_exchange_beside_a_collective_kernel():
         assert res["collective_kernel_in_exchange"] is True and res["consuming_groups"].startswith("all stream-ordered")
         assert res["agents_timed_out"] == 0 and res["collective_kernel_timeouts"] == 0, res
         assert res["ratio"] <= 2.2, res
+    # Round 6 (ABI 6): the same exchange without a single event -- GATED (the flag wait as a one-wavefront kernel in front of each
+    # consuming launch: eea_stream_wait_flag) and as ONE replayable device graph (eea_consensus_plan).  Neither may time out;
+    # measured 1.35 - 1.41 x plain (gated) and 1.4 - 1.65 x (graph) against the event-ordered form's 1.7 - 1.75
+    for mode, name, bar in (("32", "all gated", 1.7), ("22", "all stream-ordered, replayed as one device graph", 2.0)):
+        out = subprocess.run([os.path.join(BUILD, "consensus_bench"), "3000", "4096", "1", os.path.join(fake, "librccl.so.1"), "2", mode],
+                             capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout + out.stderr
+        res = json.loads([l for l in out.stdout.splitlines() if l.startswith("RESULT ")][-1][len("RESULT "):])
+        assert res["collective_kernel_in_exchange"] is True and res["consuming_groups"].startswith(name), res
+        assert res["agents_timed_out"] == 0 and res["collective_kernel_timeouts"] == 0, res
+        assert res["ratio"] <= bar, res
 
 
 @pytest.mark.gpu
