@@ -53,12 +53,27 @@ __host__ __device__ constexpr int wave_lds_elems(int K, int A, int S)
   const int e = region_elems(K, A) + park_elems(S);
   return e > 3 * kMaxS * kWave ? e : 3 * kMaxS * kWave;
 }
-// wavefronts per SIMD the kernel is compiled for: K = 5 fits 128 registers, K = 10 takes 164 (the second accumulator set,
-// the barrier gradient in registers)
+// wavefronts per SIMD the kernel is compiled for.  K = 5: four (118 registers).  K = 10, round 6: the timed 16-lane instances
+// (no stage outputs; yaml's T = 50) take <= 128 registers without scratch -- FOUR per SIMD -- since
+//  (a) lambda_k / phi_k are read where D is formed instead of being preloaded for all NB^2 entries: that preload, on top of the
+//      accumulators and the per-step state, was the kernel's register peak (146 of 162; found with a liveness profile of the
+//      ISA -- not in the contraction, where round 5 looked for it): 162 -> 138 for every group size;
+//  (b) with 16 lanes per agent the four blocks of a matrix instruction are the wavefront's FOUR AGENTS (kOneSet below): one
+//      accumulator set instead of one per half of the wavefront (-18), half the D section, and half-passes without a point
+//      are skipped altogether.
+// 8 lanes per agent (eight agents: two sets by necessity) and 32 stay at three per SIMD.  EEA_PACK_LEAN = 1 (experiment, same
+// box: 4 wavefronts per SIMD at 126 registers but 13 % more time per wavefront -- not kept) single-buffers the matrix operands.
+// LDS: 10 KB per wavefront at S = 4 = 16 wavefronts per CU exactly.
 #ifndef EEA_PACK_WAVES_K10
-#define EEA_PACK_WAVES_K10 3
+#define EEA_PACK_WAVES_K10 4
 #endif
-constexpr int waves_per_simd(int KC) { return KC == 5 ? 4 : EEA_PACK_WAVES_K10; }
+#ifndef EEA_PACK_LEAN
+#define EEA_PACK_LEAN 0
+#endif
+constexpr int waves_per_simd(int KC, bool STAGES, int L)
+{
+  return KC == 5 ? 4 : ((!STAGES && (L == 16 || EEA_PACK_LEAN != 0)) ? EEA_PACK_WAVES_K10 : 3);
+}
 
 // row_shr:N inside the 16-lane row, lanes without a source read 0
 template <int N>
@@ -134,7 +149,7 @@ __device__ __forceinline__ int block_agent(int h, int bb)
 
 // MODEL, KC (5 or 10), STAGES as in control_wave_kernel; L = lanes per agent; WPB = wavefronts per workgroup
 template <int MODEL, int KC, bool STAGES, int L, int WPB>
-__global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_kernel(const ControlParams<double> p_arg, const unsigned B,
+__global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L)) void control_pack_kernel(const ControlParams<double> p_arg, const unsigned B,
                                                                      const int S_arg, const int rollout_arg)
 {
   using R = double;
@@ -171,7 +186,13 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_k
   // (eea_batch_io::d_skip: an agent that is left out of the call is treated like one beyond the batch)
   const bool agent_in = b < B && !(p.skip != nullptr && p.skip[b < B ? b : 0] != 0);
   // the agent of lane ^ 32 (the partner whose other axis this lane stages)
-  const unsigned pb = wave_base + (al ^ (A / 2));
+  // kOneSet (16 lanes per agent): the four blocks of a matrix instruction are the four agents of the wavefront.  A half-pass
+  // then takes the points of lanes tl in [8 h, 8 h + 8) of EVERY agent (not all points of the agents of one half of the
+  // wavefront), the lane that stages the other axis of a point is lane ^ 8 -- a lane of the same agent --, and one accumulator
+  // set holds all four agents' sums.
+  constexpr bool kOneSet = (L == 16);
+  constexpr int NSETS = kOneSet ? 1 : 2;
+  const unsigned pb = kOneSet ? b : wave_base + (al ^ (A / 2));
   const bool partner_in = pb < B && !(p.skip != nullptr && p.skip[pb < B ? pb : 0] != 0);
 
   const int T = p.T;
@@ -379,19 +400,26 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_k
     nmem = (p.n_mem != nullptr) ? p.n_mem[b] : static_cast<int>(p.mem_stride);
     nmem = nmem < 0 ? 0 : (nmem > static_cast<int>(p.mem_stride) ? static_cast<int>(p.mem_stride) : nmem);
   }
-  R cacc[2][NB][NB];  // one accumulator set per half of the wavefront
+  R cacc[NSETS][NB][NB];  // one accumulator set per half of the wavefront (kOneSet: one for all four agents)
 #pragma unroll
-  for (int h = 0; h < 2; ++h) {
+  for (int h = 0; h < NSETS; ++h) {
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
 #pragma unroll
       for (int J = 0; J < NB; ++J) cacc[h][I][J] = R(0);
     }
   }
-  const bool lo = lane < 32;
-  const int trow = tile_row<L>(lane & 31);
-  R* const st_lower = (lo ? tabx : taby) + trow * KS;  // staging the tile of the points of lanes 0..31
-  R* const st_upper = (lo ? taby : tabx) + trow * KS;  // ... of lanes 32..63
+  // lo: this lane's own point belongs to the FIRST half-pass of a slot (lanes 0..31; kOneSet: lanes tl < 8 of every agent)
+  const bool lo = kOneSet ? ((lane & 8) == 0) : (lane < 32);
+  const int trow = kOneSet ? tile_row<8>(8 * al + (tl & 7)) : tile_row<L>(lane & 31);
+  // steps of the PARTNER lane, whose other axis this lane stages: the lane at the same place of another agent (the same
+  // count) -- kOneSet: lane ^ 8 of the same agent, another place in the horizon
+  const int ptl = tl ^ 8;
+  const int cnt_p = !kOneSet ? cnt : (top_heavy ? (ptl < r_top ? S : S - 1) : max(0, min(S, T - S * ptl)));
+  const int cnt_lower = lo ? cnt : cnt_p;  // steps of the lane whose point this lane stages in the first / second half-pass
+  const int cnt_upper = lo ? cnt_p : cnt;
+  R* const st_lower = (lo ? tabx : taby) + trow * KS;  // staging the tile of the first half-pass's points
+  R* const st_upper = (lo ? taby : tabx) + trow * KS;  // ... of the second
   struct Tab1
   {
     R a, b, two;  // T_k, T_{k+1}, 2 cos
@@ -410,18 +438,32 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_k
     t.b = d;
   };
   auto stage_cos = [&](R ca, R cb, R& c_lower, R& c_upper) {
-    R from_lower, from_upper;
-    wave::half_swap(cb, from_lower, from_upper);
-    c_lower = lo ? ca : from_lower;
-    c_upper = lo ? from_upper : ca;
+    if constexpr (kOneSet) {
+      const R partner_cb = dpp_or_zero<0x128, 0xf>(cb);  // row_ror:8 -- the cosine of lane ^ 8, a lane of the same agent
+      c_lower = lo ? ca : partner_cb;
+      c_upper = lo ? partner_cb : ca;
+    } else {
+      R from_lower, from_upper;
+      wave::half_swap(cb, from_lower, from_upper);
+      c_lower = lo ? ca : from_lower;
+      c_upper = lo ? from_upper : ca;
+    }
   };
   constexpr int kPairs = KS / 2;
   const int orow = 4 * ((lane >> 2) & 3) + 2 * ((lane >> 4) & 1) + (lane >> 5), oi = lane & 3;
   R qa[2][NB], qb[2][NB];
   const unsigned oaddr = wave::lds_addr(tabx + orow * KS + oi);
+  constexpr bool kLean = (KC == 10) && (EEA_PACK_LEAN != 0) && !kOneSet;
   auto read_operands4 = [&]() { wave::OperandReads4<KS, NB, 0, 0>::run(oaddr, qa, qb); };
   auto operands4_ready = [&]() { wave::wait_operands4<NB>(qa, qb); };
-  auto mma4_group = [&](int h, int q) {
+  // lean: group q of the tile into the ONE operand set (index 0)
+  auto read_group = [&](int q) {
+    if (q == 0) wave::OperandReads4One<KS, NB, 0, 0>::run(oaddr, qa[0], qb[0]);
+    else wave::OperandReads4One<KS, NB, 1, 0>::run(oaddr, qa[0], qb[0]);
+  };
+  auto group_ready = [&]() { wave::wait_operands4_one<NB>(qa[0], qb[0]); };
+  auto mma4_group = [&](int h_arg, int q) {
+    const int h = kOneSet ? 0 : h_arg;
 #pragma unroll
     for (int I = 0; I < NB; ++I) {
 #pragma unroll
@@ -429,7 +471,8 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_k
     }
   };
   // the matrix instructions of one 16-row group with the staging of `dst` (kPairs stores) spread between them
-  auto mma4_group_staging = [&](int h, int q, Tab1& u, R* dst) {
+  auto mma4_group_staging = [&](int h_arg, int q, Tab1& u, R* dst) {
+    const int h = kOneSet ? 0 : h_arg;
     constexpr int kEvery = (NB * NB + kPairs - 1) / kPairs;
     int done = 0;
 #pragma unroll
@@ -461,7 +504,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_k
     R cl, cu;
     stage_cos(c1x[0], c1y[0], cl, cu);
     {
-      Tab1 u = tab1_init(cl, (lo ? agent_in : partner_in) && 0 < cnt);
+      Tab1 u = tab1_init(cl, (lo ? agent_in : partner_in) && 0 < cnt_lower);
 #pragma unroll
       for (int q = 0; q < kPairs; ++q) {
         tab1_store(u, st_lower, 2 * q);
@@ -471,26 +514,68 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_k
 #pragma unroll
     for (int j = 0; j < kMaxS; ++j) {
       if (j < S) {  // wavefront-uniform
-        const bool second = lanes_in_slot(j) > L / 2;  // wavefront-uniform
+        // which 16-row groups of the two half-passes hold a point (wavefront-uniform): a half-pass takes lanes tl in
+        // [0, L / 2) resp. [L / 2, L) of the agents of its half of the wavefront -- kOneSet: tl in [0, 8) resp. [8, 16) of every
+        // agent, so that the whole second half-pass goes when no agent owns a step there (the tail slot of yaml's T = 50)
+        const int lis = lanes_in_slot(j);
+        const bool second0 = kOneSet ? lis > 4 : lis > L / 2;
+        const bool any1 = kOneSet ? lis > 8 : true;
+        const bool second1 = kOneSet ? lis > 12 : lis > L / 2;
+        const bool second = second0;
         lds_fence();
-        read_operands4();  // rows of lanes 0..31, slot j
-        lds_fence();       // operands in registers: the tile is free
-        {
-          Tab1 u = tab1_init(cu, (lo ? partner_in : agent_in) && j < cnt);
+        if constexpr (kLean) {
+          if (second) {  // wavefront-uniform: the first group's operands, its matrix instructions, then the second group's
+            read_group(0);
+            group_ready();
+            mma4_group(0, 0);
+            read_group(1);
+          } else {
+            read_group(0);
+          }
+          lds_fence();  // the last group's operands are on their way to the registers: the tile is free
+          Tab1 u = tab1_init(cu, (lo ? partner_in : agent_in) && j < cnt_upper);
+          group_ready();
+          mma4_group_staging(0, 0, u, st_upper);
+        } else {
+          read_operands4();  // the first half-pass's rows, slot j
+          lds_fence();       // operands in registers: the tile is free
+          Tab1 u = tab1_init(cu, (lo ? partner_in : agent_in) && j < cnt_upper);
           operands4_ready();
           mma4_group_staging(0, 0, u, st_upper);
-          if (second) mma4_group(0, 1);
+          if (second0) mma4_group(0, 1);
         }
         lds_fence();
-        read_operands4();  // rows of lanes 32..63, slot j
-        lds_fence();
-        {
-          const int jn = (j + 1 < kMaxS) ? j + 1 : j;
+        const int jn = (j + 1 < kMaxS) ? j + 1 : j;
+        if constexpr (kLean) {
+          if (second) {
+            read_group(0);
+            group_ready();
+            mma4_group(1, 0);
+            read_group(1);
+          } else {
+            read_group(0);
+          }
+          lds_fence();
           stage_cos(c1x[jn], c1y[jn], cl, cu);
-          Tab1 u = tab1_init(cl, (lo ? agent_in : partner_in) && (j + 1 < S) && (j + 1 < cnt));
+          Tab1 u = tab1_init(cl, (lo ? agent_in : partner_in) && (j + 1 < S) && (j + 1 < cnt_lower));
+          group_ready();
+          mma4_group_staging(1, 0, u, st_lower);
+        } else if (any1) {  // wavefront-uniform
+          read_operands4();  // the second half-pass's rows, slot j
+          lds_fence();
+          stage_cos(c1x[jn], c1y[jn], cl, cu);
+          Tab1 u = tab1_init(cl, (lo ? agent_in : partner_in) && (j + 1 < S) && (j + 1 < cnt_lower));
           operands4_ready();
           mma4_group_staging(1, 0, u, st_lower);
-          if (second) mma4_group(1, 1);
+          if (second1) mma4_group(1, 1);
+        } else {  // no point in the second half-pass: only the next slot's first tile is staged
+          stage_cos(c1x[jn], c1y[jn], cl, cu);
+          Tab1 u = tab1_init(cl, (lo ? agent_in : partner_in) && (j + 1 < S) && (j + 1 < cnt_lower));
+#pragma unroll
+          for (int q = 0; q < kPairs; ++q) {
+            tab1_store(u, st_lower, 2 * q);
+            tab1_step(u);
+          }
         }
       }
     }
@@ -508,14 +593,18 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_k
         sincospi_r((mem[3 * q + 1] - p.map_y) * p.inv_ly, &sb, &cb);
       }
       const unsigned long long vm = __ballot(valid);
-      const bool partner_valid = ((vm >> (lane ^ 32)) & 1ull) != 0ull;
-      const unsigned long long vm2 = __ballot(valid && tl >= L / 2);
+      const bool partner_valid = ((vm >> (lane ^ (kOneSet ? 8 : 32))) & 1ull) != 0ull;
+      // columns in the second 16-row group of their half-pass
+      const unsigned long long vm2 = __ballot(valid && (kOneSet ? (tl & 7) >= 4 : tl >= L / 2));
       R cl, cu;
       stage_cos(ca, cb, cl, cu);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
-        const unsigned half_any = static_cast<unsigned>(vm >> (32 * h)), half_second = static_cast<unsigned>(vm2 >> (32 * h));
-        if (half_any != 0u) {  // wavefront-uniform
+        // the lanes whose own column belongs to half-pass h
+        const unsigned long long hmask = kOneSet ? (0x00ff00ff00ff00ffull << (8 * h)) : (0xffffffffull << (32 * h));
+        const bool half_any = (vm & hmask) != 0ull, half_second_b = (vm2 & hmask) != 0ull;
+        const unsigned half_second = half_second_b ? 1u : 0u;
+        if (half_any) {  // wavefront-uniform
           {
             // lanes of half h stage the x axis of their own point, the others the y axis of their partner's
             const bool own = (h == 0) == lo;
@@ -528,11 +617,23 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_k
             }
           }
           lds_fence();
-          read_operands4();
-          lds_fence();
-          operands4_ready();
-          mma4_group(h, 0);
-          if (half_second != 0u) mma4_group(h, 1);
+          if constexpr (kLean) {
+            read_group(0);
+            group_ready();
+            mma4_group(h, 0);
+            if (half_second != 0u) {
+              read_group(1);
+              group_ready();
+              mma4_group(h, 0);
+            }
+            lds_fence();
+          } else {
+            read_operands4();
+            lds_fence();
+            operands4_ready();
+            mma4_group(h, 0);
+            if (half_second != 0u) mma4_group(h, 1);
+          }
         }
       }
     }
@@ -543,18 +644,26 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_k
     // lane l = 16 i + 4 bb + j holds, in set h, block bb's sum for c(k1 = 4 I + i, k2 = 4 J + j); the blocks of one agent
     // are added by row rotations (L = 16: bb and bb ^ 2; L = 32: all four)
     const int di = lane >> 4, db = (lane >> 2) & 3, dj = lane & 3;
-    R lamv[NB][NB], phiv[NB][NB];
+    // lambda_k and phi_k of this lane's entries.  Preloaded for all NB^2 entries (the loads run under the rotations: what a
+    // batch of one wavefront per SIMD wants -- read one pair at a time where D is formed, configs[1] at 4096 agents took 9.4
+    // instead of 8.0 us) they are 4 NB^2 registers on top of the accumulators and the per-step state: the kernel's register
+    // peak (146 of 162).  The 16-lane instances, compiled for four wavefronts per SIMD, read them where they are used: the
+    // tables are 800 bytes, L1-resident, and the other wavefronts of the SIMD cover the latency.
+    constexpr bool kPreload = !kOneSet;
+    R lamv[kPreload ? NB : 1][kPreload ? NB : 1], phiv[kPreload ? NB : 1][kPreload ? NB : 1];
+    if constexpr (kPreload) {
 #pragma unroll
-    for (int I = 0; I < NB; ++I) {
+      for (int I = 0; I < NB; ++I) {
 #pragma unroll
-      for (int J = 0; J < NB; ++J) {
-        const int k1 = 4 * I + di, k2 = 4 * J + dj;
-        const int idx = (k1 < K && k2 < K) ? k2 * K + k1 : 0;
-        lamv[I][J] = p.lamdak[idx];
-        phiv[I][J] = p.phik[idx];
+        for (int J = 0; J < NB; ++J) {
+          const int k1 = 4 * I + di, k2 = 4 * J + dj;
+          const int idx = (k1 < K && k2 < K) ? k2 * K + k1 : 0;
+          lamv[I][J] = p.lamdak[idx];
+          phiv[I][J] = p.phik[idx];
+        }
       }
     }
-    const bool writer = (L == 8) || (L == 16 && db < 2) || (L == 32 && db == 0);  // one copy stores c_k
+    const bool writer = (L == 8) || kOneSet || (L == 32 && db == 0);  // one copy stores c_k (kOneSet: every block is an agent)
     // The agents' sum records (eea_batch_io::d_ck_rec: [c_k, 1, pad]; decentralised consensus, README ref. [2]) leave from the
     // registers that hold c_k -- the same lanes, the same addresses within the agent as the d_ck stores --, BEFORE anything
     // of the shared c_k is read: with the device-bound exchange (d_rec_ready) they go write-through, the agents' ready marks
@@ -565,8 +674,8 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_k
     const bool rec_wt = p.rec_ready != nullptr;                // wavefront-uniform: write-through + ready marks
     constexpr unsigned long long kGrp = (L == 32) ? 0xffffffffull : ((1ull << L) - 1ull);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int ab = block_agent<L>(h, db);
+    for (int h = 0; h < NSETS; ++h) {
+      const int ab = kOneSet ? db : block_agent<L>(h, db);
       const unsigned bb = wave_base + ab;
       // (an agent left out of the call is treated like one beyond the batch: nothing of it is read or written)
       const bool in = bb < B && !(p.skip != nullptr && p.skip[bb < B ? bb : 0] != 0);
@@ -583,7 +692,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_k
 #pragma unroll
         for (int J = 0; J < NB; ++J) {
           R v = cacc[h][I][J];
-          if constexpr (L == 16) v = wave::add_row_ror<8>(v);
+          if constexpr (L == 16 && !kOneSet) v = wave::add_row_ror<8>(v);
           if constexpr (L == 32) v = wave::add_row_ror<8>(wave::add_row_ror<4>(v));
           const R c = invN * v;
           cacc[h][I][J] = c;
@@ -624,8 +733,8 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_k
       use_shared = ok;
     }
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int ab = block_agent<L>(h, db);
+    for (int h = 0; h < NSETS; ++h) {
+      const int ab = kOneSet ? db : block_agent<L>(h, db);
 #pragma unroll
       for (int I = 0; I < NB; ++I) {
 #pragma unroll
@@ -636,7 +745,8 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC)) void control_pack_k
             R c = cacc[h][I][J];
             // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
             if (use_shared) c = shared_ck_value(p, p.ck_shared, idx, K2, c);
-            s_D[ab * DS + idx] = lamv[I][J] * (c - phiv[I][J]);
+            if constexpr (kPreload) s_D[ab * DS + idx] = lamv[I][J] * (c - phiv[I][J]);
+            else s_D[ab * DS + idx] = p.lamdak[idx] * (c - p.phik[idx]);
           }
         }
       }

@@ -193,6 +193,29 @@ __device__ __forceinline__ void wait_operands4(double (&qa)[2][NB], double (&qb)
   }
 }
 
+// one 16-row group's operands only (the lean packed instances: single-buffered operands, control_pack_impl.hpp)
+template <int KS, int NB, int Q, int G>
+struct OperandReads4One
+{
+  static __device__ __forceinline__ void run(unsigned ax, double (&qa)[NB], double (&qb)[NB])
+  {
+    constexpr int off = (16 * Q * KS + 4 * G) * 8;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qa[G]) : "v"(ax), "n"(off) : "memory");
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qb[G]) : "v"(ax), "n"(off + 32 * KS * 8) : "memory");
+    if constexpr (G + 1 < NB) OperandReads4One<KS, NB, Q, G + 1>::run(ax, qa, qb);
+  }
+};
+template <int NB>
+__device__ __forceinline__ void wait_operands4_one(double (&qa)[NB], double (&qb)[NB])
+{
+  if constexpr (NB == 3) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qa[0]), "+v"(qa[1]), "+v"(qa[2]), "+v"(qb[0]), "+v"(qb[1]), "+v"(qb[2]));
+  } else {
+    static_assert(NB == 2, "lean packed instances: K = 5 or 10");
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qa[0]), "+v"(qa[1]), "+v"(qb[0]), "+v"(qb[1]));
+  }
+}
+
 // v + (v rotated right by N lanes inside its row of 16 lanes)
 template <int N>
 __device__ __forceinline__ double add_row_ror(double v)

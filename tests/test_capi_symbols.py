@@ -134,3 +134,31 @@ def test_timed_control_instances_leave_room_for_the_record_sum():
     assert seen == 408   # 2 models x K in {5, 10} x stage outputs on / off, + 2 x 2 resident instances
     sums = [k for n, k in demangled(os.path.join(build, "control_kernel.o")).items() if "ck_records_sum_kernel" in n]
     assert len(sums) == 2 and all(int(k["vgpr_count"]) <= 32 and int(k["group_segment_fixed_size"]) == 0 for k in sums), sums
+
+
+def test_packed_timed_instances_fit_four_wavefronts_per_simd():
+    """Round 6: the timed instances of the several-agents-per-wavefront kernel (no stage outputs) that are compiled for FOUR
+    wavefronts per SIMD -- K = 5 at every group size, K = 10 at 16 lanes per agent (yaml's T = 50: round 5 had 162-164
+    registers, three per SIMD) -- take <= 128 registers and no scratch.  What keeps the K = 10 instance there: lambda_k / phi_k
+    read where D is formed (not preloaded), one accumulator set for the four agents of a wavefront (csrc/control_pack_impl.hpp).
+    No instance uses scratch."""
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import kernel_resources as kr
+    build = os.path.join(os.path.dirname(capi.LIB_PATH), "..", "csrc", "build")
+    seen = 0
+    for k in kr.kernels(os.path.join(build, "control_pack_kernel.o")):
+        if "vgpr_count" not in k:
+            continue
+        name = subprocess.run(["c++filt", k["name"]], capture_output=True, text=True).stdout.strip()
+        if "control_pack_kernel<" not in name:
+            continue
+        assert int(k["private_segment_fixed_size"]) == 0, (name, k)
+        four = (", 5, false, " in name) or (", 10, false, 16, " in name)   # <MODEL, KC, STAGES = false, L, WPB>
+        if four:
+            assert int(k["vgpr_count"]) <= 128, (name, k)
+            seen += 1
+        elif ", 10, " in name:
+            assert int(k["vgpr_count"]) <= 168, (name, k)   # three per SIMD
+    assert seen == 8   # 2 models x (K = 5: L in {8, 16, 32}; K = 10: L = 16)
