@@ -23,7 +23,7 @@ def main():
     a = ap.parse_args()
     import numpy as np
     import torch
-    import bench
+    import bench_legs as bench
     from ergodic_exploration_amd import capi
     if a.lanes:
         capi.set_option(capi.OPT_AGENT_LANES, a.lanes)
