@@ -70,9 +70,11 @@ __host__ __device__ constexpr int wave_lds_elems(int K, int A, int S)
 #ifndef EEA_PACK_LEAN
 #define EEA_PACK_LEAN 0
 #endif
-constexpr int waves_per_simd(int KC, bool STAGES, int L)
+constexpr int waves_per_simd(int KC, bool STAGES, int L, int SM)
 {
-  return KC == 5 ? 4 : ((!STAGES && (L == 16 || EEA_PACK_LEAN != 0)) ? EEA_PACK_WAVES_K10 : 3);
+  // K = 10, four per SIMD: 16 lanes per agent (one accumulator set), and 8 lanes per agent at <= 3 steps per lane (SM = 3:
+  // configs[1]'s T = 20 -- a quarter less per-step state instead)
+  return KC == 5 ? 4 : ((!STAGES && (L == 16 || (L == 8 && SM == 3) || EEA_PACK_LEAN != 0)) ? EEA_PACK_WAVES_K10 : 3);
 }
 
 // row_shr:N inside the 16-lane row, lanes without a source read 0
@@ -147,13 +149,18 @@ __device__ __forceinline__ int block_agent(int h, int bb)
   else return h;
 }
 
-// MODEL, KC (5 or 10), STAGES as in control_wave_kernel; L = lanes per agent; WPB = wavefronts per workgroup
-template <int MODEL, int KC, bool STAGES, int L, int WPB>
-__global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L)) void control_pack_kernel(const ControlParams<double> p_arg, const unsigned B,
+// MODEL, KC (5 or 10), STAGES as in control_wave_kernel; L = lanes per agent; WPB = wavefronts per workgroup; SM = the most
+// steps a lane owns in this instance (3 or 4 = wave::kMaxS): the per-step state is SM-element register arrays, and a horizon
+// of <= 3 L steps (configs[1]: T = 20 on 8 lanes) does not have to carry a fourth, empty element of each through the kernel
+template <int MODEL, int KC, bool STAGES, int L, int WPB, int SM = wave::kMaxS>
+__global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L, SM)) void control_pack_kernel(const ControlParams<double> p_arg, const unsigned B,
                                                                      const int S_arg, const int rollout_arg)
 {
   using R = double;
   (void)p_arg;  // read through the kernel-argument segment below
+  constexpr int kLay = wave::kMaxS;  // the LDS layouts (hand-over of the controls between steps) are the same for every SM
+  constexpr int kMaxS = SM;          // ... the register arrays and the slot loops are not (shadows wave::kMaxS from here on)
+  static_assert(SM == 3 || SM == wave::kMaxS, "steps per lane: 3 or 4");
   static_assert(L == 8 || L == 16 || L == 32, "lanes per agent");
   static_assert(KC == 5 || KC == 10, "block contraction: K = 5 or 10");
   constexpr int A = kWave / L;
@@ -208,7 +215,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L)) void con
   // steps, all others S - 1; the last slot then holds r steps per agent, whose gradient all lanes take together (8 lanes per
   // step, below) instead of a full pass at r / L of the lanes
   const int r_top = T - L * (S - 1);
-  const bool top_heavy = S == kMaxS && r_top >= 1 && r_top <= L / 8;  // wavefront-uniform
+  const bool top_heavy = SM == kLay && S == kLay && r_top >= 1 && r_top <= L / 8;  // wavefront-uniform
   const int i0 = top_heavy ? (tl < r_top ? S * tl : S * r_top + (S - 1) * (tl - r_top)) : S * tl;
   const int cnt = top_heavy ? (tl < r_top ? S : S - 1) : max(0, min(S, T - i0));
   // lanes of an agent that own a step in slot j
@@ -221,7 +228,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L)) void con
   // the controls a step leaves for the next one change hands in LDS (everything there is dead between the update and the
   // next forward half): s_next[r][4 L al + step index], read back one column to the right (a rejected agent left nothing
   // there: it stays rejected, below)
-  R* const s_next = sm + kMaxS * L * al;
+  R* const s_next = sm + kLay * L * al;
   if (step == 0) {  // wavefront-uniform
 #pragma unroll
     for (int j = 0; j < kMaxS; ++j) {
@@ -244,9 +251,9 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L)) void con
       if (j < S) {
         const int src = i0 + j + 1;
         if (agent_in && j < cnt && src < T) {
-          vx[j] = s_next[0 * kMaxS * kWave + src];
-          vy[j] = s_next[1 * kMaxS * kWave + src];
-          w[j] = s_next[2 * kMaxS * kWave + src];
+          vx[j] = s_next[0 * kLay * kWave + src];
+          vy[j] = s_next[1 * kLay * kWave + src];
+          w[j] = s_next[2 * kLay * kWave + src];
         }
         if (MODEL == kModelSimpleCart && j < cnt && !(fabs(vy[j]) < R(1.0e-12))) bad = true;
       }
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L)) void con
     // instead of 8.0 us) they are 4 NB^2 registers on top of the accumulators and the per-step state: the kernel's register
     // peak (146 of 162).  The 16-lane instances, compiled for four wavefronts per SIMD, read them where they are used: the
     // tables are 800 bytes, L1-resident, and the other wavefronts of the SIMD cover the latency.
-    constexpr bool kPreload = !kOneSet;
+    constexpr bool kPreload = !kOneSet && !(L == 8 && SM == 3);
     R lamv[kPreload ? NB : 1][kPreload ? NB : 1], phiv[kPreload ? NB : 1][kPreload ? NB : 1];
     if constexpr (kPreload) {
 #pragma unroll
@@ -825,6 +832,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L)) void con
       }
     }
   }
+  if constexpr (SM == kLay) {
   if (top_heavy) {  // wavefront-uniform
     // The tail slot, all lanes together (control_wave_kernel's cooperative tail with BLOCK <-> AGENT): lane l = 8 st + sub
     // works on tail step e = (l % L) / 8 of ITS OWN agent -- the step of that agent's lane e --, rows k2 = sub and sub + 8 of
@@ -928,6 +936,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L)) void con
       g1[jt] = act ? eyj + g1[jt] : R(0);
     }
   }
+  }  // SM == kLay
   if (STAGES && agent_ok) {
 #pragma unroll
     for (int j = 0; j < kMaxS; ++j) {
@@ -1051,9 +1060,9 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L)) void con
         ut[3 * i + 1] = u[1];
         ut[3 * i + 2] = u[2];
         if (step + 1 < n_steps) {  // wavefront-uniform: hand-over to the next step
-          s_next[0 * kMaxS * kWave + i] = u[0];
-          s_next[1 * kMaxS * kWave + i] = u[1];
-          s_next[2 * kMaxS * kWave + i] = u[2];
+          s_next[0 * kLay * kWave + i] = u[0];
+          s_next[1 * kLay * kWave + i] = u[1];
+          s_next[2 * kLay * kWave + i] = u[2];
         }
         if (STAGES && p.rhot != nullptr) {
           R* const o = p.rhot + 3 * (static_cast<size_t>(T) * b + i);

@@ -14,8 +14,14 @@ hipError_t launch_pack_one(const ControlParams<double>& p, unsigned B, bool roll
   const int S = (p.T + L - 1) / L;
   const size_t lds = static_cast<size_t>(kPackWPB) * pack::wave_lds_elems(KC, A, S) * sizeof(double);
   const unsigned waves = (B + A - 1) / A;
-  hipLaunchKernelGGL((pack::control_pack_kernel<MODEL, KC, STAGES, L, kPackWPB>), dim3((waves + kPackWPB - 1) / kPackWPB),
-                     dim3(kPackWPB * kWave), lds, stream, p, B, S, rollout_only ? 1 : 0);
+  // (horizons of <= 3 steps per lane take the instance whose per-step register arrays have three elements)
+  if (S <= 3) {
+    hipLaunchKernelGGL((pack::control_pack_kernel<MODEL, KC, STAGES, L, kPackWPB, 3>), dim3((waves + kPackWPB - 1) / kPackWPB),
+                       dim3(kPackWPB * kWave), lds, stream, p, B, S, rollout_only ? 1 : 0);
+  } else {
+    hipLaunchKernelGGL((pack::control_pack_kernel<MODEL, KC, STAGES, L, kPackWPB, pack::kMaxS>), dim3((waves + kPackWPB - 1) / kPackWPB),
+                       dim3(kPackWPB * kWave), lds, stream, p, B, S, rollout_only ? 1 : 0);
+  }
   return hipGetLastError();
 }
 
