@@ -236,7 +236,10 @@ eea_engine* make_engine(const World& w, unsigned k, double horizon)
 
 // `passes` consensus passes of n agents (two agent groups on two streams) through the device-bound exchange, lag 1;
 // returns the final u0 (3 x n) and the number of agents that ever reported a status != 0
-mat bound_consensus_passes(const World& w, eea_comm* c, const mat& poses, int passes, int* bad_status, bool lockstep = true)
+// gated (round 6, ABI 6): no in-kernel flag wait and no event -- every consuming launch of EVERY group sits behind a one-wavefront
+// gate (eea_stream_wait_flag) for the flag of pass i - lag; the form for exchanges with a collective kernel
+mat bound_consensus_passes(const World& w, eea_comm* c, const mat& poses, int passes, int* bad_status, bool lockstep = true,
+                           bool gated = false, int lag = 1)
 {
   const unsigned n = poses.n_cols();
   eea_engine* e = make_engine(w, K, 20.0);
@@ -249,6 +252,7 @@ mat bound_consensus_passes(const World& w, eea_comm* c, const mat& poses, int pa
   int* const d_status = static_cast<int*>(d.alloc(sizeof(int) * n));
   unsigned* const d_ready = static_cast<unsigned*>(d.alloc(sizeof(unsigned) * n));
   unsigned* const d_flag = static_cast<unsigned*>(d.alloc(sizeof(unsigned)));
+  unsigned* const d_gate_timeouts = static_cast<unsigned*>(d.alloc(sizeof(unsigned)));
   double* d_arec[NB];
   double* d_sum[NB];
   for (int s = 0; s < NB; ++s) {
@@ -263,7 +267,7 @@ mat bound_consensus_passes(const World& w, eea_comm* c, const mat& poses, int pa
   const unsigned gb[3] = { 0, n / 2, n };
   for (int i = 0; i < passes; ++i) {
     const unsigned seq = static_cast<unsigned>(i) + 1;
-    const int slot = i % NB, src = (i - 1) % NB;
+    const int slot = i % NB, src = (i - lag + NB) % NB;
     for (int g = 0; g < 2; ++g) {
       const unsigned first = gb[g], cnt = gb[g + 1] - gb[g];
       eea_batch_io io{};
@@ -274,11 +278,15 @@ mat bound_consensus_passes(const World& w, eea_comm* c, const mat& poses, int pa
       io.d_ck_rec = d_arec[slot] + static_cast<size_t>(L) * first;
       io.d_rec_ready = d_ready + first;
       io.rec_seq = seq;
-      if (i >= 1) {
+      if (i >= lag && gated) {
+        io.d_ck_shared = d_sum[src];
+        io.ck_shared_parts = 1;
+        throw_on_error(eea_stream_wait_flag(d_flag, seq - static_cast<unsigned>(lag), d_gate_timeouts, streams[g]));
+      } else if (i >= lag) {
         io.d_ck_shared = d_sum[src];
         io.ck_shared_parts = 1;
         io.d_ck_flag = d_flag;
-        io.ck_flag_seq = seq - 1;
+        io.ck_flag_seq = seq - static_cast<unsigned>(lag);
         // more than one rank: the second group consumes stream-ordered (the rule of eea_comm_records_exchange_bound: its
         // execution slots are where the collective kernel lands)
         if (g == 1 && eea_comm_nranks(c) > 1) throw_on_error(eea_comm_wait(c, src, streams[g]));
@@ -296,6 +304,9 @@ mat bound_consensus_passes(const World& w, eea_comm* c, const mat& poses, int pa
     hip_check(hipMemcpy(h_status.data(), d_status, sizeof(int) * n, hipMemcpyDeviceToHost));
     for (int st : h_status) *bad_status += st != 0;
   }
+  unsigned gate_timeouts = 0;
+  hip_check(hipMemcpy(&gate_timeouts, d_gate_timeouts, sizeof(unsigned), hipMemcpyDeviceToHost));
+  *bad_status += static_cast<int>(gate_timeouts);
   mat u(3, n);
   hip_check(hipMemcpy(u.memptr(), d_u0, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
   for (hipStream_t s : streams) (void)hipStreamDestroy(s);
@@ -304,7 +315,7 @@ mat bound_consensus_passes(const World& w, eea_comm* c, const mat& poses, int pa
 }
 
 // (4): the device-bound exchange with two ranks
-void test_bound_exchange_two_ranks(unsigned n0, unsigned n1, int passes = 5, bool lockstep = true)
+void test_bound_exchange_two_ranks(unsigned n0, unsigned n1, int passes = 5, bool lockstep = true, bool gated = false, int lag = 1)
 {
   const World w;
   const unsigned N = n0 + n1;
@@ -316,7 +327,7 @@ void test_bound_exchange_two_ranks(unsigned n0, unsigned n1, int passes = 5, boo
   int bad_ref = 0;
   mat u_ref;
   for (int turn = 0; turn < 2; ++turn) {
-    if (turn == g_rank) u_ref = bound_consensus_passes(w, local, poses, passes, &bad_ref, lockstep);
+    if (turn == g_rank) u_ref = bound_consensus_passes(w, local, poses, passes, &bad_ref, lockstep, gated, lag);
     proc_ranks::barrier(g_shared, 2);
   }
   eea_comm_destroy(local);
@@ -325,7 +336,7 @@ void test_bound_exchange_two_ranks(unsigned n0, unsigned n1, int passes = 5, boo
   eea_comm* const c = next_comm();
   const unsigned first = rank == 0 ? 0 : n0, n = rank == 0 ? n0 : n1;
   int bad = -1;
-  const mat u = bound_consensus_passes(w, c, cols(poses, first, n), passes, &bad, lockstep);
+  const mat u = bound_consensus_passes(w, c, cols(poses, first, n), passes, &bad, lockstep, gated, lag);
   CHECK(bad == 0);
   CHECK(collective_kernels_gave_up() == 0);
   CHECK(u.n_cols() == n);
@@ -336,8 +347,9 @@ void test_bound_exchange_two_ranks(unsigned n0, unsigned n1, int passes = 5, boo
   // (every further dependent pass amplifies the difference about tenfold through the warm start: 8 passes -> 1e-6)
   const double bar = passes <= 5 ? 1e-9 : 1e-9 * std::pow(10.0, passes - 5);
   CHECK(wu <= bar);
-  std::printf("  rank %d: device-bound exchange %u + %u agents, lag 1, %d passes%s: |u diff| %.2e, agents timed out %d, collective kernels that gave up %d\n",
-              rank, n0, n1, passes, lockstep ? "" : " FREE-RUNNING (no host wait)", wu, bad, collective_kernels_gave_up());
+  std::printf("  rank %d: %s exchange %u + %u agents, lag %d, %d passes%s: |u diff| %.2e, agents / gates timed out %d, collective kernels that gave up %d\n",
+              rank, gated ? "GATED" : "device-bound", n0, n1, lag, passes, lockstep ? "" : " FREE-RUNNING (no host wait)", wu, bad,
+              collective_kernels_gave_up());
   eea_comm_destroy(c);
 }
 
@@ -454,6 +466,10 @@ int main(int argc, char** argv)
     test_bound_exchange_two_ranks(300, 300);
     test_bound_exchange_two_ranks(77, 130);
     test_bound_exchange_two_ranks(512, 512, 8, false);
+    // round 6: the gated exchange (what bench.py and consensus_bench take with a communicator), lag 2 and 1
+    test_bound_exchange_two_ranks(300, 300, 6, true, true, 2);
+    test_bound_exchange_two_ranks(77, 130, 5, true, true, 1);
+    test_bound_exchange_two_ranks(512, 512, 8, false, true, 2);
     test_grid_tile_two_ranks();
   } catch (const std::exception& e) {
     std::printf("FAIL exception: %s\n", e.what());

@@ -408,6 +408,7 @@ eea_status eea_stream_wait_flag(const unsigned* d_flag, unsigned seq, unsigned* 
  * those buffers between launches (new poses), not the pointers.  Across launches the protocol continues: pass 0 of a launch
  * consumes the record of the last passes of the launch before (the first `lag` passes ever consume an empty record: own c_k).
  * With several ranks every rank creates and launches its plan the same number of times (the all-reduces pair up in order).
+ * A plan refers to its engine and communicator: destroy it before either.
  * EEA_ERR_UNSUPPORTED: the collective library cannot be captured -- use the per-call form.  No reference counterpart
  * (decentralised ergodic control shares c_k, README.md:225-227). */
 typedef struct eea_consensus_plan eea_consensus_plan;

@@ -66,6 +66,8 @@ def test_two_ranks_on_one_gpu_through_the_rccl_test_double():
     out = subprocess.run([os.path.join(BUILD, "rank_tests")], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "0 failures" in out.stdout and "ranks2:" in out.stdout
+    # round 6: the GATED exchange between the two ranks (lock-step at lag 2 and 1, free-running at lag 2), no gate timed out
+    assert out.stdout.count("GATED exchange") >= 6, out.stdout
     # the binary has no link dependency on any RCCL; with the fake in front, that is what dlopen("librccl.so.1") finds
     ldd = subprocess.run(["ldd", os.path.join(BUILD, "rank_tests")], capture_output=True, text=True, env=env).stdout
     assert "rccl" not in ldd
