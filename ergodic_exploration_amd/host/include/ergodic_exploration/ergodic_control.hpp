@@ -65,6 +65,11 @@ public:
     eea_engine* e = nullptr;
     throw_on_error(eea_create(&cfg, &e));  // std::invalid_argument when steps == 1, like the reference
     engine_ = std::shared_ptr<eea_engine>(e, eea_destroy);
+    // The reference's member is a default-constructed Target -- no Gaussians -- until setTarget is called, and control()
+    // then divides 0 / 0 in Target::fill (target.cpp:87) and returns NaN (ergodic_control.hpp:411-413).  The C ABI answers
+    // a control call without a target with EEA_ERR_NO_TARGET; the CLASS reproduces the reference: it installs the same
+    // default target (an empty Gaussian list is a target whose grid is 0 / 0), so control() before setTarget is NaN here too.
+    throw_on_error(eea_set_target_gaussians(engine_.get(), 0u, nullptr, nullptr));
   }
 
   // one receding-horizon optimisation; returns the first twist of the updated control signal

@@ -380,6 +380,23 @@ static void test_ergodic_control()
     CHECK_NEAR(u(1), 0.29234914265332201, 1e-9);
     CHECK_NEAR(u(2), 0.0, 1e-9);
   }
+  // setTarget skipped: the reference's default Target has no Gaussians, Target::fill divides 0 / 0 and control() returns NaN
+  // (ergodic_control.hpp:411-413, SURVEY.md hazard 12) -- the class does the same (the C ABI alone answers EEA_ERR_NO_TARGET);
+  // once a target is set the same object works normally
+  {
+    const GridMap grid(0.0, 12.0, 0.0, 6.0, 0.1, GridData(120 * 60, 0));
+    mat Rinv(3, 3);
+    for (int i = 0; i < 3; ++i) Rinv(i, i) = 1.0;
+    ErgodicControl<models::Omni> ec(models::Omni(), Collision(0.7, 1.0, 0.2, 0.8), 0.1, 2.0, 0.1, 1.0, 5, 10, 10, Rinv,
+                                    vec{ -1.0, -1.0, -2.0 }, vec{ 1.0, 1.0, 2.0 });
+    const vec u = ec.control(grid, vec{ 1.0, 1.0, 0.3 });
+    CHECK(std::isnan(u(0)) && std::isnan(u(1)) && std::isnan(u(2)));
+    ErgodicControl<models::Omni> ec2(models::Omni(), Collision(0.7, 1.0, 0.2, 0.8), 0.1, 2.0, 0.1, 1.0, 5, 10, 10, Rinv,
+                                     vec{ -1.0, -1.0, -2.0 }, vec{ 1.0, 1.0, 2.0 });
+    ec2.setTarget(Target({ Gaussian({ 2.5, 2.5 }, { 1.5, 1.5 }) }));
+    const vec v = ec2.control(grid, vec{ 1.0, 1.0, 0.3 });
+    CHECK(std::isfinite(v(0)) && std::isfinite(v(1)) && std::isfinite(v(2)));
+  }
   // horizon == dt is rejected at construction like the reference
   bool threw = false;
   try {
