@@ -176,7 +176,37 @@ __global__ __launch_bounds__(kBlock) void collision_check_kernel(const Collision
   hit[q] = collision_check(c, grid, pose[3 * static_cast<size_t>(q)], pose[3 * static_cast<size_t>(q) + 1]) ? 1 : 0;
 }
 
-__device__ __forceinline__ double wrap_pi_d(double rad) { return wrap_pi<double>(rad); }
+// Round 6: the constant-twist rollouts of validate_control / the dynamic window are instruction-issue bound (20 dependent steps
+// per lane of sincos + normalize_angle_PI + a byte lookup: ~245 instructions per step with the device library's sincos and the
+// literal wrap, whose quotient is an fp64 DIVISION).  EEA_TICK_FAST_TRIG (default): sin / cos by the engine's own sincospi_r
+// (exact reduction, max error 1.9e-16: common.hpp) of theta / pi, and the wrap's quotient by a multiplication with 1 / (2 pi) --
+// a quotient that lands on the other side of an integer is repaired by the wrap's own range fixes, everything else is bitwise
+// the literal form.  The outputs the reference pins are integer decisions (collision verdicts, the chosen sample), which
+// tests/test_gpu_collision_parity.py / test_gpu_dwa_parity.py / test_gpu_fleet_tick.py check bit for bit against the oracle.
+#ifndef EEA_TICK_FAST_TRIG
+#define EEA_TICK_FAST_TRIG 1
+#endif
+__device__ __forceinline__ double wrap_pi_d(double rad)
+{
+#if EEA_TICK_FAST_TRIG
+  const double pi = kPi, two_pi = 2.0 * kPi;
+  const double q = floor((rad + pi) * (1.0 / (2.0 * kPi)));
+  rad = (rad + pi) - q * two_pi;
+  if (rad < 0.0) rad += two_pi;
+  if (!(rad < two_pi)) rad -= two_pi;
+  return rad - pi;
+#else
+  return wrap_pi<double>(rad);
+#endif
+}
+__device__ __forceinline__ void tick_sincos(double th, double* s, double* c)
+{
+#if EEA_TICK_FAST_TRIG
+  sincospi_r<double>(th * (1.0 / kPi), s, c);
+#else
+  sincos(th, s, c);
+#endif
+}
 
 // one collision test through the inflated map (MAP) or by the ring search
 template <bool MAP>
@@ -215,7 +245,7 @@ __global__ __launch_bounds__(kBlock) void validate_control_kernel(const Collisio
   } else {
     const double vb0 = u0 * dt, vb1 = u1 * dt, vb2 = u2 * dt;
     double s, cc;
-    sincos(vb2, &s, &cc);
+    tick_sincos(vb2, &s, &cc);
     d0 = (vb0 * s + vb1 * (cc - 1.0)) / vb2;
     d1 = (vb1 * s + vb0 * (1.0 - cc)) / vb2;
     d2 = vb2;
@@ -223,7 +253,7 @@ __global__ __launch_bounds__(kBlock) void validate_control_kernel(const Collisio
   int ok = 1;
   for (unsigned i = 0; i < steps; ++i) {
     double s, cc;
-    sincos(th, &s, &cc);
+    tick_sincos(th, &s, &cc);
     x = x + (cc * d0 + (-s) * d1);
     y = y + (s * d0 + cc * d1);
     th = wrap_pi_d(th + d2);
@@ -309,7 +339,7 @@ __global__ __launch_bounds__(kDwaBlock) void dwa_control_kernel(const CollisionP
     } else {
       const double vb0 = u0 * d.dt, vb1 = u1 * d.dt, vb2 = u2 * d.dt;
       double sn, cs;
-      sincos(vb2, &sn, &cs);
+      tick_sincos(vb2, &sn, &cs);
       d0 = (vb0 * sn + vb1 * (cs - 1.0)) / vb2;
       d1 = (vb1 * sn + vb0 * (1.0 - cs)) / vb2;
       d2 = vb2;
@@ -319,10 +349,10 @@ __global__ __launch_bounds__(kDwaBlock) void dwa_control_kernel(const CollisionP
     bool hit = false;
     for (unsigned st = 0; st < d.steps; ++st) {
       double sn, cs;
-      sincos(th, &sn, &cs);
+      tick_sincos(th, &sn, &cs);
       x = x + (cs * d0 + (-sn) * d1);
       y = y + (sn * d0 + cs * d1);
-      th = wrap_pi<double>(th + d2);
+      th = wrap_pi_d(th + d2);
       if (pose_collides<MAP>(c, grid, m, x, y)) {
         hit = true;
         break;
@@ -331,7 +361,7 @@ __global__ __launch_bounds__(kDwaBlock) void dwa_control_kernel(const CollisionP
         const unsigned jj = cast_u32_x86(round(static_cast<double>(n_ref - 1) * t / tf));
         const double ex = xr[3 * jj + 0] - x, ey = xr[3 * jj + 1] - y;
         cost += sqrt(ex * ex + ey * ey);
-        cost += fabs(wrap_pi<double>(wrap_pi<double>(xr[3 * jj + 2]) - th));
+        cost += fabs(wrap_pi_d(wrap_pi_d(xr[3 * jj + 2]) - th));
         t += d.dt;
       }
     }
@@ -758,7 +788,7 @@ __global__ __launch_bounds__(kBlock) void integrate_twist_kernel(const double* _
   } else {
     const double vb0 = u0 * dt, vb1 = u1 * dt, vb2 = u2 * dt;
     double s, cc;
-    sincos(vb2, &s, &cc);
+    sincos(vb2, &s, &cc);  // (the device library's: one call per robot and tick, kept closest to libm)
     d0 = (vb0 * s + vb1 * (cc - 1.0)) / vb2;
     d1 = (vb1 * s + vb0 * (1.0 - cc)) / vb2;
     d2 = vb2;
