@@ -428,18 +428,10 @@ def tick_legs(torch, capi, np):
         move_only = timed(lambda: (capi.integrate_twist_batch(d_pose, d_u, 0.1, normalize_heading=True, stream=sp), d_vb_copy(d_u)), 200)
     src_moving = d_src.cpu().numpy()
     eng.close()
-    # What the two byte-lookup kernels of a tick should cost ("state the bound"):
-    #  * dwa_control_kernel<MAP, FLEET>: one workgroup per robot that needs the window, one lane per velocity sample, a rollout of
-    #    `steps` DEPENDENT steps per lane -- per step one sincos + ~12 fp64 operations + ONE byte of the inflated map (L2-resident:
-    #    the map is 33 KB).  The chain is latency, not bytes: ~steps x (sincos ~60 + arithmetic ~30 + L2 byte ~120 cycles ~ 0.1 us at
-    #    2.3 GHz) ~ 2 us per wavefront, and with 2 wavefronts per robot (120 samples) x 4096 robots = 8192 wavefronts on 1024 SIMDs
-    #    x 8 resident = one round: the floor is ~2-4 us of chain + launch (~5 us), against 34 us measured -> the kernel is 4-5x its
-    #    dependent-chain floor; the difference is the objective (distance to optTraj: `steps` more dependent sqrt / loads of the
-    #    reference trajectory per step in the "traj" mode) and the serial first-minimum reduction over 120 samples by lane 0.
-    #  * inflate_kernel (dilation of the occupied cells by the ring offsets): bytes = grid read once (28.8 KB) + every occupied
-    #    cell stamps |offsets| ~ 250 bytes of the map; at ~10 % occupied cells of 240 x 120 that is ~0.7 MB of scattered byte
-    #    stores -> HBM/L2 bandwidth is irrelevant (<< 1 us at 8 TB/s); the floor is the launch (~5 us) + one round of the
-    #    workgroups' list-then-stamp (two barriers), against 18 us measured.
+    # What the two byte-lookup kernels of a tick should cost ("state the bound"): DESIGN.md section 4.5 --
+    # dwa_control_kernel<MAP, FLEET> is instruction-issue bound (~245 instructions per rollout step before round 6's fast trig:
+    # sincos, wrap, the two exact divisions of world2Grid, one L2-resident byte, the objective), never bandwidth bound (<= 9.8 M
+    # byte lookups per tick of a 33 KB map); inflate_kernel: < 1 MB of scattered byte stores, launch + two barriers.
     lookups = B * 120 * 20
     return {"tick_kernels": {"grid": "%dx%d int8 @ %.2f m" % (xs, ys, res), "dwa_window": "3 x 8 x 5 samples x 20 steps",
                              "note": "device microseconds per call (HIP events on the launch stream); ring search: dependent byte "
@@ -454,12 +446,11 @@ def tick_legs(torch, capi, np):
                                                                                                 "dwa_replan"))},
                            "sources_last_tick_moving": {n: int((src_moving == i).sum()) for i, n in
                                                         enumerate(("control", "dwa_follow", "dwa_reference", "dwa_replan"))},
-                           "bounds": {"dwa_window_lookups_per_tick_at_most": lookups,
-                                      "dwa_window_dependent_chain_floor_us": 4.0, "dilation_launch_floor_us": 5.0,
-                                      "note": "dwa_control_kernel<MAP, FLEET>: 20 dependent rollout steps per lane (sincos + one L2 byte "
-                                              "each): a latency chain of ~2-4 us + launch, not a bandwidth problem (the map is 33 KB); "
-                                              "inflate_kernel: < 1 MB of scattered byte stores, launch + two barriers ~5 us (bench.py "
-                                              "tick_legs carries the derivation)"},
+                           "bounds": {"dwa_window_lookups_per_tick_at_most": lookups, "dilation_launch_floor_us": 5.0,
+                                      "note": "dwa_control_kernel<MAP, FLEET>: instruction-issue bound (20 dependent rollout steps per "
+                                              "lane: sin/cos, wrap, two exact fp64 divisions of world2Grid, one L2-resident byte, the "
+                                              "objective), never a bandwidth problem (the map is 33 KB); inflate_kernel: < 1 MB of "
+                                              "scattered byte stores, launch + two barriers ~5 us (DESIGN.md section 4.5)"},
                            "note": "eea_tick_batch: step counters -> control() of the robots that follow no DWA twist -> optTraj "
                                    "rollout -> validate_control -> dynamic window per robot in its mode, one stream, no host round "
                                    "trip; us_per_tick: static poses (the robots in front of obstacles stay in the DWA branches); "
