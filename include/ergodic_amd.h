@@ -392,6 +392,8 @@ eea_status eea_comm_records_exchange_bound(eea_engine* e, eea_comm* c, unsigned 
  * wait is still for work enqueued before the waiter).  Bounded: after about a second the gate gives up, adds 1 to *d_timeouts
  * (optional) and lets the stream go on -- the consuming launches then read whatever the record's slot holds at that moment: a
  * time-out is an error to be reported (the producer never became resident), not a mode of operation.  No reference counterpart. */
+/* (No engine argument: the launch goes to the calling thread's CURRENT device, which must be the stream's -- it is after any
+ * eea_* call on an engine or communicator of that device.) */
 eea_status eea_stream_wait_flag(const unsigned* d_flag, unsigned seq, unsigned* d_timeouts, void* stream);
 
 /* ---- ABI 6: the consensus loop of a rank as ONE replayable device graph ----------------------------------------------------
