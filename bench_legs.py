@@ -196,20 +196,20 @@ def other_config_legs(args, torch, capi, np, spl, only=None, spinup_s=0.0):
     cases = [
         # short horizons: several agents share a wavefront (csrc/control_pack_impl.hpp) -- at the headline's 4096 agents a
         # pass is latency-bound (one or two wavefronts per SIMD), so each shape is also timed at the batch that fills the
-        # chip with resident wavefronts of the engine's choice of lanes per agent (4 x 1024 x 64 / lanes: four wavefronts per SIMD
-        # since round 6, K = 10 too)
+        # chip with resident wavefronts of the engine's choice of lanes per agent: TWO rounds of four wavefronts per SIMD
+        # (2 x 4 x 1024 x 64 / lanes agents; one round is 1.5 - 2 % slower: the tail of a launch is a larger share)
         dict(name="configs[0]", model="omni", K=5, dt=0.1, horizon=0.5, prec="f64", bounds=MAP_BOUNDS,
              means=[[2.5, 2.5]], sigmas=[[1.5, 1.5]]),
         dict(name="configs[0], chip-filling batch", model="omni", K=5, dt=0.1, horizon=0.5, prec="f64", bounds=MAP_BOUNDS,
-             means=[[2.5, 2.5]], sigmas=[[1.5, 1.5]], agents=32768),
+             means=[[2.5, 2.5]], sigmas=[[1.5, 1.5]], agents=65536),
         dict(name="configs[1]", model="simple_cart", K=10, dt=0.1, horizon=2.0, prec="f64", bounds=MAP_BOUNDS,
              means=MEANS, sigmas=SIGMAS),
         dict(name="configs[1], chip-filling batch", model="simple_cart", K=10, dt=0.1, horizon=2.0, prec="f64", bounds=MAP_BOUNDS,
-             means=MEANS, sigmas=SIGMAS, agents=32768),
+             means=MEANS, sigmas=SIGMAS, agents=65536),
         dict(name="explore_omni.yaml as shipped (K = 10, T = 50)", model="omni", K=10, dt=0.1, horizon=5.0, prec="f64",
              bounds=MAP_BOUNDS, means=MEANS, sigmas=SIGMAS),
         dict(name="explore_omni.yaml as shipped, chip-filling batch", model="omni", K=10, dt=0.1, horizon=5.0, prec="f64",
-             bounds=MAP_BOUNDS, means=MEANS, sigmas=SIGMAS, agents=16384),
+             bounds=MAP_BOUNDS, means=MEANS, sigmas=SIGMAS, agents=32768),
         dict(name="configs[2]", model="omni", K=20, dt=0.02, horizon=5.0, prec="f32", bounds=(0.0, 25.5, 0.0, 25.5),
              means=[[6.0, 6.0], [19.0, 12.0]], sigmas=[[3.0, 3.0], [3.0, 3.0]]),
         dict(name="configs[2] fp64 twin", model="omni", K=20, dt=0.02, horizon=5.0, prec="f64", bounds=(0.0, 25.5, 0.0, 25.5),
