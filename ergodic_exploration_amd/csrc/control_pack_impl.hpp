@@ -39,9 +39,18 @@ using wave::tab_stride;
 
 __host__ __device__ constexpr int d_stride(int K) { return (K * K + 3) & ~3; }  // K = 10: 100 (200 dwords = 8 mod 64), K = 5: 28
 constexpr int kTailElems = 24;  // hand-over space of the cooperative tail gradient, behind the agents' D: [3][8] reals
+// Between the two 16-row groups of a table: 8 reals (16 dwords).  A 16-byte staging store is served in groups of 8 contiguous
+// lanes on 32 banks of 4 bytes; with 8 or 16 lanes per agent those 8 lanes are rows {0..3} of BOTH 16-row groups of one block,
+// and 16 rows of 20 (K = 10) or 12 (K = 5) dwords are a multiple of 32 banks apart: every staging store was a two-way
+// conflict (SQ_LDS_BANK_CONFLICT 1.3 cycles per LDS instruction against the wavefront kernel's 0.13, profiles/r06_pack_pmc.txt).
+// Shifted by 16 banks the second group's four windows tile the banks the first group's leave free.
+#ifndef EEA_PACK_GROUP_PAD
+#define EEA_PACK_GROUP_PAD 8
+#endif
+constexpr int kGroupPad = EEA_PACK_GROUP_PAD;
 __host__ __device__ constexpr int region_elems(int K, int A)
 {
-  const int t = 2 * kStageRows * tab_stride(K), d = A * d_stride(K) + kTailElems;
+  const int t = 2 * (kStageRows * tab_stride(K) + kGroupPad), d = A * d_stride(K) + kTailElems;
   return ((t > d ? t : d) + 3) & ~3;
 }
 // the parked post-step headings: cos and sin, [S][64] each.  S is a launch argument: a horizon of <= 3 steps per lane leaves
@@ -204,8 +213,8 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L, SM)) void
 
   const int T = p.T;
   R* const sm = reinterpret_cast<R*>(smem_raw) + static_cast<size_t>(wv) * wave_lds_elems(KC, A, S);
-  R* const tabx = sm;  // [32 rows][KS]
-  R* const taby = tabx + kStageRows * KS;
+  R* const tabx = sm;  // [32 rows][KS], kGroupPad reals between rows 15 and 16
+  R* const taby = tabx + kStageRows * KS + kGroupPad;
   R* const s_cp = sm + region_elems(KC, A);  // cos of the post-step heading, [j][lane]
   R* const s_sp = s_cp + S * kWave;          // sin
   R* const s_D = tabx;                       // D of agent a at a * DS (after the contraction)
@@ -425,8 +434,9 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L, SM)) void
   const int cnt_p = !kOneSet ? cnt : (top_heavy ? (ptl < r_top ? S : S - 1) : max(0, min(S, T - S * ptl)));
   const int cnt_lower = lo ? cnt : cnt_p;  // steps of the lane whose point this lane stages in the first / second half-pass
   const int cnt_upper = lo ? cnt_p : cnt;
-  R* const st_lower = (lo ? tabx : taby) + trow * KS;  // staging the tile of the first half-pass's points
-  R* const st_upper = (lo ? taby : tabx) + trow * KS;  // ... of the second
+  const int trow_off = trow * KS + (trow >= 16 ? kGroupPad : 0);
+  R* const st_lower = (lo ? tabx : taby) + trow_off;  // staging the tile of the first half-pass's points
+  R* const st_upper = (lo ? taby : tabx) + trow_off;  // ... of the second
   struct Tab1
   {
     R a, b, two;  // T_k, T_{k+1}, 2 cos
@@ -461,12 +471,12 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L, SM)) void
   R qa[2][NB], qb[2][NB];
   const unsigned oaddr = wave::lds_addr(tabx + orow * KS + oi);
   constexpr bool kLean = (KC == 10) && (EEA_PACK_LEAN != 0) && !kOneSet;
-  auto read_operands4 = [&]() { wave::OperandReads4<KS, NB, 0, 0>::run(oaddr, qa, qb); };
+  auto read_operands4 = [&]() { wave::OperandReads4<KS, NB, 0, 0, kGroupPad>::run(oaddr, qa, qb); };
   auto operands4_ready = [&]() { wave::wait_operands4<NB>(qa, qb); };
   // lean: group q of the tile into the ONE operand set (index 0)
   auto read_group = [&](int q) {
-    if (q == 0) wave::OperandReads4One<KS, NB, 0, 0>::run(oaddr, qa[0], qb[0]);
-    else wave::OperandReads4One<KS, NB, 1, 0>::run(oaddr, qa[0], qb[0]);
+    if (q == 0) wave::OperandReads4One<KS, NB, 0, 0, kGroupPad>::run(oaddr, qa[0], qb[0]);
+    else wave::OperandReads4One<KS, NB, 1, 0, kGroupPad>::run(oaddr, qa[0], qb[0]);
   };
   auto group_ready = [&]() { wave::wait_operands4_one<NB>(qa[0], qb[0]); };
   auto mma4_group = [&](int h_arg, int q) {

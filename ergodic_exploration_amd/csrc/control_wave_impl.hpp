@@ -158,16 +158,18 @@ __device__ __forceinline__ unsigned lds_addr(const void* q)
 // at HALF the rate of two ds_read_b64 (8 instead of 2 x 2 LDS cycles, MI355X_MICROARCH.md "LDS"), and in 16-lane groups
 // the rows of this layout (k, k + 4, k + 8, k + 12: 20 dwords apart) collide pairwise: 8 more cycles per instruction --
 // SQ_LDS_BANK_CONFLICT 390 per agent, all of it from these reads (profiles/r04_lds_conflicts.txt).
-template <int KS, int NB, int Q, int G>
+// PAD (elements; the packed kernel): the second 16-row group of a table starts PAD elements later -- its rows then fall on the
+// banks the first group's rows leave free for the 16-byte staging stores (control_pack_impl.hpp kGroupPad)
+template <int KS, int NB, int Q, int G, int PAD = 0>
 struct OperandReads4
 {
   static __device__ __forceinline__ void run(unsigned ax, double (&qa)[2][NB], double (&qb)[2][NB])
   {
-    constexpr int off = (16 * Q * KS + 4 * G) * 8;
+    constexpr int off = (16 * Q * KS + Q * PAD + 4 * G) * 8;
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qa[Q][G]) : "v"(ax), "n"(off) : "memory");
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qb[Q][G]) : "v"(ax), "n"(off + 32 * KS * 8) : "memory");
-    if constexpr (G + 1 < NB) OperandReads4<KS, NB, Q, G + 1>::run(ax, qa, qb);
-    else if constexpr (Q == 0) OperandReads4<KS, NB, 1, 0>::run(ax, qa, qb);
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qb[Q][G]) : "v"(ax), "n"(off + (32 * KS + PAD) * 8) : "memory");
+    if constexpr (G + 1 < NB) OperandReads4<KS, NB, Q, G + 1, PAD>::run(ax, qa, qb);
+    else if constexpr (Q == 0) OperandReads4<KS, NB, 1, 0, PAD>::run(ax, qa, qb);
   }
 };
 // the compiler does not count hand-written DS operations: wait for them before the first use (the values are tied to
@@ -194,15 +196,15 @@ __device__ __forceinline__ void wait_operands4(double (&qa)[2][NB], double (&qb)
 }
 
 // one 16-row group's operands only (the lean packed instances: single-buffered operands, control_pack_impl.hpp)
-template <int KS, int NB, int Q, int G>
+template <int KS, int NB, int Q, int G, int PAD = 0>
 struct OperandReads4One
 {
   static __device__ __forceinline__ void run(unsigned ax, double (&qa)[NB], double (&qb)[NB])
   {
-    constexpr int off = (16 * Q * KS + 4 * G) * 8;
+    constexpr int off = (16 * Q * KS + Q * PAD + 4 * G) * 8;
     asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qa[G]) : "v"(ax), "n"(off) : "memory");
-    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qb[G]) : "v"(ax), "n"(off + 32 * KS * 8) : "memory");
-    if constexpr (G + 1 < NB) OperandReads4One<KS, NB, Q, G + 1>::run(ax, qa, qb);
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(qb[G]) : "v"(ax), "n"(off + (32 * KS + PAD) * 8) : "memory");
+    if constexpr (G + 1 < NB) OperandReads4One<KS, NB, Q, G + 1, PAD>::run(ax, qa, qb);
   }
 };
 template <int NB>
