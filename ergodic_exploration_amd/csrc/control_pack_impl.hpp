@@ -212,7 +212,11 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L, SM)) void
   const bool partner_in = pb < B && !(p.skip != nullptr && p.skip[pb < B ? pb : 0] != 0);
 
   const int T = p.T;
-  R* const sm = reinterpret_cast<R*>(smem_raw) + static_cast<size_t>(wv) * wave_lds_elems(KC, A, S);
+  // (the wavefront's LDS carve is a multiple of 32 bytes -- region_elems is rounded to 4 reals, the park is 128 S reals -- but S is
+  // a launch argument: told so, the compiler reads the rows of D in the gradient as 16-byte ds_read_b128 (4 LDS cycles, 64
+  // banks) like the wavefront kernel does, instead of ds_read2_b64 pairs (8 cycles, 32 banks))
+  R* const sm = static_cast<R*>(__builtin_assume_aligned(
+      reinterpret_cast<R*>(smem_raw) + static_cast<size_t>(wv) * wave_lds_elems(KC, A, S), 32));
   R* const tabx = sm;  // [32 rows][KS], kGroupPad reals between rows 15 and 16
   R* const taby = tabx + kStageRows * KS + kGroupPad;
   R* const s_cp = sm + region_elems(KC, A);  // cos of the post-step heading, [j][lane]
@@ -777,6 +781,15 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L, SM)) void
   //   edx_y = -pi/ly sin(b y) sum_k2 k2 U_{k2-1}(cos b y) H(k2),  H(k2) = sum_k1 D(k1,k2) cos(a_k1 x)
   R ex[STAGES ? kMaxS : 1], ey[STAGES ? kMaxS : 1];
   const R* const Da = s_D + al * DS;
+  // 16-byte reads of D's rows (K even): ds_read_b128 instead of the compiler's ds_read2_b64 pairs.  EEA_PACK_WIDE_D: 0 = never,
+  // 1 = slot loop, 2 = slot loop and the cooperative tail.  Same box: configs[1] (8 lanes per agent) +2.8 %, yaml T = 50 (16 lanes)
+  // +0.8 % -- but the 16-lane instance with four steps per lane sits AT 128 registers, and the aligned register quads of the
+  // wide reads cost it 12 - 28 bytes of scratch: it keeps the narrow reads (126 registers, no scratch)
+#ifndef EEA_PACK_WIDE_D
+#define EEA_PACK_WIDE_D 2
+#endif
+  constexpr bool kWideD = (K % 2 == 0) && (EEA_PACK_WIDE_D >= 1) && !(kOneSet && SM == kLay);
+  constexpr bool kWideTail = (K % 2 == 0) && (EEA_PACK_WIDE_D >= 2) && !(kOneSet && SM == kLay);
 #pragma unroll
   for (int j = 0; j < kMaxS; ++j) {
     if (STAGES) ex[j] = ey[j] = R(0);
@@ -804,12 +817,24 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L, SM)) void
       for (int k2 = 1; k2 < K; ++k2) {
         const R* const row = Da + k2 * K;
         R h = R(0);
-#pragma unroll
-        for (int i = 0; i < K; ++i) {
-          const R d = row[i];
+        // the row of D, two entries per LDS read where the rows are 16-byte aligned (K even: 80-byte rows, agents 800 bytes apart):
+        // ds_read_b128 -- 4 LDS cycles on 64 banks -- instead of the ds_read2_b64 pairs the compiler forms from 8-byte reads
+        // (8 cycles, 32 banks: the alignment of a row of another agent's D is not visible to it)
+        auto entry = [&](int i, R d) {
           if (i > 0) G[i] += d * t0;
           if (i == 0) h = d;  // cos(0 x) = 1
           else h += d * cxa[i];
+        };
+        if constexpr (kWideD) {
+#pragma unroll
+          for (int i = 0; i < K; i += 2) {
+            const double2 dd = *reinterpret_cast<const double2*>(row + i);
+            entry(i, dd.x);
+            entry(i + 1, dd.y);
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < K; ++i) entry(i, row[i]);
         }
         accy = wave::fma_k(u0 * h, k2, accy);
         const R un = twoy * u0 - um;
@@ -900,9 +925,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L, SM)) void
     auto tail_row = [&](int k2, R cyv, R ksv) {  // k2 < K; cyv = cos(k2 b), ksv = k2 sin(k2 b) (both 0: row not taken)
       const R* const row = Da + k2 * K;
       R a0 = R(0), a1 = R(0), b0 = R(0), b1 = R(0);
-#pragma unroll
-      for (int k1 = 0; k1 < K; ++k1) {
-        const R d = row[k1];
+      auto entry = [&](int k1, R d) {
         if (k1 & 1) {
           a1 += d * cxa[k1];
           b1 += d * kux[k1];
@@ -910,6 +933,17 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L, SM)) void
           a0 += d * cxa[k1];
           if (k1 > 0) b0 += d * kux[k1];
         }
+      };
+      if constexpr (kWideTail) {  // (two entries per LDS read where the rows are 16-byte aligned, as in the slot loop above)
+#pragma unroll
+        for (int k1 = 0; k1 < K; k1 += 2) {
+          const double2 dd = *reinterpret_cast<const double2*>(row + k1);
+          entry(k1, dd.x);
+          entry(k1 + 1, dd.y);
+        }
+      } else {
+#pragma unroll
+        for (int k1 = 0; k1 < K; ++k1) entry(k1, row[k1]);
       }
       tpx += cyv * (b0 + b1);
       tpy += ksv * (a0 + a1);
