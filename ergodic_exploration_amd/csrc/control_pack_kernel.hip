@@ -59,13 +59,16 @@ bool control_pack_eligible(const ControlParams<double>& p, int lanes)
 }
 
 // Lanes per agent for a batch of B agents: 0 = the wavefront-per-agent kernel.  `forced` (EEA_OPT_AGENT_LANES): 64 = never
-// pack, 8 / 16 / 32 = that group size where eligible; 0 = by the cost model below, fitted to profiles/r05_pack_sweep.txt:
+// pack, 8 / 16 / 32 = that group size where eligible; 0 = by the cost model below, refitted in round 6 to the instances that run
+// four wavefronts per SIMD (profiles/r06_pack_points.txt, profiles/r06_ablation.txt item 11):
 //   * a wavefront of either kernel issues I(S) = 600 + 580 S pipe slots (K = 10; 500 + 250 S at K = 5), S = ceil(T / L) steps
-//     per lane -- measured SQ_INSTS_VALU: 1071 / 1540 / 2010 at S = 1 / 2 / 3 with L = 64 and 1099 / 1568 / 2039 / 2509 with
-//     L = 8, matrix instructions counted four times -- whatever the number of agents in it;
-//   * w wavefronts per SIMD retire an instruction per max(16, 5 w) cycles each: one wavefront alone waits on its own
-//     dependency chains (T = 20, one wavefront per SIMD: 7.6 us = 16 cycles per instruction), from ~3 per SIMD on the pipe is
-//     the limit (0.75 - 0.8 busy);
+//     per lane (SQ_INSTS_VALU, matrix instructions counted four times) -- whatever the number of agents in it; a top-heavy
+//     horizon's last slot costs about 0.6 slots; with 16 lanes per agent a slot whose steps all lie in lanes 0..7 takes one
+//     half-pass instead of two (x 0.8); the 8-lane K = 10 instances retire their instructions ~20 % slower (two accumulator sets);
+//   * w wavefronts of a SIMD retire an instruction per c(w) = max(12.5, 4.3 w) cycles each: a lone wavefront waits on its own
+//     dependency chains (measured 11.6 - 12.9 cycles per instruction at w <= 2), from ~3 per SIMD on the pipe is the limit
+//     (16 - 17 at w = 4); more wavefronts than the instance's residency R (4, or 3 for the 32-lane instances and the 8-lane one at
+//     four steps per lane) run in rounds: floor(w / R) rounds at c(R) + the rest at c(w mod R);
 //   * the call is taken to be one of TWO concurrent agent groups (the launch form of bench.py and AgentBatch): w = 2 x its own
 //     wavefronts / 1024 SIMDs.
 // Ties go to the narrower group; a batch of fewer than 256 wavefronts is not worth packing.
@@ -73,6 +76,7 @@ int control_pack_lanes(const ControlParams<double>& p, unsigned B, int forced)
 {
   if (forced == 64) return 0;
   if (forced == 8 || forced == 16 || forced == 32) return control_pack_eligible(p, forced) ? forced : 0;
+  auto c = [](double w) { return 4.3 * w > 12.5 ? 4.3 * w : 12.5; };
   double best = 0.0;
   int best_l = 0;
   for (int lanes = 64; lanes >= 8; lanes /= 2) {
@@ -82,12 +86,15 @@ int control_pack_lanes(const ControlParams<double>& p, unsigned B, int forced)
     const unsigned waves = (B + A - 1) / A;
     if (lanes < 64 && waves < 256u) continue;
     const double w = 2.0 * static_cast<double>(waves) / 1024.0;
-    // (a top-heavy horizon's last slot -- T = 3 L + 1 .. 3 L + L / 8, its gradient taken by all lanes together -- costs about
-    // 0.6 slots: yaml T = 50 on 16 lanes 20.85 -> 19.4 us per 12288-agent pass)
     const int r_top = p.T - lanes * (S - 1);
     const double slots = (lanes < 64 && S == pack::kMaxS && r_top <= lanes / 8) ? S - 0.4 : static_cast<double>(S);
-    const double insts = p.K == 5 ? 500.0 + 250.0 * slots : 600.0 + 580.0 * slots;
-    const double cost = insts * (5.0 * w > 16.0 ? 5.0 * w : 16.0);
+    double insts = p.K == 5 ? 500.0 + 250.0 * slots : 600.0 + 580.0 * slots;
+    if (lanes == 16 && (p.T + S - 1) / S <= 8) insts *= 0.8;  // every slot's steps in lanes 0..7: one half-pass per slot
+    if (lanes == 8 && p.K != 5) insts *= 1.2;
+    // wavefronts per SIMD the instance is compiled for (control_pack_impl.hpp waves_per_simd; the wavefront kernel: 4)
+    const double R = (lanes == 32 || (lanes == 8 && S > 3 && p.K != 5)) ? 3.0 : 4.0;
+    const double full = static_cast<double>(static_cast<int>(w / R)), rest = w - full * R;
+    const double cost = insts * (full * c(R) + (rest > 1e-9 ? c(rest) : 0.0));
     if (best_l == 0 || cost <= best) {
       best = cost;
       best_l = lanes;

@@ -247,16 +247,18 @@ def test_engine_choice_of_lanes_per_agent():
     still fills the SIMDs; ineligible shapes (fp32, other K, long horizons) keep one wavefront per agent; the forced values
     fall back the same way"""
     capi.set_option(capi.OPT_AGENT_LANES, 0)
+    # (round 6: refitted to the instances that run four wavefronts per SIMD -- the choices below are the measured winners of
+    # profiles/r06_ablation.txt item 11; the argument is the batch of ONE call = one of two concurrent agent groups)
     eng, _ = make_pair("simple_cart", 10, 2.0, n_oracles=0)       # BASELINE configs[1]: T = 20
     assert eng.agent_lanes(64) == 64 and eng.agent_lanes(256) == 64
-    assert eng.agent_lanes(2048) == 32 and eng.agent_lanes(4096) == 32
+    assert eng.agent_lanes(2048) == 32 and eng.agent_lanes(4096) == 16
     assert eng.agent_lanes(6144) == 16 and eng.agent_lanes(12288) == 8 and eng.agent_lanes(32768) == 8
     eng.close()
     eng, _ = make_pair("omni", 10, 5.0, n_oracles=0)              # yaml as shipped: T = 50
-    assert eng.agent_lanes(2048) == 64 and eng.agent_lanes(6144) == 16 and eng.agent_lanes(1 << 20) == 16
+    assert eng.agent_lanes(2048) == 64 and eng.agent_lanes(4096) == 16 and eng.agent_lanes(6144) == 16 and eng.agent_lanes(1 << 20) == 16
     eng.close()
     eng, _ = make_pair("omni", 5, 0.5, n_oracles=0)               # BASELINE configs[0]: T = 5
-    assert eng.agent_lanes(2048) == 8 and eng.agent_lanes(1 << 20) == 8
+    assert eng.agent_lanes(2048) == 16 and eng.agent_lanes(4096) == 16 and eng.agent_lanes(16384) == 8 and eng.agent_lanes(1 << 20) == 8
     eng.close()
     eng, _ = make_pair("omni", 10, 20.0, n_oracles=0)             # T = 200: never
     assert eng.agent_lanes(1 << 20) == 64
