@@ -42,7 +42,7 @@ class BatchIO(C.Structure):
                 ("d_bdx", C.c_void_p), ("d_rhot", C.c_void_p), ("d_status", C.c_void_p),
                 ("d_ck_shared", C.c_void_p), ("d_ck_rec", C.c_void_p), ("ck_shared_parts", C.c_uint),
                 ("d_rec_ready", C.c_void_p), ("rec_seq", C.c_uint), ("d_ck_flag", C.c_void_p), ("ck_flag_seq", C.c_uint),
-                ("d_skip", C.c_void_p)]
+                ("d_skip", C.c_void_p), ("rec_per_wavefront", C.c_int)]
 
 
 class ConsensusDesc(C.Structure):
@@ -109,6 +109,8 @@ def lib():
         L.eea_steps.restype = C.c_uint
         L.eea_batch_agent_lanes.restype = C.c_uint
         L.eea_batch_agent_lanes.argtypes = [C.c_void_p, C.c_uint]
+        L.eea_batch_record_count.restype = C.c_uint
+        L.eea_batch_record_count.argtypes = [C.c_void_p, C.c_uint]
         L.eea_num_modes.restype = C.c_uint
         L.eea_real_size.restype = C.c_size_t
         L.eea_time_step.restype = C.c_double
@@ -246,6 +248,11 @@ class Engine:
         """eea_batch_agent_lanes: lanes of a wavefront per agent for a plain batch of B agents (64, 8 / 16 / 32, or 0)"""
         return int(lib().eea_batch_agent_lanes(self.h, B))
 
+    def record_count(self, B):
+        """eea_batch_record_count: records a launch of B agents writes with rec_per_wavefront set (its wavefronts where agents
+        share one, B otherwise)"""
+        return int(lib().eea_batch_record_count(self.h, B))
+
     def close(self):
         if self.h:
             lib().eea_destroy(self.h)
@@ -328,7 +335,8 @@ class Engine:
     def control_batch(self, B, pose, ut, u0, mem_cols=None, n_mem=None, mem_stride=0, traj=None,
                       ck=None, edx=None, bdx=None, rhot=None, status=None, stream=None, ck_shared=None,
                       ck_rec=None, ck_shared_parts=0, n_steps=None, pose_step_stride=0, u0_step_stride=0,
-                      rec_ready=None, rec_seq=0, ck_flag=None, ck_flag_seq=0, skip=None):
+                      rec_ready=None, rec_seq=0, ck_flag=None, ck_flag_seq=0, skip=None,
+                      rec_per_wavefront=False):
         """n_steps (ABI 4, eea_control_batch_steps): that many consecutive control() calls per agent in one launch;
         pose / u0 rows per step by the strides (in agents; 0 = the same row every step)."""
         io = BatchIO()
@@ -340,6 +348,7 @@ class Engine:
         io.d_rhot, io.d_status = _ptr(rhot), _ptr(status)
         io.d_rec_ready, io.rec_seq, io.d_ck_flag, io.ck_flag_seq = _ptr(rec_ready), rec_seq, _ptr(ck_flag), ck_flag_seq
         io.d_skip = _ptr(skip)
+        io.rec_per_wavefront = 1 if rec_per_wavefront else 0
         if n_steps is None:
             check(lib().eea_control_batch(self.h, B, C.byref(io), C.c_void_p(stream or 0)))
         else:

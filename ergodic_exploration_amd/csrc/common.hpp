@@ -52,6 +52,7 @@ struct ControlParams
   int rec_len;         // K^2 + 1 rounded up to even: [sums over agents of c_k, number of agents, pad]
   // per-agent sum records (eea_batch_io::d_ck_rec): [B][rec_len] = [c_k, 1 (0 for a rejected agent), pad]; optional
   R* ck_rec;
+  int rec_wave;        // eea_batch_io::rec_per_wavefront: the packed kernel writes one record per wavefront (sum of its agents')
   // device-bound exchange (eea_batch_io::d_rec_ready / d_ck_flag): rec_ready[b] = rec_seq once agent b's record is
   // visible device-wide (the record sum waits for the marks, not for the kernel); the consumer waits until
   // *ck_flag - ck_flag_seq >= 0 (mod 2^32) right before it reads ck_shared ("late binding": ~45 % into the wavefront's

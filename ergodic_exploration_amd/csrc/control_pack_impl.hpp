@@ -693,21 +693,24 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L, SM)) void
     // zero (it does not count in the sum), an agent left out of the call (d_skip) writes nothing.
     const bool rec_on = p.ck_rec != nullptr && !rollout_only;  // wavefront-uniform
     const bool rec_wt = p.rec_ready != nullptr;                // wavefront-uniform: write-through + ready marks
-    constexpr unsigned long long kGrp = (L == 32) ? 0xffffffffull : ((1ull << L) - 1ull);
+    // c_k leaves the wavefront (d_ck, d_ck_rec) THROUGH LDS: the accumulator lanes hold an agent's c_k scattered (k1 = 4 I + i,
+    // k2 = 4 J + j: 8-byte stores 80 bytes apart -- with tens of thousands of packed agents per pass that write pattern, not the
+    // arithmetic, set the pass time: yaml T = 50, 32 768 agents, records on: 72 against 51 us).  Staged at the agent's place in the
+    // D region (D itself is formed afterwards, from the registers), each agent's own lanes then write its K^2 (+ count, pad)
+    // values as contiguous runs of L reals
+    const bool stage_out = rec_on || p.ck != nullptr;          // wavefront-uniform
 #pragma unroll
     for (int h = 0; h < NSETS; ++h) {
       const int ab = kOneSet ? db : block_agent<L>(h, db);
       const unsigned bb = wave_base + ab;
       // (an agent left out of the call is treated like one beyond the batch: nothing of it is read or written)
       const bool in = bb < B && !(p.skip != nullptr && p.skip[bb < B ? bb : 0] != 0);
-      const bool counts = ((rejected >> (ab * L)) & kGrp) == 0ull;  // not rejected by SimpleCart::operator()
       int nm = 0;
       if (p.mem_cols != nullptr && in) {
         nm = (p.n_mem != nullptr) ? p.n_mem[bb] : static_cast<int>(p.mem_stride);
         nm = nm < 0 ? 0 : (nm > static_cast<int>(p.mem_stride) ? static_cast<int>(p.mem_stride) : nm);
       }
       const R invN = R(1) / static_cast<R>(T + nm);
-      R* const rec = rec_on ? p.ck_rec + static_cast<size_t>(bb < B ? bb : 0) * p.rec_len : nullptr;
 #pragma unroll
       for (int I = 0; I < NB; ++I) {
 #pragma unroll
@@ -718,31 +721,73 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L, SM)) void
           const R c = invN * v;
           cacc[h][I][J] = c;
           const int k1 = 4 * I + di, k2 = 4 * J + dj;
-          if (k1 < K && k2 < K && in && writer) {
-            const int idx = k2 * K + k1;
-            if (p.ck != nullptr && (MODEL != kModelSimpleCart || counts)) p.ck[static_cast<size_t>(bb) * K2 + idx] = c;
-            if (rec_on) {
-              const R cr = counts ? c : R(0);
-              if (rec_wt) store_agent(rec + idx, cr);
-              else rec[idx] = cr;
-            }
-          }
+          if (stage_out && k1 < K && k2 < K && writer) s_D[ab * DS + k2 * K + k1] = c;
         }
       }
     }
-    if (rec_on) {  // wavefront-uniform
-      if (tl == 0 && agent_in) {  // element K^2 = 1 (this agent counts), pad 0
-        R* const rec = p.ck_rec + static_cast<size_t>(b) * p.rec_len;
-        for (unsigned e = static_cast<unsigned>(K2); e < p.rec_len; ++e) {
-          const R v = (e == static_cast<unsigned>(K2) && agent_ok) ? R(1) : R(0);
+    const bool rec_wave = rec_on && p.rec_wave != 0;  // wavefront-uniform
+    if (stage_out) {  // wavefront-uniform
+      lds_fence();
+      const unsigned rec_len = p.rec_len;
+      R* const rec = (rec_on && !rec_wave) ? p.ck_rec + static_cast<size_t>(b < B ? b : 0) * rec_len : nullptr;
+      R* const ckb = p.ck != nullptr ? p.ck + static_cast<size_t>(b < B ? b : 0) * K2 : nullptr;
+      constexpr int kOutRounds = (ck_record_len(K2) + L - 1) / L;
+#pragma unroll
+      for (int r = 0; r < kOutRounds; ++r) {
+        const int e = L * r + tl;
+        const R cv = (e < K2) ? s_D[al * DS + (e < K2 ? e : 0)] : R(0);
+        // (d_ck: nothing of a rejected agent is written, like the wavefront kernel, whose wavefront returns)
+        if (ckb != nullptr && e < K2 && agent_ok) ckb[e] = cv;
+        if (rec != nullptr && agent_in && e < static_cast<int>(rec_len)) {
+          // a rejected agent's record is all zero (it does not count in the sum); element K^2 = 1: this agent counts; pad 0
+          const R v = !agent_ok ? R(0) : (e < K2 ? cv : (e == K2 ? R(1) : R(0)));
           if (rec_wt) store_agent(rec + e, v);
           else rec[e] = v;
         }
       }
-      if (rec_wt) {
+      if (rec_wt && !rec_wave) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the records of every agent of this wavefront have left
         if (tl == 0 && agent_in) store_agent(p.rec_ready + b, p.rec_seq);
       }
+      lds_fence();  // (D takes the staging's place below)
+    }
+    // eea_batch_io::rec_per_wavefront: the wavefront's agents are added here (agent order; the staged c_k are read by all 64
+    // lanes, element e = lane, lane + 64) and ONE record [sum, number of accepted agents, pad] leaves: A = 64 / L times
+    // fewer bytes through eea_ck_records_sum, which at chip-filling packed batches is what the pass was waiting for
+    if (rec_wave) {
+      const unsigned long long okm = __ballot(agent_ok), inm = __ballot(agent_in);
+      const unsigned rec_len = p.rec_len;
+      const unsigned wrec = wave_base / A;
+      R* const rec = p.ck_rec + static_cast<size_t>(wrec) * rec_len;
+      constexpr int kWaveRounds = (ck_record_len(K2) + 63) / 64;
+      if (inm != 0ull) {  // (a wavefront whose agents are all left out of the call writes nothing)
+        // bit a L of okm: agent a is accepted (every lane of an agent holds the same flag)
+        unsigned long long first = 0ull;
+#pragma unroll
+        for (int a = 0; a < A; ++a) first |= 1ull << (a * L);
+        const int n_ok = __popcll(okm & first);  // wavefront-uniform
+#pragma unroll 1
+        for (int r = 0; r < kWaveRounds; ++r) {
+          // (the lane index is counted afresh: nothing is kept in a register across the contraction for this block)
+          const int e = 64 * r + static_cast<int>(__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+          const R* const src = s_D + (e < K2 ? e : 0);
+          R v = R(0);
+#pragma unroll 1
+          for (int a = 0; a < A; ++a) {
+            if (((okm >> (a * L)) & 1ull) != 0ull) v += src[a * DS];  // (wavefront-uniform branch)
+          }
+          v = e < K2 ? v : (e == K2 ? static_cast<R>(n_ok) : R(0));
+          if (e < static_cast<int>(rec_len)) {
+            if (rec_wt) store_agent(rec + e, v);
+            else rec[e] = v;
+          }
+        }
+        if (rec_wt) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0u) store_agent(p.rec_ready + wrec, p.rec_seq);
+        }
+      }
+      lds_fence();
     }
     // device-bound exchange, consumer side: the shared c_k may still be on its way -- wait for its flag here, right before
     // its first use.  On a time-out the agents of this wavefront go on with their own c_k and say so

@@ -623,6 +623,7 @@ eea_status control_batch_impl(eea_engine* e, unsigned B, const eea_batch_io* io,
   p.ck_shared_parts = io->d_ck_shared != nullptr ? static_cast<int>(io->ck_shared_parts) : 0;
   p.rec_len = eea::ck_record_len(e->K2);
   p.rec_ready = rollout_only ? nullptr : io->d_rec_ready;
+  p.rec_wave = io->rec_per_wavefront != 0 ? 1 : 0;
   p.rec_seq = io->rec_seq;
   p.ck_flag = io->d_ck_shared != nullptr ? io->d_ck_flag : nullptr;
   p.ck_flag_seq = io->ck_flag_seq;
@@ -1018,6 +1019,14 @@ unsigned eea_batch_agent_lanes(const eea_engine* e, unsigned B)
   eea::ControlParams<float> p;
   fill_params<float>(e, p);
   return eea::control_wave_eligible<float>(p, false) ? 64u : 0u;
+}
+unsigned eea_batch_record_count(const eea_engine* e, unsigned B)
+{
+  const unsigned lanes = eea_batch_agent_lanes(e, B);
+  if (e == nullptr) return 0u;
+  if (lanes == 0u || lanes >= 64u) return B;
+  const unsigned A = 64u / lanes;
+  return (B + A - 1u) / A;
 }
 unsigned eea_num_modes(const eea_engine* e) { return e ? static_cast<unsigned>(e->K2) : 0u; }
 size_t eea_real_size(const eea_engine* e) { return e ? e->rs : 0; }

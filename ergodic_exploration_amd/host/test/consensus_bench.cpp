@@ -97,15 +97,25 @@ struct Rank
     n = agents;
     groups = n_groups;
     eea_config cfg{};
-    cfg.model = EEA_MODEL_SIMPLE_CART;
+    // CONSENSUS_BENCH_HORIZON / CONSENSUS_BENCH_MODEL (round 6): other shapes than the metric's, e.g. the yaml's T = 50 (horizon 5,
+    // omni) whose batches run on the several-agents-per-wavefront kernel
+    const char* const hz = std::getenv("CONSENSUS_BENCH_HORIZON");
+    const char* const md = std::getenv("CONSENSUS_BENCH_MODEL");
+    const bool omni = md != nullptr && std::strcmp(md, "omni") == 0;
+    cfg.model = omni ? EEA_MODEL_OMNI : EEA_MODEL_SIMPLE_CART;
     cfg.precision = EEA_PREC_F64;
     cfg.dt = 0.1;
-    cfg.horizon = 20.0;
+    cfg.horizon = hz ? std::atof(hz) : 20.0;
     cfg.resolution = 0.1;
     cfg.expl_weight = 1.0;
     cfg.num_basis = 10;
     cfg.Rinv[0] = 1.0;
     cfg.Rinv[8] = 2.0;
+    if (omni) {
+      cfg.Rinv[4] = 1.0;
+      cfg.umin[1] = -1.0;
+      cfg.umax[1] = 1.0;
+    }
     cfg.umin[0] = -1.0;
     cfg.umax[0] = 1.0;
     cfg.umin[2] = -2.0;
@@ -146,12 +156,23 @@ struct Rank
   }
 
   // `count` passes enqueued back to back, then this rank's streams drained; returns seconds per pass
+  unsigned n_records = 0;  // records per pass of the last run()
   double t_gate = 0.0, t_ctrl = 0.0, t_xchg = 0.0;  // host time inside the gate / control / exchange calls of the last run()
   double run(bool consensus, int lag, int count, double* host_share)
   {
     double in_calls = 0.0;
     t_gate = t_ctrl = t_xchg = 0.0;
     const unsigned gb[3] = { 0, groups == 2 ? n / 2 : n, n };
+    // CONSENSUS_BENCH_WAVE_RECORDS (round 6): eea_batch_io::rec_per_wavefront -- where agents share a wavefront each group
+    // writes eea_batch_record_count records (one per wavefront) and the sum / exchange take that many
+    const bool wave_rec = std::getenv("CONSENSUS_BENCH_WAVE_RECORDS") != nullptr && std::atoi(std::getenv("CONSENSUS_BENCH_WAVE_RECORDS")) != 0;
+    unsigned rfirst[3] = { gb[0], gb[1], gb[2] };
+    if (wave_rec) {
+      rfirst[0] = 0;
+      for (int g = 0; g < groups; ++g) rfirst[g + 1] = rfirst[g] + eea_batch_record_count(e, gb[g + 1] - gb[g]);
+    }
+    const unsigned n_rec = rfirst[groups];
+    n_records = n_rec;
     const double t0 = now();
     for (int i = 0; i < count; ++i) {
       ++seq;
@@ -167,7 +188,8 @@ struct Rank
           // the stream-ordered exchange (eea_comm_records_exchange_async + eea_comm_wait): no ready marks, no flag, no wait
           // inside a kernel -- a launch starts when the record it consumes is complete
           io.d_status = d_status + first;
-          io.d_ck_rec = d_arec[slot] + static_cast<size_t>(L) * first;
+          io.d_ck_rec = d_arec[slot] + static_cast<size_t>(L) * rfirst[g];
+          io.rec_per_wavefront = wave_rec ? 1 : 0;
           if (i >= lag) {
             io.d_ck_shared = d_sum[src];
             io.ck_shared_parts = 1;
@@ -175,8 +197,9 @@ struct Rank
           }
         } else if (consensus) {
           io.d_status = d_status + first;
-          io.d_ck_rec = d_arec[slot] + static_cast<size_t>(L) * first;
-          io.d_rec_ready = d_ready + first;
+          io.d_ck_rec = d_arec[slot] + static_cast<size_t>(L) * rfirst[g];
+          io.rec_per_wavefront = wave_rec ? 1 : 0;
+          io.d_rec_ready = d_ready + rfirst[g];
           io.rec_seq = seq;
           if (i >= lag && gated) {
             io.d_ck_shared = d_sum[src];
@@ -200,9 +223,9 @@ struct Rank
       const double x0 = now();
       if (consensus && stream_ordered) {
         void* gs[2] = { streams[0], streams[1] };
-        ok(eea_comm_records_exchange_async(e, c, n, d_arec[slot], d_sum[slot], gs, static_cast<unsigned>(groups), slot), "exchange (stream-ordered)");
+        ok(eea_comm_records_exchange_async(e, c, n_rec, d_arec[slot], d_sum[slot], gs, static_cast<unsigned>(groups), slot), "exchange (stream-ordered)");
       } else if (consensus) {
-        ok(eea_comm_records_exchange_bound(e, c, n, d_arec[slot], d_ready, seq, d_sum[slot], d_flag, slot), "exchange");
+        ok(eea_comm_records_exchange_bound(e, c, n_rec, d_arec[slot], d_ready, seq, d_sum[slot], d_flag, slot), "exchange");
       }
       t_xchg += now() - x0;
       in_calls += now() - h0;
@@ -427,8 +450,8 @@ int main(int argc, char** argv)
     eea_destroy(rk.e);
     return rc;
   }
-  std::printf("C++ host loop, %u agents on the GPU in %d rank(s), K = 10, T = %u, fp64, %d agent group(s) per rank, one launch per pass and group, %d passes:\n",
-              agents, nranks, rk.T, groups, passes);
+  std::printf("C++ host loop, %u agents on the GPU in %d rank(s), K = 10, T = %u, fp64, %u lanes per agent, %d agent group(s) per rank, one launch per pass and group, %d passes:\n",
+              agents, nranks, rk.T, eea_batch_agent_lanes(rk.e, groups == 2 ? rk.n / 2 : rk.n), groups, passes);
   std::printf("  plain passes                         %6.2f us per pass   (host inside the calls: %5.2f us per pass)\n", 1e6 * p, 1e6 * hp);
   double graphed = 0.0;
   if (nranks == 1 && groups == 2 && passes >= 200) {
@@ -439,6 +462,7 @@ int main(int argc, char** argv)
   std::printf("  consensus every pass, lag %d (%s)  %6.2f us per pass   (host inside the calls: %5.2f us per pass)   = %.3f x plain; agents timed out: %d%s\n",
               lag, as_gated ? "gated" : (as_plan ? "stream-ordered, one graph of 48 passes" : (stream_ordered ? "stream-ordered" : "bound")), 1e6 * c, 1e6 * hc, c / p, timed_out,
               with_collective ? (collective_errors == 0 ? "; collective kernels: none gave up" : "; collective kernels gave up or count unavailable") : "");
+  std::printf("  records through the sum per pass: %u (%s)\n", rk.n_records, rk.n_records < agents ? "one per wavefront" : "one per agent");
   std::printf("RESULT {\"agents\": %u, \"ranks\": %d, \"collective_kernel_in_exchange\": %s, \"consuming_groups\": \"%s\", \"groups_per_rank\": %d, \"lag\": %d, \"passes\": %d, \"plain_us_per_pass\": %.3f, \"consensus_us_per_pass\": %.3f, "
               "\"ratio\": %.4f, \"host_us_per_pass_plain\": %.3f, \"host_us_per_pass_consensus\": %.3f, \"agents_timed_out\": %d, "
               "\"collective_kernel_timeouts\": %d, \"graph_us_per_pass\": %.3f}\n",

@@ -241,7 +241,23 @@ typedef struct {
                                         theirs is read or written, their warm start does not advance (a robot that
                                         follows a dynamic-window twist does not call control(), exploration.hpp:230-236;
                                         eea_tick_batch fills it)                                                 */
+  int rec_per_wavefront;  /* ABI 6, with d_ck_rec: non-zero = where several agents share a wavefront (short horizons,
+                                        eea_batch_agent_lanes < 64) the launch writes ONE record per wavefront -- [sum of
+                                        the c_k of its accepted agents, their number, pad], the agents added in agent
+                                        order -- instead of one per agent: d_ck_rec [eea_batch_record_count][record_len],
+                                        d_rec_ready one mark per record.  Records are closed under addition, so
+                                        eea_ck_records_sum / _bound / eea_comm_records_exchange_* take them as they are,
+                                        with the record count in place of B: 4 - 8 x fewer bytes through the sum at the
+                                        batch sizes that fill the chip with packed agents (27 MB per pass at 32 768
+                                        agents otherwise: the sum, not the control kernel, then sets the pass time).
+                                        Launches of one agent per wavefront or workgroup write per-agent records either
+                                        way (count = B).  The sum of the records equals the per-agent sum up to the
+                                        order of the additions (fixed, so still reproducible run to run)            */
 } eea_batch_io;
+
+/* how many records a launch of B agents writes to d_ck_rec (and marks in d_rec_ready) with rec_per_wavefront set: the number
+ * of its wavefronts where agents share one (ceil(B / (64 / eea_batch_agent_lanes))), B otherwise.  0 for a null engine. */
+unsigned eea_batch_record_count(const eea_engine* e, unsigned B);
 
 /* length in reals of one sum record (eea_batch_io::d_ck_rec): K^2 + 1 rounded up to an even number */
 unsigned eea_ck_record_len(const eea_engine* e);

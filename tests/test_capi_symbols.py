@@ -32,7 +32,8 @@ def test_library_exports_only_the_documented_abi():
 def test_struct_layouts_match_header():
     # sizes the C compiler gives the ABI structs (kept in sync with ergodic_amd.h by hand)
     assert C.sizeof(capi.Config) == 3 * 4 + 4 + 4 * 8 + 8 + 15 * 8  # ints, pad, doubles, K+pad, arrays
-    assert C.sizeof(capi.BatchIO) == 15 * 8 + 4 * 8 + 8  # ABI 3 (15 slots) + d_rec_ready, rec_seq, d_ck_flag, ck_flag_seq (ABI 4) + d_skip (ABI 5)
+    assert C.sizeof(capi.BatchIO) == 15 * 8 + 4 * 8 + 8 + 8  # ABI 3 (15 slots) + d_rec_ready, rec_seq, d_ck_flag, ck_flag_seq (ABI 4) + d_skip (ABI 5)
+    # + rec_per_wavefront and its tail padding (ABI 6)
     assert C.sizeof(capi.CollisionCfg) == 3 * 8 + 2 * 4 + 4 * 8
 
 
@@ -142,7 +143,7 @@ def test_packed_timed_instances_fit_four_wavefronts_per_simd():
     T = 50: round 5 had 162-164 registers, three per SIMD) and at 8 lanes per agent with <= 3 steps per lane (configs[1]'s
     T = 20).  What keeps them there: lambda_k / phi_k read where D is formed (not preloaded), one accumulator set for the four
     agents of a 16-lane wavefront, three-element per-step arrays for horizons of <= 3 steps per lane
-    (csrc/control_pack_impl.hpp).  No instance uses scratch."""
+    (csrc/control_pack_impl.hpp).  No instance uses scratch but one, which parks one value (below)."""
     import re
     import subprocess
     import sys
@@ -158,7 +159,11 @@ def test_packed_timed_instances_fit_four_wavefronts_per_simd():
         if not m:
             continue
         KC, stages, L, SM = int(m.group(2)), m.group(3) == "true", int(m.group(4)), int(m.group(6))
-        assert int(k["private_segment_fixed_size"]) == 0, (name, k)
+        # (the 8-lane K = 10 instance at <= 3 steps per lane sits exactly at 128 registers: with the per-wavefront sum records in
+        # the kernel the allocator parks ONE per-step sine in scratch across the contraction -- one store after the rollout, one
+        # load in the tail, per wavefront; measured: no change of configs[1]'s pass time, profiles/r06_ablation.txt item 12)
+        parked = 12 if (KC == 10 and L == 8 and SM == 3 and not stages) else 0
+        assert int(k["private_segment_fixed_size"]) <= parked, (name, k)
         four = not stages and (KC == 5 or L == 16 or (L == 8 and SM == 3))
         if four:
             assert int(k["vgpr_count"]) <= 128, (name, k)
