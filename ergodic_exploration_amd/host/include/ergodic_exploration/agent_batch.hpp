@@ -106,7 +106,8 @@ public:
   }
   // One receding-horizon optimisation of every agent (ErgodicControl::control per agent).  consensus: the
   // gradient uses the mean c_k of ALL agents of all ranks from the previous step (decentralised ergodic control).
-  // The control kernels leave per-agent sum records (eea_batch_io::d_ck_rec); ONE small launch adds them
+  // The control kernels leave sum records (eea_batch_io::d_ck_rec: one per agent, or -- short horizons, where several agents
+  // share a wavefront -- one per wavefront, eea_batch_io::rec_per_wavefront: 4 - 8 x fewer bytes through the sum); ONE small launch adds them
   // (eea_ck_records_sum), ONE collective adds the ranks' records (nothing with one rank) and the next step's
   // kernels divide sum by count themselves (ck_shared_parts = 1).  Everything is stream-ordered: no host
   // synchronisation, and every stream that reads the record waits for the event behind the exchange.
@@ -115,6 +116,7 @@ public:
     double* const rec_now = static_cast<double*>(d_recs_.get()) + static_cast<size_t>(step_ & 1u) * rec_len_;
     const double* const rec_prev = static_cast<const double*>(d_recs_.get()) + static_cast<size_t>((step_ + 1u) & 1u) * rec_len_;
     const bool shared = consensus && have_records_;
+    unsigned int rec_first = 0;  // this group's first record (records per launch: eea_batch_record_count)
     for (unsigned int g = 0; g < groups_; ++g) {
       const unsigned int first = (n_ * g) / groups_, last = (n_ * (g + 1)) / groups_;
       if (last == first) continue;
@@ -129,7 +131,11 @@ public:
         io.d_ck_shared = rec_prev;
         io.ck_shared_parts = 1;
       }
-      if (consensus) io.d_ck_rec = static_cast<double*>(d_agent_recs_.get()) + static_cast<size_t>(rec_len_) * first;
+      if (consensus) {
+        io.d_ck_rec = static_cast<double*>(d_agent_recs_.get()) + static_cast<size_t>(rec_len_) * rec_first;
+        io.rec_per_wavefront = 1;
+        rec_first += eea_batch_record_count(engine_.get(), last - first);
+      }
       throw_on_error(eea_control_batch(engine_.get(), last - first, &io, streams_[g]));
     }
     if (consensus) {
@@ -138,7 +144,7 @@ public:
         hip_check(hipEventRecord(ev_group_[g], streams_[g]));
         hip_check(hipStreamWaitEvent(streams_[0], ev_group_[g], 0));
       }
-      throw_on_error(eea_ck_records_sum(engine_.get(), n_, d_agent_recs_.get(), rec_now, streams_[0]));
+      throw_on_error(eea_ck_records_sum(engine_.get(), rec_first, d_agent_recs_.get(), rec_now, streams_[0]));
       throw_on_error(eea_comm_allreduce_sum(engine_.get(), comm_, rec_now, rec_len_, streams_[0]));
       hip_check(hipEventRecord(ev_exchange_, streams_[0]));
       have_records_ = true;
