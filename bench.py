@@ -840,10 +840,13 @@ def main():
     if not args.no_exchange:
         limit = float(os.environ.get("EEA_BENCH_EXCHANGE_TIMEOUT", "300"))
         finished = threading.Event()
+        gave_up = threading.Event()
+        t_exchange = time.time()
 
         def watchdog():
             if finished.wait(limit):
                 return
+            gave_up.set()
             if rank == 0:
                 out["exchange"] = {"error": "exchange legs did not finish within %g s; headline leg unaffected" % limit}
             emit()
@@ -911,6 +914,12 @@ def main():
                     out["grid_tile"] = gt
         except Exception as exc:  # noqa: BLE001 -- the headline line must not die with a secondary leg
             exchange = {"error": repr(exc)}
+            # an exception at the time limit is the time-out seen from the other side (a peer's watchdog ended its process and
+            # the collective library reports a reset connection): the watchdog of THIS process owns the line and the exit code
+            if gave_up.is_set() or time.time() - t_exchange >= limit:
+                gave_up.wait(10.0)
+                while gave_up.is_set():
+                    time.sleep(1.0)
         finished.set()
         if rank == 0:
             out["exchange"] = exchange

@@ -482,11 +482,19 @@ def cpp_host_loop_leg(agents):
                    "(eea_consensus_plan)", fake, 2, "22"),
                   ("collective kernel in the exchange (test double), stream-ordered per call (round 5's form)", fake, 2, "12")]
     cases += [("local exchange (no collective), gated", "", 2, "32")]
+    # the same consensus on the several-agents-per-wavefront kernel (explore_omni.yaml: T = 50, omni) at a chip-filling batch, one sum
+    # record per WAVEFRONT (eea_batch_io::rec_per_wavefront) against one per agent: at short horizons the record sum sets the pass time
+    yaml_env = {"CONSENSUS_BENCH_HORIZON": "5.0", "CONSENSUS_BENCH_MODEL": "omni"}
+    for wave in ("1", "0"):
+        cases.append(("explore_omni.yaml (T = 50, omni) at 32768 agents, gated, local, sum records per %s" % ("wavefront" if wave == "1" else "agent"),
+                      "", 2, "32", dict(yaml_env, CONSENSUS_BENCH_WAVE_RECORDS=wave), 32768))
     for case in cases:
         name, lib, lag = case[:3]
         mode = case[3] if len(case) > 3 else "2"
+        env = dict(os.environ, **case[4]) if len(case) > 4 else None
+        n_agents = case[5] if len(case) > 5 else agents
         try:
-            r = subprocess.run([exe, "3000", str(agents), "1", lib, str(lag), mode], capture_output=True, text=True, timeout=120)
+            r = subprocess.run([exe, "3000", str(n_agents), "1", lib, str(lag), mode], capture_output=True, text=True, timeout=120, env=env)
             line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
             res = json.loads(line[-1][len("RESULT "):]) if line else {"error": (r.stdout + r.stderr)[-300:]}
         except Exception as exc:  # noqa: BLE001

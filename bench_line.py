@@ -81,8 +81,13 @@ def _exchange(ex):
     cpp = ex.get("cpp_host_loop")
     if isinstance(cpp, dict):
         rows = []
+        packed = []
         for c in cpp.get("cases", []):
             if not isinstance(c, dict):
+                continue
+            if (c.get("lanes_per_agent") or 64) < 64:   # the short-horizon cases have their own plain pass: their own block
+                packed.append([c.get("agents"), c.get("horizon_steps"), c.get("records_per_pass"), _r(c.get("plain_us_per_pass"), 4),
+                               _r(c.get("consensus_us_per_pass"), 4), _r(c.get("ratio"), 4)])
                 continue
             form = str(c.get("form") or c.get("consuming_groups", ""))
             form = "plan" if "eea_consensus_plan" in form else ("stream-ordered" if form.startswith("all stream") else
@@ -97,6 +102,8 @@ def _exchange(ex):
         cols = ("form", "collective_kernel", "lag", "consensus_us", "ratio", "host_us", "timeouts")
         if keep:
             o["cpp_host_loop"] = {"plain_us": keep[0]["plain_us"], "cols": list(cols), "rows": [[r[k] for k in cols] for r in keep]}
+        if packed:
+            o["packed_gated"] = {"cols": ["agents", "T", "records", "plain_us", "consensus_us", "ratio"], "rows": packed[:2]}
     return o
 
 

@@ -465,12 +465,13 @@ int main(int argc, char** argv)
   std::printf("  records through the sum per pass: %u (%s)\n", rk.n_records, rk.n_records < agents ? "one per wavefront" : "one per agent");
   std::printf("RESULT {\"agents\": %u, \"ranks\": %d, \"collective_kernel_in_exchange\": %s, \"consuming_groups\": \"%s\", \"groups_per_rank\": %d, \"lag\": %d, \"passes\": %d, \"plain_us_per_pass\": %.3f, \"consensus_us_per_pass\": %.3f, "
               "\"ratio\": %.4f, \"host_us_per_pass_plain\": %.3f, \"host_us_per_pass_consensus\": %.3f, \"agents_timed_out\": %d, "
-              "\"collective_kernel_timeouts\": %d, \"graph_us_per_pass\": %.3f}\n",
+              "\"collective_kernel_timeouts\": %d, \"graph_us_per_pass\": %.3f, \"horizon_steps\": %u, \"lanes_per_agent\": %u, \"records_per_pass\": %u}\n",
               agents, nranks, with_collective ? "true" : "false", as_gated ? "all gated (eea_stream_wait_flag in front of every consuming launch)"
               : as_plan ? "all stream-ordered, replayed as one device graph (eea_consensus_plan)"
               : rk.stream_ordered ? "all stream-ordered (eea_comm_records_exchange_async + eea_comm_wait)"
                                                          : (rk.last_group_stream_ordered ? "one device-bound, one stream-ordered" : "all device-bound"),
-              groups, lag, passes, 1e6 * p, 1e6 * c, c / p, 1e6 * hp, 1e6 * hc, timed_out, collective_errors, 1e6 * graphed);
+              groups, lag, passes, 1e6 * p, 1e6 * c, c / p, 1e6 * hp, 1e6 * hc, timed_out, collective_errors, 1e6 * graphed, rk.T,
+              eea_batch_agent_lanes(rk.e, groups == 2 ? rk.n / 2 : rk.n), rk.n_records);
   if (rk.plan) eea_consensus_plan_destroy(rk.plan);
   eea_comm_destroy(rk.c);
   eea_destroy(rk.e);

@@ -25,7 +25,8 @@ def main():
     for src, dst in (("bench_detail.json", "r06_bench_detail.json"), ("exchange_modes.txt", "r06_exchange_modes.txt"),
                      ("pack_summary.txt", "r06_pack_summary.txt"), ("pack_profile.json", "r06_pack_profile.json"),
                      ("pack_pmc.txt", "r06_pack_pmc.txt"), ("pack_points.txt", "r06_pack_points.txt"),
-                     ("pack_c2_kernel_stats.csv", "r06_pack_c2_kernel_stats.csv"), ("pack_c3_kernel_stats.csv", "r06_pack_c3_kernel_stats.csv")):
+                     ("pack_c2_kernel_stats.csv", "r06_pack_c2_kernel_stats.csv"), ("pack_c3_kernel_stats.csv", "r06_pack_c3_kernel_stats.csv"),
+                     ("packed_consensus.txt", "r06_packed_consensus.txt")):
         cp(src, dst)
     for g in ("spl50", "spl1", "k20_f32"):
         cp("%s_summary.txt" % g, "r06_%s_summary.txt" % g)

@@ -26,6 +26,7 @@ bash tools/r06_pack_pmc.sh r06ev > /dev/null 2>&1
 cp gpurun_out/pack_pmc_r06ev/summary.txt "$OUT/pack_pmc.txt"
 bash tools/r06_pack_points.sh > "$OUT/pack_points.txt" 2>&1
 bash tools/r06_exchange_modes.sh > "$OUT/exchange_modes.txt" 2>&1
+bash tools/r06_packed_consensus.sh > "$OUT/packed_consensus.txt" 2>&1
 PHIK_CASES=16384:10:f64 bash tools/phik_pmc.sh > "$OUT/phik_pmc.txt" 2>&1
 python3 tools/parity_report.py > "$OUT/parity_report.txt" 2>&1
 EEA_PRINT_WORST=1 python3 -m pytest tests/test_analytic_checks.py -m gpu -q -s 2>&1 | grep -E "digits|closed-form|passed|failed" > "$OUT/analytic_checks.txt"
