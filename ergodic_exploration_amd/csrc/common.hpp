@@ -430,19 +430,58 @@ __device__ __forceinline__ R load_agent(const R* q)
   return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-template <typename R, typename P>  // P: ControlParams<R>, possibly in the kernel-argument address space
-__device__ __forceinline__ R shared_ck_value(const P& p, const R* shared, int m, int K2, R own)
+// The divisor is the same for every mode: the reciprocal of the summed agent counts is formed ONCE per wavefront (wavefront-
+// uniform, kept in scalar registers) and the modes are multiplied by it -- the quotient per mode was nine fp64 divisions per lane
+// of the wavefront kernels, 4 - 7 % of a consensus pass (profiles/r06_ablation.txt item 13).
+template <typename R>
+struct SharedCk
 {
+  R inv;      // 1 / (sum of the records' agent counts); unused with ck_shared_parts = 0
+  bool have;  // some agent contributed
+};
+__device__ __forceinline__ double uniform_value(double v)
+{
+  union { double d; unsigned u[2]; } x;
+  x.d = v;
+  x.u[0] = __builtin_amdgcn_readfirstlane(x.u[0]);
+  x.u[1] = __builtin_amdgcn_readfirstlane(x.u[1]);
+  return x.d;
+}
+__device__ __forceinline__ float uniform_value(float v)
+{
+  union { float f; unsigned u; } x;
+  x.f = v;
+  x.u = __builtin_amdgcn_readfirstlane(x.u);
+  return x.f;
+}
+template <typename R, typename P>  // P: ControlParams<R>, possibly in the kernel-argument address space
+__device__ __forceinline__ SharedCk<R> shared_ck_begin(const P& p, const R* shared, int K2)
+{
+  SharedCk<R> sc{ R(1), true };
+  if (p.ck_shared_parts <= 0) return sc;
   // a buffer another kernel fills WHILE this one runs (device-bound exchange) is read past the L1
   const bool bound = p.ck_flag != nullptr;
+  R n = R(0);
+  for (int i = 0; i < p.ck_shared_parts; ++i) {
+    const R* const rec = shared + static_cast<size_t>(i) * p.rec_len;
+    n += bound ? load_agent(rec + K2) : rec[K2];
+  }
+  n = uniform_value(n);
+  sc.have = n > R(0);
+  sc.inv = sc.have ? uniform_value(R(1) / n) : R(0);
+  return sc;
+}
+template <typename R, typename P>
+__device__ __forceinline__ R shared_ck_value(const P& p, const SharedCk<R>& sc, const R* shared, int m, R own)
+{
+  const bool bound = p.ck_flag != nullptr;
   if (p.ck_shared_parts <= 0) return bound ? load_agent(shared + m) : shared[m];
-  R s = R(0), n = R(0);
+  R s = R(0);
   for (int i = 0; i < p.ck_shared_parts; ++i) {
     const R* const rec = shared + static_cast<size_t>(i) * p.rec_len;
     s += bound ? load_agent(rec + m) : rec[m];
-    n += bound ? load_agent(rec + K2) : rec[K2];
   }
-  return n > R(0) ? s / n : own;
+  return sc.have ? s * sc.inv : own;
 }
 
 // Device-bound exchange, consumer side: wait (bounded) until *flag has reached seq.  One lane polls past the L1 with a

@@ -687,10 +687,12 @@ __device__ __forceinline__ void control_agent(const ControlParams<R>& p, const i
       use_shared = s_sw[46] != R(0);
       __syncthreads();
     }
+    SharedCk<R> shared_ck{ R(1), true };
+    if (use_shared) shared_ck = shared_ck_begin<R>(p, p.ck_shared, K2);  // workgroup-uniform
     for (int m = tid; m < K2; m += BLK) {
       R c = s_D[m];
       // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
-      if (use_shared) c = shared_ck_value(p, p.ck_shared, m, K2, c);
+      if (use_shared) c = shared_ck_value(p, shared_ck, p.ck_shared, m, c);
       // fourier_diff = lamdak % (ck - phik)  (ergodic_control.hpp:422)
       const R lam = (m == tid) ? lam_m : p.lamdak[m];
       const R phi = (m == tid) ? phi_m : p.phik[m];

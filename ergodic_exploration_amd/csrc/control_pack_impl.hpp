@@ -798,6 +798,8 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L, SM)) void
       if (!ok && tl == 0 && agent_ok && p.status != nullptr) p.status[b] = 6;  // EEA_ERR_TIMEOUT
       use_shared = ok;
     }
+    SharedCk<R> shared_ck{ R(1), true };
+    if (use_shared) shared_ck = shared_ck_begin<R>(p, p.ck_shared, K2);  // wavefront-uniform
 #pragma unroll
     for (int h = 0; h < NSETS; ++h) {
       const int ab = kOneSet ? db : block_agent<L>(h, db);
@@ -810,7 +812,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, STAGES, L, SM)) void
             const int idx = k2 * K + k1;
             R c = cacc[h][I][J];
             // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
-            if (use_shared) c = shared_ck_value(p, p.ck_shared, idx, K2, c);
+            if (use_shared) c = shared_ck_value(p, shared_ck, p.ck_shared, idx, c);
             if constexpr (kPreload) s_D[ab * DS + idx] = lamv[I][J] * (c - phiv[I][J]);
             else s_D[ab * DS + idx] = p.lamdak[idx] * (c - p.phik[idx]);
           }

@@ -1184,10 +1184,12 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
       publish_record();
     }
     const bool use_shared = bind_shared_ck();
+    SharedCk<R> shared_ck{ R(1), true };
+    if (use_shared) shared_ck = shared_ck_begin<R>(p, ck_shared_step, K2);  // wavefront-uniform
 #pragma unroll
     for (int t = 0; t < TS; ++t) {
       // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
-      if (use_shared) cv[t] = shared_ck_value(p, ck_shared_step, idx[t], K2, cv[t]);
+      if (use_shared) cv[t] = shared_ck_value(p, shared_ck, ck_shared_step, idx[t], cv[t]);
       if (okv[t]) s_D[idx[t]] = lamv[t] * (cv[t] - phiv[t]);
     }
     lds_fence();
@@ -1219,11 +1221,13 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
       publish_record();
     }
     const bool use_shared = bind_shared_ck();
+    SharedCk<R> shared_ck{ R(1), true };
+    if (use_shared) shared_ck = shared_ck_begin<R>(p, ck_shared_step, K2);  // wavefront-uniform
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       if (use_shared) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) cv[t][r] = shared_ck_value(p, ck_shared_step, idx[t] + r, K2, static_cast<R>(cv[t][r]));
+        for (int r = 0; r < 4; ++r) cv[t][r] = shared_ck_value(p, shared_ck, ck_shared_step, idx[t] + r, static_cast<R>(cv[t][r]));
       }
       if (okv[t]) *reinterpret_cast<f32x4*>(s_D + idx[t]) = lamv[t] * (cv[t] - phiv[t]);
     }
@@ -1247,6 +1251,8 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
     }
     if (ck_rec_step != nullptr) publish_record();  // wavefront-uniform
     const bool use_shared = bind_shared_ck();
+    SharedCk<R> shared_ck{ R(1), true };
+    if (use_shared) shared_ck = shared_ck_begin<R>(p, ck_shared_step, K2);  // wavefront-uniform
 #pragma unroll
     for (int t = 0; t < NT * NT; ++t) {
 #pragma unroll
@@ -1256,7 +1262,7 @@ __global__ __launch_bounds__(WPB* kWave, waves_per_simd(KC, sizeof(R))) void con
         if (k1 < K && k2 < K) {
           R c = invN * (*accs[t])[r];
           // decentralised consensus (eea_batch_io::d_ck_shared): the agents' shared c_k replaces the own one
-          if (use_shared) c = shared_ck_value(p, ck_shared_step, k2 * K + k1, K2, c);
+          if (use_shared) c = shared_ck_value(p, shared_ck, ck_shared_step, k2 * K + k1, c);
           s_D[k2 * K + k1] = lam[t][r] * (c - phi[t][r]);
         }
       }

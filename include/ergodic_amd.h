@@ -220,8 +220,10 @@ typedef struct {
                                         n >= 1 = d_ck_shared holds n consecutive sum records
                                         (eea_ck_records_sum of earlier calls -- e.g. one per agent
                                         group -- all-reduced over the ranks or not): the kernel uses
-                                        c_bar[m] = sum_i rec_i[m] / sum_i rec_i[K^2]: no divide
-                                        launch, and the exchange is one all-reduce of n records */
+                                        c_bar[m] = (sum_i rec_i[m]) x (1 / sum_i rec_i[K^2]) -- the
+                                        reciprocal formed once per wavefront (ABI 6; a quotient per
+                                        mode before: <= 1 ulp apart) --: no divide launch, and the
+                                        exchange is one all-reduce of n records */
   /* ABI 4 -- device-bound exchange: producers and consumers of the shared c_k meet on the DEVICE, no host wait and no
    * stream wait anywhere (eea_comm_records_exchange_bound).  All optional (NULL / 0 = the forms above). */
   unsigned* d_rec_ready;  /* [B] out (with d_ck_rec): rec_ready[b] = rec_seq once agent b's record is visible

@@ -246,8 +246,9 @@ def test_sum_record_skips_rejected_agents_and_fp32():
 
 @pytest.mark.parametrize("K,horizon", [(10, 20.0), (30, 6.0)])
 def test_shared_ck_as_sum_records(K, horizon):
-    """ck_shared_parts = n (ABI 3): d_ck_shared holds n sum records and the kernel uses sum of sums / sum of counts --
-    bitwise the same controls as the ABI-2 form fed with that quotient, for both control kernels."""
+    """ck_shared_parts = n (ABI 3): d_ck_shared holds n sum records and the kernel uses sum of sums x (1 / sum of counts) -- the
+    reciprocal is formed once per wavefront, round 6 -- bitwise the same controls as the ABI-2 form fed with that product, for both
+    control kernels."""
     rng = np.random.default_rng(8)
     B = 150
     eng, _ = make_pair("omni", K, horizon, n_oracles=0)
@@ -267,7 +268,7 @@ def test_shared_ck_as_sum_records(K, horizon):
     torch.cuda.synchronize()
     r = recs.cpu().numpy()
     assert r[0, K2] == half and r[1, K2] == B - half
-    cbar = (r[0, :K2] + r[1, :K2]) / (r[0, K2] + r[1, K2])
+    cbar = (r[0, :K2] + r[1, :K2]) * (1.0 / (r[0, K2] + r[1, K2]))
     # pass 2 consumes the two records ...
     ut_a = d_ut.clone()
     eng.control_batch(B, d_pose, ut_a, d_u0, ck_shared=recs, ck_shared_parts=2)
