@@ -21,3 +21,5 @@ for wave in 0 1; do
   run "device-bound lag 1, wave records $wave" 2.0 cart 32768 2 1 $wave ""
   run "gated lag 2 + collective kernel, wave records $wave" 2.0 cart 32768 32 2 $wave $F
 done
+echo "== soak: explore_omni.yaml, 32768 agents, gated lag 2 + collective kernel, one record per wavefront, 60 000 passes"
+CONSENSUS_BENCH_HORIZON=5.0 CONSENSUS_BENCH_MODEL=omni CONSENSUS_BENCH_WAVE_RECORDS=1 timeout 600 $B 60000 32768 1 "$F" 2 32 2>&1 | grep "consensus every" | cut -c1-230
