@@ -75,6 +75,43 @@ def test_steps_in_one_launch_equal_separate_calls(model, K, horizon, n_mem, prec
     eng.close()
 
 
+@pytest.mark.parametrize("L,model,horizon", [(8, "simple_cart", 2.0), (16, "omni", 5.0), (32, "omni", 5.0)])
+def test_packed_steps_in_one_launch_leave_the_last_steps_records(L, model, horizon):
+    """several agents per wavefront, n_steps > 1: c_k and the sum records (one per agent, one per wavefront) of the launch are those
+    of its LAST step -- bitwise what the last of the separate calls leaves"""
+    capi.set_option(capi.OPT_AGENT_LANES, L)
+    try:
+        A = 64 // L
+        B, n_steps = 9 * A + 1, 4
+        eng, _ = make_pair(model, 10, horizon, n_oracles=0)
+        assert eng.agent_lanes(B) == L
+        seq, ut0, _ = _inputs(model, eng, B, n_steps, 0, seed=11)
+        d_seq = dev(seq)
+        RL, K2, W = eng.ck_record_len, eng.K2, eng.record_count(B)
+        out = {}
+        for form in ("calls", "launch"):
+            ut, u0 = dev(ut0), torch.empty((n_steps, B, 3), dtype=torch.float64, device="cuda")
+            ck = torch.zeros((B, K2), dtype=torch.float64, device="cuda")
+            arec = torch.zeros((B, RL), dtype=torch.float64, device="cuda")
+            wrec = torch.zeros((W, RL), dtype=torch.float64, device="cuda")
+            for wave, rec in ((False, arec), (True, wrec)):
+                utw = ut.clone()
+                if form == "calls":
+                    for n in range(n_steps):
+                        eng.control_batch(B, d_seq[n], utw, u0[n], ck=ck, ck_rec=rec, rec_per_wavefront=wave)
+                else:
+                    eng.control_batch(B, d_seq, utw, u0, n_steps=n_steps, pose_step_stride=B, u0_step_stride=B, ck=ck, ck_rec=rec,
+                                      rec_per_wavefront=wave)
+            torch.cuda.synchronize()
+            out[form] = (utw, u0, ck, arec, wrec)
+        for a, b in zip(out["calls"], out["launch"]):
+            assert torch.equal(a, b)
+        assert float(out["launch"][4][:, K2].sum()) == B and float(out["launch"][3][:, K2].sum()) == B
+        eng.close()
+    finally:
+        capi.set_option(capi.OPT_AGENT_LANES, 0)
+
+
 def test_steps_argument_errors():
     eng, _ = make_pair("omni", 10, 2.0, n_oracles=0)
     B, T = 4, eng.T
