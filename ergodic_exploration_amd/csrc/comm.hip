@@ -513,7 +513,8 @@ struct eea_consensus_plan
   int device = 0;
   unsigned n_groups = 0, lag = 0, slots = 0, passes = 0, B = 0, rec_len = 0;
   size_t rs = 8;
-  std::vector<unsigned> agents, first;
+  std::vector<unsigned> agents, first, rec_first;  // per group: agents, first agent, first record of a pass
+  unsigned n_rec = 0;                               // records per pass (<= B)
   std::vector<eea_batch_io> io;
   std::vector<hipStream_t> gstreams;
   hipStream_t xs = nullptr;
@@ -581,7 +582,9 @@ eea_status plan_enqueue(eea_consensus_plan* p)
       // ordered by the device's serialisation of the launches, no captured dependency)
       if (i >= p->lag) EEA_HIP(hipStreamWaitEvent(p->gstreams[g], p->ev_x[src], 0));
       eea_batch_io io = p->io[g];
-      io.d_ck_rec = arec + (static_cast<size_t>(slot) * p->B + p->first[g]) * rec_bytes;
+      // (one record per wavefront where agents share one, eea_batch_io::rec_per_wavefront: rec_first / n_rec count records)
+      io.d_ck_rec = arec + (static_cast<size_t>(slot) * p->B + p->rec_first[g]) * rec_bytes;
+      io.rec_per_wavefront = 1;
       io.d_ck_shared = sum + static_cast<size_t>(src) * rec_bytes;
       io.ck_shared_parts = 1;
       const eea_status st = eea_control_batch(p->e, p->agents[g], &io, p->gstreams[g]);
@@ -590,7 +593,7 @@ eea_status plan_enqueue(eea_consensus_plan* p)
       EEA_HIP(hipStreamWaitEvent(p->xs, p->ev_group[g], 0));
     }
     void* const s_slot = sum + static_cast<size_t>(slot) * rec_bytes;
-    eea_status st = eea_ck_records_sum_ws(p->e, p->B, arec + static_cast<size_t>(slot) * p->B * rec_bytes, s_slot,
+    eea_status st = eea_ck_records_sum_ws(p->e, p->n_rec, arec + static_cast<size_t>(slot) * p->B * rec_bytes, s_slot,
                                           static_cast<char*>(p->d_ws) + static_cast<size_t>(slot) * p->ws_bytes,
                                           static_cast<char*>(p->d_tickets) + static_cast<size_t>(slot) * p->ticket_bytes, p->xs);
     if (st != EEA_OK) return st;
@@ -637,6 +640,8 @@ eea_status eea_consensus_plan_create(eea_engine* e, eea_comm* c, const eea_conse
     p->first.push_back(p->B);
     p->agents.push_back(d->group_agents[g]);
     p->B += d->group_agents[g];
+    p->rec_first.push_back(p->n_rec);
+    p->n_rec += eea_batch_record_count(e, d->group_agents[g]);  // (= the group's agents for one agent per wavefront)
     eea_batch_io mine = io;  // the exchange fields are the plan's
     mine.d_ck_shared = nullptr;
     mine.d_ck_rec = nullptr;

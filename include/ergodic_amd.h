@@ -422,7 +422,8 @@ eea_status eea_stream_wait_flag(const unsigned* d_flag, unsigned seq, unsigned* 
  * on the exchange branch the record sum and the all-reduce over the ranks (nothing without an RCCL communicator) -- into one
  * hipGraph; eea_consensus_plan_launch replays it with ONE runtime call.  Nothing waits inside a kernel (the rule of
  * eea_comm_records_exchange_bound for exchanges with a collective kernel holds by construction); lag >= 2 keeps the collective
- * off the critical path of a pass.  The plan owns the record / sum buffers (lag + 2 slots, rotating), the record sum's
+ * off the critical path of a pass.  The plan owns the record / sum buffers (lag + 2 slots, rotating; one record per wavefront
+ * where agents share one: eea_batch_io::rec_per_wavefront), the record sum's
  * workspaces, the group streams and events; the caller owns what eea_batch_io names (d_pose, d_ut, d_u0, optional d_mem_cols /
  * d_n_mem / mem_stride, d_status, d_skip per group: the exchange fields of group_io are ignored) and may rewrite the CONTENTS of
  * those buffers between launches (new poses), not the pointers.  Across launches the protocol continues: pass 0 of a launch

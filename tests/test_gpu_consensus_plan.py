@@ -19,20 +19,24 @@ pytestmark = pytest.mark.gpu
 
 
 def _reference(eng, B, gb, d_pose, ut0, lag, passes, RL, status=None):
-    """the passes one call at a time: pass i consumes the sum record of pass i - lag (an empty record before there is one)"""
+    """the passes one call at a time: pass i consumes the sum record of pass i - lag (an empty record before there is one).
+    Records as the plan asks for them: one per wavefront where agents share one (eea_batch_io::rec_per_wavefront), else per agent"""
     ut, u0 = dev(ut0), torch.empty((B, 3), dtype=torch.float64, device="cuda")
-    arec = torch.zeros((B, RL), dtype=torch.float64, device="cuda")
+    counts = [eng.record_count(gb[g + 1] - gb[g]) for g in range(len(gb) - 1)]
+    roff = np.concatenate([[0], np.cumsum(counts)]).astype(int)
+    n_rec = int(roff[-1])
+    arec = torch.zeros((n_rec, RL), dtype=torch.float64, device="cuda")
     sums = [torch.zeros((RL,), dtype=torch.float64, device="cuda") for _ in range(passes)]
     empty = torch.zeros((RL,), dtype=torch.float64, device="cuda")
     for i in range(passes):
         src = i - lag
         for g in range(len(gb) - 1):
             sl = slice(gb[g], gb[g + 1])
-            eng.control_batch(gb[g + 1] - gb[g], d_pose[sl], ut[sl], u0[sl], ck_rec=arec[sl],
+            eng.control_batch(gb[g + 1] - gb[g], d_pose[sl], ut[sl], u0[sl], ck_rec=arec[roff[g]:roff[g + 1]], rec_per_wavefront=True,
                               status=None if status is None else status[sl],
                               ck_shared=sums[src] if src >= 0 else empty, ck_shared_parts=1)
         torch.cuda.synchronize()
-        eng.ck_records_sum(B, arec, sums[i])
+        eng.ck_records_sum(n_rec, arec, sums[i])
         torch.cuda.synchronize()
     return ut, u0, sums
 
@@ -213,9 +217,13 @@ def test_gated_exchange_is_bitwise_the_call_by_call_sequence(model, K, horizon, 
         comm = capi.Comm(0, 1, 0, capi.comm_unique_id() if rccl else None)
         streams = [torch.cuda.Stream() for _ in range(2)]
         ut_b, u0_b = dev(ut0), torch.empty((B, 3), dtype=torch.float64, device="cuda")
-        arecs = [torch.zeros((B, RL), dtype=torch.float64, device="cuda") for _ in range(NB)]
+        # (records as in _reference: one per wavefront where agents share one)
+        counts = [eng.record_count(gb[g + 1] - gb[g]) for g in range(2)]
+        roff = [0, counts[0], counts[0] + counts[1]]
+        n_rec = roff[2]
+        arecs = [torch.zeros((n_rec, RL), dtype=torch.float64, device="cuda") for _ in range(NB)]
         sums_b = [torch.zeros((RL,), dtype=torch.float64, device="cuda") for _ in range(NB)]
-        ready = torch.zeros((B,), dtype=torch.int32, device="cuda")
+        ready = torch.zeros((n_rec,), dtype=torch.int32, device="cuda")
         flag = torch.zeros((1,), dtype=torch.int32, device="cuda")
         timeouts = torch.zeros((1,), dtype=torch.int32, device="cuda")
         status = torch.full((B,), -1, dtype=torch.int32, device="cuda")
@@ -228,10 +236,11 @@ def test_gated_exchange_is_bitwise_the_call_by_call_sequence(model, K, horizon, 
                 sl = slice(gb[g], gb[g + 1])
                 if src is not None:
                     capi.stream_wait_flag(flag, seq - lag, timeouts, streams[g].cuda_stream)
-                eng.control_batch(gb[g + 1] - gb[g], d_pose[sl], ut_b[sl], u0_b[sl], ck_rec=arecs[slot][sl], rec_ready=ready[sl],
-                                  rec_seq=seq, status=status[sl], ck_shared=empty if src is None else sums_b[src],
-                                  ck_shared_parts=1, stream=streams[g].cuda_stream)
-            comm.records_exchange_bound(eng, B, arecs[slot], ready, seq, sums_b[slot], flag, slot)
+                rs = slice(roff[g], roff[g + 1])
+                eng.control_batch(gb[g + 1] - gb[g], d_pose[sl], ut_b[sl], u0_b[sl], ck_rec=arecs[slot][rs], rec_ready=ready[rs],
+                                  rec_per_wavefront=True, rec_seq=seq, status=status[sl],
+                                  ck_shared=empty if src is None else sums_b[src], ck_shared_parts=1, stream=streams[g].cuda_stream)
+            comm.records_exchange_bound(eng, n_rec, arecs[slot], ready, seq, sums_b[slot], flag, slot)
         torch.cuda.synchronize()
         assert int(timeouts.item()) == 0 and (status.cpu().numpy() == 0).all()
         assert int(flag.item()) == passes
