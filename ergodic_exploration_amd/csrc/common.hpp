@@ -236,10 +236,12 @@ template <typename R>
 hipError_t launch_spatial_coeff(const R* d_phi, int nx, int ny, int K, const R* d_cx, const R* d_cy,
                                 R* d_work, R* d_phik, hipStream_t s);
 // occupancy cells (int8) decoded through d_lut[256] inside the streaming kernel; d_raw receives the
-// un-normalised sums, launch_normalise_by_first divides by element 0
+// un-normalised sums, launch_normalise_by_first divides by element 0 -- or, with d_mass_out, the reduction launch divides
+// by mode (0, 0)'s sum itself (the same bits, one launch less): d_raw = the normalised coefficients, *d_mass_out = the normaliser
 template <typename R>
 hipError_t launch_spatial_coeff_cells(const int8_t* d_occ, int nx, int ny, int K, const R* d_cx,
-                                      const R* d_cy, const R* d_lut, R* d_work, R* d_raw, hipStream_t s);
+                                      const R* d_cy, const R* d_lut, R* d_work, R* d_raw, hipStream_t s,
+                                      R* d_mass_out = nullptr);
 template <typename R>
 hipError_t launch_normalise_by_first(const R* d_raw, int K2, R* d_out, hipStream_t s);
 

@@ -700,7 +700,7 @@ eea_status upload_entropy_table(eea_engine* e, hipStream_t s)
 // un-normalised coefficient sums of rows [row0, row0 + nrows) of an occupancy grid
 template <typename R>
 eea_status occupancy_rows_impl(eea_engine* e, unsigned nx, unsigned ny_total, unsigned row0, unsigned nrows,
-                               const int8_t* d_occ_rows, void* d_raw_out, hipStream_t s)
+                               const int8_t* d_occ_rows, void* d_raw_out, hipStream_t s, void* d_mass_out = nullptr)
 {
   eea_status st = upload_axes_and_tables<R>(e, nx, ny_total, s);
   if (st != EEA_OK) return st;
@@ -711,7 +711,7 @@ eea_status occupancy_rows_impl(eea_engine* e, unsigned nx, unsigned ny_total, un
   EEA_HIP(eea::launch_spatial_coeff_cells<R>(d_occ_rows, nx, nrows, e->K, static_cast<const R*>(e->d_cx.p),
                                              static_cast<const R*>(e->d_cy.p) + static_cast<size_t>(row0) * e->K,
                                              static_cast<const R*>(e->d_lut.p), static_cast<R*>(e->d_work.p),
-                                             static_cast<R*>(d_raw_out), s));
+                                             static_cast<R*>(d_raw_out), s, static_cast<R*>(d_mass_out)));
   return EEA_OK;
 }
 
@@ -1121,16 +1121,12 @@ eea_status eea_set_target_occupancy(eea_engine* e, unsigned nx, unsigned ny, con
   e->ny = ny;
   e->have_fill_grid = false;
   EEA_HIP(e->d_raw.reserve(e->rs * e->K2));
-  st = e->f32 ? occupancy_rows_impl<float>(e, nx, ny, 0, ny, d_occ, e->d_raw.p, s)
-              : occupancy_rows_impl<double>(e, nx, ny, 0, ny, d_occ, e->d_raw.p, s);
+  // the whole grid on this engine: the reduction launch normalises by mode (0, 0)'s sum itself (phi_k / sum(phi), target.cpp:87) --
+  // two launches, the same bits as sums -> launch_normalise_by_first (which the row-tiled multi-rank form still uses, behind its
+  // all-reduce); the normaliser goes to d_raw[0]
+  st = e->f32 ? occupancy_rows_impl<float>(e, nx, ny, 0, ny, d_occ, e->d_phik.p, s, e->d_raw.p)
+              : occupancy_rows_impl<double>(e, nx, ny, 0, ny, d_occ, e->d_phik.p, s, e->d_raw.p);
   if (st != EEA_OK) return st;
-  if (e->f32) {
-    EEA_HIP(eea::launch_normalise_by_first<float>(static_cast<const float*>(e->d_raw.p), e->K2,
-                                                  static_cast<float*>(e->d_phik.p), s));
-  } else {
-    EEA_HIP(eea::launch_normalise_by_first<double>(static_cast<const double*>(e->d_raw.p), e->K2,
-                                                   static_cast<double*>(e->d_phik.p), s));
-  }
   EEA_HIP(hipStreamSynchronize(s));
   e->have_phik = true;
   ++e->phik_gen;  // (the resident single-robot workgroup restarts on the next call)

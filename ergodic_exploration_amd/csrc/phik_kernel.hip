@@ -598,14 +598,16 @@ template <typename R>
 __global__ __launch_bounds__(kBlock) void sum_partials_norm_kernel(const R* __restrict__ partials, int n_parts,
                                                                    int K2, const R* __restrict__ mass_partials,
                                                                    int n_mass, R* __restrict__ out,
-                                                                   R* __restrict__ mass_out)
+                                                                   R* __restrict__ mass_out, int mass_stride)
 {
   const int lane = threadIdx.x & (kWave - 1);
   const int m = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
   if (m >= K2) return;  // whole wavefront
   R s = R(0), w = R(0);
   for (int b = lane; b < n_parts; b += kWave) s += partials[static_cast<size_t>(b) * K2 + m];
-  for (int b = lane; b < n_mass; b += kWave) w += mass_partials[b];
+  // (mass_stride = K^2, mass_partials = partials: the mass is mode (0, 0) of the same sums -- cos 0 = 1 --, added in the same order as
+  // that mode's own sum: what normalise_by_first divides by, without its launch)
+  for (int b = lane; b < n_mass; b += kWave) w += mass_partials[static_cast<size_t>(b) * mass_stride];
 #pragma unroll
   for (int o = kWave / 2; o > 0; o >>= 1) {
     s += __shfl_down(s, o, kWave);
@@ -857,8 +859,9 @@ template <typename R, typename IN>
 hipError_t launch_spatial_generic(const IN* d_in, int nx, int ny, int K, const R* d_cx, const R* d_cy,
                                   const R* d_lut, R* d_work, R* d_phik, hipStream_t s,
                                   const R* d_mass_partials = nullptr, int n_mass = 0, R* d_mass = nullptr,
-                                  hipEvent_t stop = nullptr)
+                                  hipEvent_t stop = nullptr, bool norm_by_first = false)
 {
+  int mass_stride = 1;
   // `stop` (optional) is bound to the completion of the LAST launch (hipExtLaunchKernelGGL: the kernel's own
   // completion signal, no separate event-record packet on the stream)
 #define EEA_LAUNCH_MAYBE_LAST(last, kernel, grid, block, lds, ...)                                      \
@@ -881,7 +884,12 @@ hipError_t launch_spatial_generic(const IN* d_in, int nx, int ny, int K, const R
     const size_t lds = elems * sizeof(R);
     const dim3 grid(col_tiles, row_tiles);
     // one tile and the normalised form asked for: the streaming kernel finishes the job itself
-    const bool direct = d_mass_partials != nullptr && col_tiles * row_tiles == 1;
+    const bool direct = d_mass_partials != nullptr && !norm_by_first && col_tiles * row_tiles == 1;
+    if (norm_by_first) {  // the normaliser is mode (0, 0) of the tiles' own partial sums
+      d_mass_partials = d_work;
+      n_mass = col_tiles * row_tiles;
+      mass_stride = K2;
+    }
     R* const d_direct = direct ? d_phik : nullptr;
     R* const d_direct_mass = direct ? d_mass : nullptr;
     if (NT == 1) {
@@ -895,7 +903,7 @@ hipError_t launch_spatial_generic(const IN* d_in, int nx, int ny, int K, const R
     if (e != hipSuccess || direct) return e;
     if (d_mass_partials != nullptr) {
       EEA_LAUNCH_MAYBE_LAST(true, sum_partials_norm_kernel<R>, dim3((K2 + kModesPerSumBlock - 1) / kModesPerSumBlock),
-                            dim3(kBlock), 0, d_work, col_tiles * row_tiles, K2, d_mass_partials, n_mass, d_phik, d_mass);
+                            dim3(kBlock), 0, d_work, col_tiles * row_tiles, K2, d_mass_partials, n_mass, d_phik, d_mass, mass_stride);
     } else {
       EEA_LAUNCH_MAYBE_LAST(true, sum_partials_kernel<R>, dim3((K2 + kModesPerSumBlock - 1) / kModesPerSumBlock),
                             dim3(kBlock), 0, d_work, col_tiles * row_tiles, K2, R(1), d_phik);
@@ -934,9 +942,12 @@ hipError_t launch_spatial_coeff_normalised(const R* d_phi_raw, int nx, int ny, i
 
 template <typename R>
 hipError_t launch_spatial_coeff_cells(const int8_t* d_occ, int nx, int ny, int K, const R* d_cx,
-                                      const R* d_cy, const R* d_lut, R* d_work, R* d_raw, hipStream_t s)
+                                      const R* d_cy, const R* d_lut, R* d_work, R* d_raw, hipStream_t s, R* d_mass_out)
 {
-  return launch_spatial_generic<R, int8_t>(d_occ, nx, ny, K, d_cx, d_cy, d_lut, d_work, d_raw, s);
+  // d_mass_out != nullptr: d_raw receives the NORMALISED coefficients (sums / mode (0, 0)'s sum, formed in the reduction launch
+  // itself: two launches instead of three), *d_mass_out the normaliser
+  return launch_spatial_generic<R, int8_t>(d_occ, nx, ny, K, d_cx, d_cy, d_lut, d_work, d_raw, s, nullptr, 0, d_mass_out, nullptr,
+                                           d_mass_out != nullptr);
 }
 
 template <typename R>
@@ -989,7 +1000,7 @@ hipError_t launch_point_coeff(const R* d_x, const R* d_y, const R* d_w, unsigned
   template hipError_t launch_spatial_coeff<R>(const R*, int, int, int, const R*, const R*, R*, R*,  \
                                               hipStream_t);                                         \
   template hipError_t launch_spatial_coeff_cells<R>(const int8_t*, int, int, int, const R*,         \
-                                                    const R*, const R*, R*, R*, hipStream_t);       \
+                                                    const R*, const R*, R*, R*, hipStream_t, R*);   \
   template hipError_t launch_normalise_by_first<R>(const R*, int, R*, hipStream_t);                 \
   template hipError_t launch_point_coeff<R>(const R*, const R*, const R*, unsigned, int, R, R, R,   \
                                             R*, R*, hipStream_t);
