@@ -32,6 +32,11 @@ def test_compact_line_of_a_recorded_run_is_small_and_complete(path):
     assert rec["roofline"]["frac"] == pytest.approx(full["roofline"]["achieved"] / full["roofline"]["peak"], rel=1e-4)
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(rec["cpu_baseline"])
     assert "workload" in rec["config"] and "model" not in rec["config"]
+    if "r06" in os.path.basename(path):
+        # round 6: the consensus pass of the packed kernel from the C++ host loop -- one sum record per wavefront first, per agent second
+        pg = rec["exchange"]["packed_gated"]
+        rows = [dict(zip(pg["cols"], r)) for r in pg["rows"]]
+        assert rows[0]["records"] < rows[0]["agents"] == rows[1]["records"] and rows[0]["ratio"] < rows[1]["ratio"]
     sh = rec["short_horizons"]
     assert sh["cols"][:5] == ["config", "agents", "lanes_per_agent", "us_per_4096", "frac"] and len(sh["rows"]) >= 6
     assert all(len(r) == len(sh["cols"]) for r in sh["rows"])
